@@ -1,0 +1,325 @@
+"""blight_amd -- MI355X-native Blight k-mer index (hot path only): Python mirror of the reference's `kmer_Set_Light`.
+
+The product is the C-ABI library blight_amd/libblight_mi355x.so (hand-written HIP for gfx950, include/blight_mi355x.h);
+this module is a thin ctypes binding with the reference's method names, argument meaning and error behaviour
+(reference blight.h:15-136).  There is no CPU fallback: every call that needs the GPU raises when the library or a
+device is missing.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
+
+BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+class blmx_params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("m", C.c_uint32), ("log2_mphf", C.c_uint32), ("log2_superbuckets", C.c_uint32),
+                ("threads", C.c_uint32), ("bits_saved", C.c_uint32), ("kmer_bytes", C.c_uint32), ("device", C.c_int32)]
+
+
+class blmx_stats_t(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("number_kmer", "number_super_kmer", "largest_mphf", "positions_total_size",
+                                          "number_query", "total_nt", "largest_bucket", "mphf_bytes", "fallback_keys",
+                                          "device_bytes")] + \
+               [(n, C.c_uint32) for n in ("nbuckets", "ngroups", "k", "m", "log2_mphf", "bits_saved", "kmer_bytes",
+                                          "max_levels_used")] + [("build_seconds", C.c_double)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libblight_mi355x.so (fails loudly when it has not been built: `python -m blight_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libblight_mi355x.so is missing: run `python -m blight_amd.build` (hipcc, gfx950)")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same soname); whichever is loaded first is shared.
+    # Import torch first when it is available so that torch tensors / streams and this library use the same runtime.
+    if "torch" not in sys.modules and os.environ.get("BLIGHT_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional plumbing
+            pass
+    lib = C.CDLL(LIB_PATH)
+    lib.blmx_version.restype = C.c_char_p
+    lib.blmx_create_error.restype = C.c_char_p
+    lib.blmx_last_error.restype = C.c_char_p
+    lib.blmx_last_error.argtypes = [C.c_void_p]
+    lib.blmx_create.argtypes = [C.POINTER(blmx_params), C.POINTER(C.c_void_p)]
+    lib.blmx_destroy.argtypes = [C.c_void_p]
+    lib.blmx_build_from_fasta.argtypes = [C.c_void_p, C.c_char_p]
+    lib.blmx_build_from_sequences.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64]
+    lib.blmx_build_from_device_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+    lib.blmx_query_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _i64p]
+    lib.blmx_query_kmers_with_minimizer.argtypes = [C.c_void_p, C.c_void_p, _u32p, C.c_uint64, _i64p]
+    lib.blmx_query_positions.argtypes = [C.c_void_p, C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_int32)]
+    lib.blmx_query_membership.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8)]
+    lib.blmx_query_sequences.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _i64p]
+    lib.blmx_sequence_kmer_count.argtypes = [C.c_void_p, _u64p, C.c_uint64]
+    lib.blmx_sequence_kmer_count.restype = C.c_uint64
+    lib.blmx_query_kmers_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.blmx_kmer_groups_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
+    lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+    lib.blmx_export.restype = C.c_int64
+    lib.blmx_primitive.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class BlightError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (blmx status %d)" % (msg, code))
+        self.code = code
+
+
+def _raise(code, msg):
+    # the reference's exception types: std::invalid_argument -> ValueError, std::domain_error -> ValueError,
+    # std::runtime_error (file) -> OSError
+    if code == BLMX_EINVAL:
+        raise ValueError(msg)
+    if code == BLMX_EDNA:
+        raise ValueError(msg or "Invalid char in DNA")
+    if code == BLMX_EIO:
+        raise OSError(msg or "Problem with files opening")
+    raise BlightError(code, msg)
+
+
+def _kmers_array(kmers, kmer_bytes):
+    """ints / uint64 array -> contiguous little-endian array of kmer_bytes per k-mer"""
+    if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint64:
+        a = np.ascontiguousarray(kmers)
+        return a, a.size // (kmer_bytes // 8)
+    kl = [int(x) for x in (kmers if hasattr(kmers, "__iter__") else [kmers])]
+    if kmer_bytes == 8:
+        return np.array(kl, dtype=np.uint64), len(kl)
+    a = np.empty((len(kl), 2), dtype=np.uint64)
+    for i, x in enumerate(kl):
+        a[i, 0] = x & 0xFFFFFFFFFFFFFFFF
+        a[i, 1] = x >> 64
+    return a, len(kl)
+
+
+def _concat(seqs):
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    return b"".join(bs), offs
+
+
+EXPORT = {"bucket_nt": (0, np.uint32), "bucket_start": (1, np.uint64), "seq": (2, np.uint64), "positions": (3, np.uint64),
+          "g_nkeys": (4, np.uint64), "g_prefix": (5, np.uint64), "g_posstart": (6, np.uint64), "g_nbits": (7, np.uint32),
+          "level_sizes": (8, np.uint64), "g_wbase": (9, np.uint64), "mphf_bits": (10, np.uint64), "fb_keys": (11, np.uint64),
+          "fb_ranks": (12, np.uint64), "fb_group": (13, np.uint32)}
+
+
+class kmer_Set_Light:
+    """Drop-in mirror of the reference class (blight.h:15-136).  Scalars keep the reference's per-k-mer signatures; every
+    query method also accepts a batch (sequence / uint64 array) and then returns a numpy array."""
+
+    def __init__(self, k, minimizer_length, log2_mphfs_number, log2_superbuckets_number, cores_number, bits_to_save,
+                 device=0, kmer_bytes=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        p = blmx_params(k, minimizer_length, log2_mphfs_number, log2_superbuckets_number, cores_number, bits_to_save,
+                        kmer_bytes, device)
+        rc = self._lib.blmx_create(C.byref(p), C.byref(self._h))
+        if rc:
+            self._h = None
+            _raise(rc, self._lib.blmx_create_error().decode())
+        self._k, self._minimizer_length = k, minimizer_length
+        self.kmer_bytes = kmer_bytes or (8 if k <= 32 else 16)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.blmx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            _raise(rc, self._lib.blmx_last_error(self._h).decode())
+
+    # -- construction (blight.cpp:108-125)
+    def construct_index(self, input_file):
+        self._check(self._lib.blmx_build_from_fasta(self._h, os.fsencode(input_file)))
+
+    def construct_index_from_sequences(self, seqs):
+        buf, offs = _concat(seqs)
+        self._check(self._lib.blmx_build_from_sequences(self._h, buf, offs.ctypes.data_as(_u64p), len(offs) - 1))
+
+    def construct_index_from_device(self, d_concat_ptr, d_offsets_ptr, nseq, total_len):
+        self._check(self._lib.blmx_build_from_device_sequences(self._h, d_concat_ptr, d_offsets_ptr, nseq, total_len))
+
+    # -- counters (blight.h:52-59)
+    def stats(self):
+        st = blmx_stats_t()
+        self._check(self._lib.blmx_stats(self._h, C.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in blmx_stats_t._fields_}
+
+    number_kmer = property(lambda self: self.stats()["number_kmer"])
+    number_super_kmer = property(lambda self: self.stats()["number_super_kmer"])
+    largest_MPHF = property(lambda self: self.stats()["largest_mphf"])
+    number_query = property(lambda self: self.stats()["number_query"])
+    positions_total_size = property(lambda self: self.stats()["positions_total_size"])
+
+    # -- queries
+    def query_kmer_hash(self, canon):
+        """blight.cpp:545-550; scalar int -> int, batch -> int64 array"""
+        scalar = not hasattr(canon, "__iter__")
+        a, nq = _kmers_array(canon, self.kmer_bytes)
+        out = np.empty(nq, dtype=np.int64)
+        self._check(self._lib.blmx_query_kmers(self._h, a.ctypes.data, nq, out.ctypes.data_as(_i64p)))
+        return int(out[0]) if scalar else out
+
+    def query_kmer_bool(self, canon):
+        """blight.cpp:537-541"""
+        scalar = not hasattr(canon, "__iter__")
+        a, nq = _kmers_array(canon, self.kmer_bytes)
+        out = np.empty(nq, dtype=np.uint8)
+        self._check(self._lib.blmx_query_membership(self._h, a.ctypes.data, nq, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return bool(out[0]) if scalar else out.astype(bool)
+
+    def query_get_hash(self, canon, minimizer):
+        """blight.cpp:716-742"""
+        scalar = not hasattr(canon, "__iter__")
+        a, nq = _kmers_array(canon, self.kmer_bytes)
+        mi = np.ascontiguousarray(np.atleast_1d(minimizer), dtype=np.uint32)
+        out = np.empty(nq, dtype=np.int64)
+        self._check(self._lib.blmx_query_kmers_with_minimizer(self._h, a.ctypes.data, mi.ctypes.data_as(_u32p), nq,
+                                                              out.ctypes.data_as(_i64p)))
+        return int(out[0]) if scalar else out
+
+    def query_get_pos_unitig(self, canon, minimizer):
+        """blight.cpp:686-712"""
+        scalar = not hasattr(canon, "__iter__")
+        a, nq = _kmers_array(canon, self.kmer_bytes)
+        mi = np.ascontiguousarray(np.atleast_1d(minimizer), dtype=np.uint32)
+        out = np.empty(nq, dtype=np.int32)
+        self._check(self._lib.blmx_query_positions(self._h, a.ctypes.data, mi.ctypes.data_as(_u32p), nq,
+                                                   out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return int(out[0]) if scalar else out
+
+    def single_query(self, minimizer, kastor):
+        """blight.cpp:658-660"""
+        r = self.query_get_pos_unitig(kastor, minimizer)
+        return (r >= 0) if not hasattr(r, "__iter__") else (r >= 0)
+
+    def query_sequences_hash(self, seqs):
+        """query_sequence_hash over many sequences in one launch; returns one flat int64 array"""
+        buf, offs = _concat(seqs)
+        nk = self._lib.blmx_sequence_kmer_count(self._h, offs.ctypes.data_as(_u64p), len(offs) - 1)
+        out = np.empty(nk, dtype=np.int64)
+        self._check(self._lib.blmx_query_sequences(self._h, buf, offs.ctypes.data_as(_u64p), len(offs) - 1,
+                                                   out.ctypes.data_as(_i64p)))
+        return out
+
+    def query_sequence_hash(self, query):
+        """blight.cpp:575-591"""
+        return self.query_sequences_hash([query])
+
+    def query_sequence_bool(self, query):
+        """blight.cpp:554-571 -> (found, not found)"""
+        ids = self.query_sequences_hash([query])
+        found = int((ids >= 0).sum())
+        return found, int(ids.size - found)
+
+    def file_query(self, query_file, batch=512):
+        """blight.cpp:746-799: reads 2-line FASTA records, skips sequences shorter than k, prints the recap."""
+        import gzip
+        import time
+        t0 = time.time()
+        tp = fp = 0
+        opener = gzip.open if open(query_file, "rb").read(2) == b"\x1f\x8b" else open
+        seqs = []
+
+        def flush():
+            nonlocal tp, fp
+            if seqs:
+                ids = self.query_sequences_hash(seqs)
+                f = int((ids >= 0).sum())
+                tp += f
+                fp += int(ids.size - f)
+                seqs.clear()
+
+        with opener(query_file, "rb") as fh:
+            lines = iter(fh)
+            for hdr in lines:
+                if hdr.rstrip(b"\n") == b"":
+                    next(lines, None)
+                    continue
+                seq = next(lines, b"").rstrip(b"\n")
+                if not seq:
+                    continue
+                if len(seq) >= self._k:
+                    seqs.append(seq)
+                if len(seqs) >= batch:
+                    flush()
+        flush()
+        print("-----------------------QUERY RECAP 2----------------------------")
+        print("Good kmer: %d" % tp)
+        print("Erroneous kmers: %d" % fp)
+        print("Query performed: %d" % self.number_query)
+        print("The whole QUERY took me %g seconds." % (time.time() - t0))
+        return tp, fp
+
+    # -- device-resident batch API (bench / pipelines): raw device pointers + hipStream_t
+    def query_kmers_device(self, d_kmers_ptr, nq, d_ids_ptr, stream=None):
+        self._check(self._lib.blmx_query_kmers_device(self._h, d_kmers_ptr, nq, d_ids_ptr, stream))
+
+    def kmer_groups_device(self, d_kmers_ptr, nq, d_groups_ptr, stream=None):
+        self._check(self._lib.blmx_kmer_groups_device(self._h, d_kmers_ptr, nq, d_groups_ptr, stream))
+
+    # -- array export (tests)
+    def export(self, name):
+        which, dt = EXPORT[name]
+        n = self._lib.blmx_export(self._h, which, None, 0)
+        if n < 0:
+            _raise(int(n), self._lib.blmx_last_error(self._h).decode())
+        width = (self.kmer_bytes // 8) if name == "fb_keys" else 1
+        out = np.zeros(int(n) * width, dtype=dt)
+        if n:
+            r = self._lib.blmx_export(self._h, which, out.ctypes.data, int(n))
+            if r < 0:
+                _raise(int(r), self._lib.blmx_last_error(self._h).decode())
+        return out
+
+
+def primitive(op, data, arg=0, arg2=0, kmer_bytes=8):
+    """device KAT entry point (tests): see blmx_primitive in include/blight_mi355x.h"""
+    lib = load_library()
+    a = np.ascontiguousarray(data)
+    in_elem = 4 if op <= 2 else (kmer_bytes if op in (3, 4) else (8 if op == 5 else 1))
+    n = a.nbytes // in_elem
+    if op in (0,):
+        out = np.empty(n, np.int32)
+    elif op in (1, 2, 4):
+        out = np.empty(n, np.uint32)
+    elif op == 3:
+        out = np.empty(n * (kmer_bytes // 8), np.uint64)
+    elif op == 5:
+        out = np.empty((n, 16), np.uint64)
+    else:
+        out = np.empty(n, np.uint8)
+    rc = lib.blmx_primitive(op, kmer_bytes, a.ctypes.data, n, arg, arg2, out.ctypes.data)
+    if rc:
+        _raise(rc, "blmx_primitive failed")
+    return out

@@ -1,0 +1,519 @@
+// blmx_api.hip -- the C ABI of include/blight_mi355x.h: parameter validation (reference blight.h:75-92), the host FASTA
+// reader (reference blight.cpp:212-229; I/O is host work), staging of host buffers, and dispatch to the HIP build and
+// query paths.  No exception crosses the ABI; there is no CPU compute path.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "blmx_internal.h"
+
+using namespace blmx;
+
+struct blmx_index {
+	Index ix;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(blmx_index* h, int code, const std::string& msg)
+{
+	if (h)
+		h->ix.err = msg;
+	return code;
+}
+
+template <typename F> int guarded(blmx_index* h, F&& f)
+{
+	try {
+		f();
+		return BLMX_OK;
+	} catch (const StatusError& e) {
+		return fail(h, e.code, e.msg);
+	} catch (const std::bad_alloc&) {
+		return fail(h, BLMX_ENOMEM, "host allocation failed");
+	} catch (const std::exception& e) {
+		return fail(h, BLMX_EHIP, e.what());
+	}
+}
+
+// 2-line FASTA reader, blight.cpp:212-229: read a header line; if it is empty, swallow one more line and start over;
+// read the sequence line; skip it if empty.  gzopen reads plain and gzip transparently (the reference uses zstr).
+bool read_line(gzFile f, std::string& line)
+{
+	line.clear();
+	char buf[1 << 16];
+	bool got = false;
+	while (gzgets(f, buf, (int)sizeof buf)) {
+		got = true;
+		const size_t n = strlen(buf);
+		if (n && buf[n - 1] == '\n') {
+			line.append(buf, n - 1);
+			return true;
+		}
+		line.append(buf, n);
+	}
+	return got;
+}
+
+int read_fasta(const char* path, std::string& concat, std::vector<uint64_t>& offs)
+{
+	gzFile f = gzopen(path, "rb");
+	if (!f)
+		return BLMX_EIO;
+	gzbuffer(f, 1 << 20);
+	std::string line;
+	offs.assign(1, 0);
+	for (;;) {
+		if (!read_line(f, line))
+			break;
+		if (line.empty()) {
+			if (!read_line(f, line))
+				break;
+			continue;
+		}
+		if (!read_line(f, line))
+			break;
+		if (line.empty())
+			continue;
+		concat += line;
+		offs.push_back(concat.size());
+	}
+	gzclose(f);
+	return BLMX_OK;
+}
+
+void ensure(DevBuf& b, size_t bytes, hipStream_t s)
+{
+	if (bytes > b.bytes)
+		BLMX_HIP(b.alloc(bytes + bytes / 4 + 256, false, s));
+}
+
+void build_host(blmx_index* h, const char* concat, const uint64_t* offsets, uint64_t nseq)
+{
+	Index& ix = h->ix;
+	if (ix.built)
+		throw StatusError{BLMX_ESTATE, "index already built"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	const uint64_t total = nseq ? offsets[nseq] : 0;
+	if (nseq && offsets[0] != 0)
+		throw StatusError{BLMX_EINVAL, "offsets[0] must be 0"};
+	DevBuf d_ascii, d_offs;
+	BLMX_HIP(d_ascii.alloc(total + 64, false, ix.stream));
+	BLMX_HIP(d_offs.alloc((nseq + 1) * 8, true, ix.stream));
+	if (total)
+		BLMX_HIP(hipMemcpyAsync(d_ascii.p, concat, total, hipMemcpyHostToDevice, ix.stream));
+	if (nseq)
+		BLMX_HIP(hipMemcpyAsync(d_offs.p, offsets, (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
+	build_from_device(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), nseq, total);
+	ix.built = true;
+}
+
+// host-buffer query: stage in, run, stage out
+void query_host(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode)
+{
+	Index& ix = h->ix;
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	if (nq == 0)
+		return;
+	std::lock_guard<std::mutex> lock(ix.mu);
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	const size_t kb = (size_t)ix.KW * 8;
+	const size_t ob = mode == kQueryIds ? 8 : (mode == kQueryPos ? 4 : 1);
+	ensure(ix.q_in, nq * kb, ix.stream);
+	ensure(ix.q_out, nq * ob, ix.stream);
+	BLMX_HIP(hipMemcpyAsync(ix.q_in.p, kmers, nq * kb, hipMemcpyHostToDevice, ix.stream));
+	const uint32_t* d_minis = nullptr;
+	if (minis) {
+		ensure(ix.q_aux, nq * 4, ix.stream);
+		BLMX_HIP(hipMemcpyAsync(ix.q_aux.p, minis, nq * 4, hipMemcpyHostToDevice, ix.stream));
+		d_minis = ix.q_aux.as<uint32_t>();
+	}
+	launch_query(ix, ix.q_in.p, d_minis, nq, ix.q_out.p, mode, ix.stream);
+	BLMX_HIP(hipMemcpyAsync(out, ix.q_out.p, nq * ob, hipMemcpyDeviceToHost, ix.stream));
+	BLMX_HIP(hipStreamSynchronize(ix.stream));
+	ix.st.number_query += nq;  // blight.cpp:717-718
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* blmx_version(void) { return "blight-mi355x 0.1 (gfx950)"; }
+const char* blmx_create_error(void) { return g_create_err.c_str(); }
+const char* blmx_last_error(const blmx_index* ix) { return ix ? ix->ix.err.c_str() : g_create_err.c_str(); }
+
+int blmx_create(const blmx_params* p, blmx_index** out)
+{
+	if (out)
+		*out = nullptr;
+	if (!p || !out) {
+		g_create_err = "null argument";
+		return BLMX_EINVAL;
+	}
+	blmx_params prm = *p;
+	if (prm.kmer_bytes == 0)
+		prm.kmer_bytes = prm.k <= 32 ? 8 : 16;
+	if (prm.kmer_bytes != 8 && prm.kmer_bytes != 16) {
+		g_create_err = "kmer_bytes must be 8 or 16";
+		return BLMX_EINVAL;
+	}
+	// ctor checks and messages of the reference, blight.h:75-92
+	const char* msg = nullptr;
+	if (prm.k > prm.kmer_bytes * 4)
+		msg = "kmer size too large";
+	else if ((prm.m & 1) == 0)
+		msg = "minimizer_length must be odd";
+	else if (prm.m > 16)
+		msg = "minimizer_length size too large";
+	else if (prm.log2_mphf > 2 * prm.m - 1)
+		msg = "log2_mphfs_number must not be larger than 2*minimizer_length - 1";
+	else if (prm.log2_superbuckets > prm.log2_mphf)
+		msg = "log2_superbuckets_number must not be larger than log2_mphfs_number";
+	// limits of this implementation (outside the reference's own usable range: SURVEY D-3)
+	else if (prm.k < prm.m || prm.k < 2)
+		msg = "k must be at least max(2, minimizer_length)";
+	else if (prm.kmer_bytes == 16 && prm.k > 63)
+		msg = "kmer size too large";
+	else if (prm.bits_saved > 20)
+		msg = "bits_to_save must be at most 20";
+	if (msg) {
+		g_create_err = msg;
+		return BLMX_EINVAL;
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		g_create_err = "no HIP device: the Blight MI355X path has no CPU fallback";
+		return BLMX_EHIP;
+	}
+	if (prm.device < 0 || prm.device >= ndev) {
+		g_create_err = "invalid device ordinal";
+		return BLMX_EINVAL;
+	}
+	blmx_index* h = new (std::nothrow) blmx_index();
+	if (!h) {
+		g_create_err = "host allocation failed";
+		return BLMX_ENOMEM;
+	}
+	h->ix.prm = prm;
+	h->ix.KW = (int)prm.kmer_bytes / 8;
+	h->ix.gshift = (int)(2 * prm.m - 1 - prm.log2_mphf);
+	h->ix.nbuckets = 1u << (2 * prm.m - 1);
+	h->ix.ngroups = 1u << prm.log2_mphf;
+	if (hipSetDevice(prm.device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
+		g_create_err = "hipStreamCreate failed";
+		delete h;
+		return BLMX_EHIP;
+	}
+	*out = h;
+	return BLMX_OK;
+}
+
+void blmx_destroy(blmx_index* h)
+{
+	if (!h)
+		return;
+	(void)hipSetDevice(h->ix.prm.device);
+	if (h->ix.stream) {
+		(void)hipStreamSynchronize(h->ix.stream);
+		(void)hipStreamDestroy(h->ix.stream);
+	}
+	delete h;
+}
+
+int blmx_build_from_fasta(blmx_index* h, const char* path)
+{
+	if (!h || !path)
+		return BLMX_EINVAL;
+	std::string concat;
+	std::vector<uint64_t> offs;
+	const int rc = read_fasta(path, concat, offs);
+	if (rc)
+		return fail(h, rc, "Problem with files opening");  // blight.cpp:188-189
+	return guarded(h, [&] { build_host(h, concat.data(), offs.data(), offs.size() - 1); });
+}
+
+int blmx_build_from_sequences(blmx_index* h, const char* concat, const uint64_t* offsets, uint64_t nseq)
+{
+	if (!h || (nseq && (!concat || !offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { build_host(h, concat, offsets, nseq); });
+}
+
+int blmx_build_from_device_sequences(blmx_index* h, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq, uint64_t total_len)
+{
+	if (!h || (nseq && (!d_concat || !d_offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		if (h->ix.built)
+			throw StatusError{BLMX_ESTATE, "index already built"};
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		build_from_device(h->ix, reinterpret_cast<const uint8_t*>(d_concat), d_offsets, nseq, total_len);
+		h->ix.built = true;
+	});
+}
+
+int blmx_query_kmers(blmx_index* h, const void* kmers, uint64_t nq, int64_t* ids_out)
+{
+	if (!h || (nq && (!kmers || !ids_out)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { query_host(h, kmers, nullptr, nq, ids_out, kQueryIds); });
+}
+
+int blmx_query_kmers_with_minimizer(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_t nq, int64_t* ids_out)
+{
+	if (!h || (nq && (!kmers || !ids_out || !minis)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { query_host(h, kmers, minis, nq, ids_out, kQueryIds); });
+}
+
+int blmx_query_positions(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_t nq, int32_t* pos_out)
+{
+	if (!h || (nq && (!kmers || !pos_out || !minis)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { query_host(h, kmers, minis, nq, pos_out, kQueryPos); });
+}
+
+int blmx_query_membership(blmx_index* h, const void* kmers, uint64_t nq, uint8_t* present_out)
+{
+	if (!h || (nq && (!kmers || !present_out)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { query_host(h, kmers, nullptr, nq, present_out, kQueryBool); });
+}
+
+uint64_t blmx_sequence_kmer_count(const blmx_index* h, const uint64_t* offsets, uint64_t nseq)
+{
+	if (!h || !offsets)
+		return 0;
+	const uint64_t k = h->ix.prm.k;
+	uint64_t n = 0;
+	for (uint64_t i = 0; i < nseq; i++) {
+		const uint64_t len = offsets[i + 1] - offsets[i];
+		if (len >= k)
+			n += len - k + 1;
+	}
+	return n;
+}
+
+int blmx_query_sequences(blmx_index* h, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out)
+{
+	if (!h || (nseq && (!concat || !offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		Index& ix = h->ix;
+		if (!ix.built)
+			throw StatusError{BLMX_ESTATE, "index not built"};
+		const uint64_t k = ix.prm.k;
+		std::vector<uint64_t> koffs(nseq + 1, 0);
+		for (uint64_t i = 0; i < nseq; i++) {
+			const uint64_t len = offsets[i + 1] - offsets[i];
+			koffs[i + 1] = koffs[i] + (len >= k ? len - k + 1 : 0);  // blight.cpp:577-579: shorter than k -> nothing
+		}
+		const uint64_t nk = koffs[nseq];
+		if (nk == 0)
+			return;
+		if (!ids_out)
+			throw StatusError{BLMX_EINVAL, "ids_out is null"};
+		std::lock_guard<std::mutex> lock(ix.mu);
+		BLMX_HIP(hipSetDevice(ix.prm.device));
+		hipStream_t s = ix.stream;
+		const uint64_t total = offsets[nseq];
+		DevBuf d_ascii, d_offs, d_koffs, d_err;
+		BLMX_HIP(d_ascii.alloc(total + 64, false, s));
+		BLMX_HIP(d_offs.alloc((nseq + 1) * 8, false, s));
+		BLMX_HIP(d_koffs.alloc((nseq + 1) * 8, false, s));
+		BLMX_HIP(d_err.alloc(4, true, s));
+		BLMX_HIP(hipMemcpyAsync(d_ascii.p, concat, total, hipMemcpyHostToDevice, s));
+		BLMX_HIP(hipMemcpyAsync(d_offs.p, offsets, (nseq + 1) * 8, hipMemcpyHostToDevice, s));
+		BLMX_HIP(hipMemcpyAsync(d_koffs.p, koffs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, s));
+		ensure(ix.q_in, nk * 8 * (size_t)ix.KW, s);
+		ensure(ix.q_out, nk * 8, s);
+		launch_sequence_kmers(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), d_koffs.as<uint64_t>(), nseq, nk, ix.q_in.p,
+		                      d_err.as<int>(), s);
+		launch_query(ix, ix.q_in.p, nullptr, nk, ix.q_out.p, kQueryIds, s);
+		int e = 0;
+		BLMX_HIP(hipMemcpyAsync(&e, d_err.p, 4, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipMemcpyAsync(ids_out, ix.q_out.p, nk * 8, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+		if (e)
+			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
+		ix.st.number_query += nk;
+	});
+}
+
+int blmx_query_kmers_device(blmx_index* h, const void* d_kmers, uint64_t nq, int64_t* d_ids, void* stream)
+{
+	if (!h || (nq && (!d_kmers || !d_ids)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		if (!h->ix.built)
+			throw StatusError{BLMX_ESTATE, "index not built"};
+		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		launch_query(h->ix, d_kmers, nullptr, nq, d_ids, kQueryIds, s);
+		if (!stream)
+			BLMX_HIP(hipStreamSynchronize(s));
+		h->ix.st.number_query += nq;
+	});
+}
+
+int blmx_kmer_groups_device(blmx_index* h, const void* d_kmers, uint64_t nq, uint32_t* d_groups, void* stream)
+{
+	if (!h || (nq && (!d_kmers || !d_groups)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		launch_kmer_groups(h->ix, d_kmers, nq, d_groups, s);
+		if (!stream)
+			BLMX_HIP(hipStreamSynchronize(s));
+	});
+}
+
+int blmx_stats(const blmx_index* h, blmx_stats_t* out)
+{
+	if (!h || !out)
+		return BLMX_EINVAL;
+	*out = h->ix.st;
+	out->nbuckets = h->ix.nbuckets;
+	out->ngroups = h->ix.ngroups;
+	out->k = h->ix.prm.k;
+	out->m = h->ix.prm.m;
+	out->log2_mphf = h->ix.prm.log2_mphf;
+	out->bits_saved = h->ix.prm.bits_saved;
+	out->kmer_bytes = h->ix.prm.kmer_bytes;
+	return BLMX_OK;
+}
+
+int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
+{
+	if (!h || !h->ix.built)
+		return BLMX_ESTATE;
+	Index& ix = h->ix;
+	int64_t result = -1;
+	const int rc = guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(ix.prm.device));
+		hipStream_t s = ix.stream;
+		auto copy_out = [&](const void* src, size_t elem, uint64_t avail) {
+			result = (int64_t)avail;
+			if (out && avail)
+				memcpy(out, src, elem * (size_t)std::min<uint64_t>(avail, cap));
+		};
+		auto dev_out = [&](const void* dsrc, size_t elem, uint64_t avail) {
+			result = (int64_t)avail;
+			const uint64_t n = std::min<uint64_t>(avail, cap);
+			if (out && n) {
+				BLMX_HIP(hipMemcpyAsync(out, dsrc, elem * n, hipMemcpyDeviceToHost, s));
+				BLMX_HIP(hipStreamSynchronize(s));
+			}
+		};
+		const uint32_t ng = ix.ngroups;
+		switch (which) {
+		case 0:
+		case 1: {
+			std::vector<BucketDesc> hb(ix.nbuckets);
+			BLMX_HIP(hipMemcpyAsync(hb.data(), ix.buckets.p, hb.size() * sizeof(BucketDesc), hipMemcpyDeviceToHost, s));
+			BLMX_HIP(hipStreamSynchronize(s));
+			if (which == 0) {
+				std::vector<uint32_t> v(ix.nbuckets);
+				for (uint32_t i = 0; i < ix.nbuckets; i++)
+					v[i] = hb[i].nt;
+				copy_out(v.data(), 4, v.size());
+			} else {
+				std::vector<uint64_t> v(ix.nbuckets);
+				for (uint32_t i = 0; i < ix.nbuckets; i++)
+					v[i] = hb[i].start;
+				copy_out(v.data(), 8, v.size());
+			}
+			break;
+		}
+		case 2:
+			dev_out(ix.seq.p, 8, (ix.st.total_nt + 31) / 32);
+			break;
+		case 3:
+			dev_out(ix.positions.p, 8, (ix.st.positions_total_size + 63) / 64);
+			break;
+		case 4:
+		case 5:
+		case 6:
+		case 9: {
+			std::vector<uint64_t> v(ng + (which == 9 ? 1 : 0));
+			for (uint32_t g = 0; g < ng; g++)
+				v[g] = which == 4 ? ix.h_groups[g].nkeys : which == 5 ? ix.h_groups[g].prefix : which == 6 ? ix.h_groups[g].posstart
+				                                                                                        : ix.h_groups[g].wbase;
+			if (which == 9)
+				v[ng] = ix.total_logical_words;
+			copy_out(v.data(), 8, v.size());
+			break;
+		}
+		case 7: {
+			std::vector<uint32_t> v(ng);
+			for (uint32_t g = 0; g < ng; g++)
+				v[g] = ix.h_groups[g].nbits;
+			copy_out(v.data(), 4, v.size());
+			break;
+		}
+		case 8: {
+			std::vector<uint64_t> v((size_t)ng * kLevels);
+			for (uint32_t g = 0; g < ng; g++)
+				for (int l = 0; l < kLevels; l++)
+					v[(size_t)g * kLevels + l] = ix.h_groups[g].nkeys ? ix.h_groups[g].size[l] : 0;
+			copy_out(v.data(), 8, v.size());
+			break;
+		}
+		case 10: {  // logical level bit arrays: strip the rank word of every 64-B line
+			std::vector<uint64_t> hl((size_t)ix.total_lines * kLineWords);
+			if (!hl.empty()) {
+				BLMX_HIP(hipMemcpyAsync(hl.data(), ix.lines.p, hl.size() * 8, hipMemcpyDeviceToHost, s));
+				BLMX_HIP(hipStreamSynchronize(s));
+			}
+			std::vector<uint64_t> v((size_t)ix.total_logical_words);
+			for (uint32_t g = 0; g < ng; g++) {
+				const GroupDesc& gd = ix.h_groups[g];
+				for (uint64_t w = 0; w < gd.nwords; w++)
+					v[gd.wbase + w] = hl[(gd.line_base + w / kLineData) * kLineWords + 1 + w % kLineData];
+			}
+			copy_out(v.data(), 8, v.size());
+			break;
+		}
+		case 11:
+			dev_out(ix.fb_keys.p, 8 * (size_t)ix.KW, ix.st.fallback_keys);
+			break;
+		case 12:
+			dev_out(ix.fb_ranks.p, 8, ix.st.fallback_keys);
+			break;
+		case 13:
+			copy_out(ix.h_fb_group.data(), 4, ix.h_fb_group.size());
+			break;
+		default:
+			throw StatusError{BLMX_EINVAL, "unknown export id"};
+		}
+	});
+	return rc ? rc : result;
+}
+
+int blmx_primitive(int op, int kmer_bytes, const void* in, uint64_t n, int arg, int arg2, void* out)
+{
+	if (!in || !out || (kmer_bytes != 8 && kmer_bytes != 16) || op < 0 || op > 6)
+		return BLMX_EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+		return BLMX_EHIP;
+	return guarded(nullptr, [&] {
+		const size_t in_elem = (op <= 2) ? 4 : (op == 3 || op == 4) ? (size_t)kmer_bytes : (op == 5 ? 8 : 1);
+		const size_t out_elem = (op == 0 || op == 1 || op == 2 || op == 4) ? 4 : (op == 3 ? (size_t)kmer_bytes : (op == 5 ? 8 * kLevels : 1));
+		DevBuf d_in, d_out;
+		BLMX_HIP(d_in.alloc(n * in_elem + 16, false, nullptr));
+		BLMX_HIP(d_out.alloc(n * out_elem + 16, false, nullptr));
+		BLMX_HIP(hipMemcpy(d_in.p, in, n * in_elem, hipMemcpyHostToDevice));
+		launch_primitive(op, kmer_bytes / 8, d_in.p, n, arg, arg2, d_out.p, nullptr);
+		BLMX_HIP(hipDeviceSynchronize());
+		BLMX_HIP(hipMemcpy(out, d_out.p, n * out_elem, hipMemcpyDeviceToHost));
+	});
+}
+
+}  // extern "C"

@@ -1,0 +1,1051 @@
+// blmx_build.hip -- gfx950 index construction (reference construct_index, blight.cpp:108-125).
+//
+// The reference streams unitigs through a per-thread chopper, shuffles super-k-mers through gzip temp files and builds
+// one MPHF after the other.  Here the whole input is resident in HBM and every phase is a data-parallel kernel:
+//
+//   K1  k_mark_starts / k_encode_pack   ASCII -> 2-bit packed source (nuc2int, kmer.h:56-69) + unitig-start bitmap
+//   K2  k_superkmer_flags               per k-mer minimizer (kmer.h:791-810) ; super-k-mer head / end bitmaps via wave
+//                                       ballot (a super-k-mer = maximal run of equal minimizer VALUE, kmer.h:654-693)
+//   K3  scan + k_collect / k_sk_minis   compact super-k-mers: (source position, #k-mers, minimizer)
+//   K4  radix sort by minimizer (stable: bucket order = unitig file order then offset, as the reference at t=1) ;
+//       scans -> global nt / key offsets ; bucket table ; group table (blight.cpp:259-306)
+//   K5  k_scatter_pack                  super-k-mers -> bucketSeq (str2bool, blight.cpp:311-324)
+//   K6  k_expand_keys                   canonical k-mer of every valid position, in (bucket, position) order (:421-451)
+//   K7  k_mphf_mark / k_mphf_survive    BBHash levels for ALL groups at once (bbhash.h:677-709): atomicOr test-and-set,
+//                                       collision bitmap, survivors compacted with wave-aggregated appends
+//   K8  k_line_popc / scan / k_line_write  clear collisions (bbhash.h:358-368) + ranks (bbhash.h:447-465) -> 64-B lines
+//   K9  fallback table (bbhash.h:711-728) ; k_fill_positions (blight.cpp:486-519)
+//
+// All build-time atomics are ORs into zeroed arrays or order-independent appends that are sorted afterwards, so the
+// finished index is bit-for-bit reproducible.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "blmx_internal.h"
+#include "index_device.h"
+
+namespace blmx {
+
+namespace {
+
+constexpr unsigned kBlock = 256;
+inline unsigned grid_for(uint64_t n, unsigned block = kBlock) { return (unsigned)std::max<uint64_t>(1, (n + block - 1) / block); }
+
+enum BuildErr : int { kErrShort = 1, kErrDna = 2, kErrLimit = 4 };
+
+// ---- K1 ----------------------------------------------------------------------------------------------------------------
+__global__ void k_mark_starts(const uint64_t* __restrict__ offs, uint64_t nseq, int k, unsigned long long* __restrict__ ustart,
+                              int* __restrict__ err)
+{
+	const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (u >= nseq)
+		return;
+	const uint64_t a = offs[u], b = offs[u + 1];
+	if (b < a + (uint64_t)k)
+		atomicOr(err, kErrShort);
+	atomicOr(&ustart[a >> 6], 1ull << (a & 63));
+}
+
+// 32 nt -> one u64, first nt most significant.  Full words are read as two 16-B loads when the buffer is 16-B aligned.
+template <bool ALIGNED>
+__global__ void k_encode_pack(const uint8_t* __restrict__ ascii, uint64_t total_len, uint64_t nwords, uint64_t* __restrict__ src,
+                              int* __restrict__ err)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords)
+		return;
+	const uint64_t p0 = w * 32;
+	uint64_t word = 0;
+	bool bad = false;
+	if (ALIGNED && p0 + 32 <= total_len) {
+		const uint4* q = reinterpret_cast<const uint4*>(ascii + p0);
+		const uint4 a = q[0], b = q[1];
+		const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const uint32_t c = nuc_code((uint8_t)(v[i] >> (8 * t)));
+				bad |= c > 3;
+				word = (word << 2) | (c & 3u);
+			}
+		}
+	} else {
+		for (int t = 0; t < 32; t++) {
+			const uint64_t p = p0 + t;
+			uint32_t c = 0;
+			if (p < total_len) {
+				c = nuc_code(ascii[p]);
+				bad |= c > 3;
+			}
+			word = (word << 2) | (c & 3u);
+		}
+	}
+	if (bad)
+		atomicOr(err, kErrDna);
+	src[w] = word;
+}
+
+// ---- K2 ----------------------------------------------------------------------------------------------------------------
+// bits of the LSB-first bitmap U at positions q .. q+63
+__device__ __forceinline__ uint64_t bitmap_window(const unsigned long long* __restrict__ U, uint64_t q)
+{
+	const uint64_t w = q >> 6;
+	const uint32_t s = (uint32_t)q & 63u;
+	const uint64_t lo = U[w], hi = U[w + 1];
+	return s ? ((lo >> s) | (hi << (64 - s))) : lo;
+}
+
+// One lane per source position q in [0, total_len].  valid(q): a k-mer starts at q and lies inside one unitig.
+// cont(q): k-mers q-1 and q belong to the same super-k-mer (both valid, same unitig, equal minimizer).
+//   head bit q = valid(q) && !cont(q)          -> a super-k-mer starts at q
+//   end  bit q = valid(q-1) && !cont(q)        -> a super-k-mer's last k-mer is q-1
+// Each wave covers one aligned 64-position word of both bitmaps and writes it with one ballot.
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_superkmer_flags(const uint64_t* __restrict__ src, const unsigned long long* __restrict__ ustart,
+                                                            uint64_t total_len, int k, int m, unsigned long long* __restrict__ Hb,
+                                                            unsigned long long* __restrict__ Eb)
+{
+	__shared__ uint32_t sm_mini[kBlock + 1];
+	__shared__ uint8_t sm_valid[kBlock + 1];
+	const uint64_t base = (uint64_t)blockIdx.x * kBlock;
+	const uint64_t q = base + threadIdx.x;
+	auto eval = [&](uint64_t p, uint32_t& mini) -> bool {
+		mini = 0;
+		if (p + (uint64_t)k > total_len)
+			return false;
+		// unitig starts inside (p, p+k-1] make the k-mer straddle two unitigs
+		const uint64_t win = bitmap_window(ustart, p + 1);
+		const uint64_t msk = (k - 1 >= 64) ? ~0ull : ((1ull << (k - 1)) - 1ull);
+		if (win & msk)
+			return false;
+		const Kmer<KW> x = packed_kmer<KW>(src, p, k);
+		mini = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m);
+		return true;
+	};
+	uint32_t mini;
+	const bool valid = eval(q, mini);
+	sm_mini[threadIdx.x + 1] = mini;
+	sm_valid[threadIdx.x + 1] = valid ? 1 : 0;
+	if (threadIdx.x == 0) {
+		uint32_t pm = 0;
+		const bool pv = base > 0 ? eval(base - 1, pm) : false;
+		sm_mini[0] = pm;
+		sm_valid[0] = pv ? 1 : 0;
+	}
+	__syncthreads();
+	const bool pvalid = sm_valid[threadIdx.x] != 0;
+	const uint32_t pmini = sm_mini[threadIdx.x];
+	const bool is_start = q <= total_len && ((ustart[q >> 6] >> (q & 63)) & 1ull);
+	const bool cont = pvalid && valid && pmini == mini && !is_start;
+	const unsigned long long hb = __ballot(valid && !cont);
+	const unsigned long long eb = __ballot(pvalid && !cont);
+	if ((threadIdx.x & 63) == 0) {
+		Hb[q >> 6] = hb;
+		Eb[q >> 6] = eb;
+	}
+}
+
+struct PopcU64 {
+	__host__ __device__ uint64_t operator()(unsigned long long v) const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		return (uint64_t)__popcll(v);
+#else
+		return (uint64_t)__builtin_popcountll(v);
+#endif
+	}
+};
+
+// ---- K3 ----------------------------------------------------------------------------------------------------------------
+// One lane per bitmap word: scatter the positions of its set bits (heads -> sk_pos, ends -> sk_last = q-1).
+__global__ void k_collect(const unsigned long long* __restrict__ Hb, const unsigned long long* __restrict__ Eb,
+                          const uint64_t* __restrict__ Hpre, const uint64_t* __restrict__ Epre, uint64_t nwords,
+                          uint64_t* __restrict__ sk_pos, uint64_t* __restrict__ sk_last)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords)
+		return;
+	unsigned long long h = Hb[w];
+	uint64_t o = Hpre[w];
+	while (h) {
+		const int b = __ffsll(h) - 1;
+		sk_pos[o++] = w * 64 + (uint64_t)b;
+		h &= h - 1;
+	}
+	unsigned long long e = Eb[w];
+	o = Epre[w];
+	while (e) {
+		const int b = __ffsll(e) - 1;
+		sk_last[o++] = w * 64 + (uint64_t)b - 1;
+		e &= e - 1;
+	}
+}
+
+template <int KW>
+__global__ void k_sk_minis(const uint64_t* __restrict__ src, const uint64_t* __restrict__ sk_pos, uint64_t nsk, int k, int m,
+                           uint32_t* __restrict__ sk_mini)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nsk)
+		return;
+	const Kmer<KW> x = packed_kmer<KW>(src, sk_pos[i], k);
+	sk_mini[i] = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m);
+}
+
+// ---- K4 ----------------------------------------------------------------------------------------------------------------
+__global__ void k_sorted_lengths(const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
+                                 const uint64_t* __restrict__ sk_last, uint64_t nsk, int k, uint64_t* __restrict__ len_nt,
+                                 uint64_t* __restrict__ len_k)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > nsk)
+		return;
+	if (j == nsk) {  // sentinel so that the exclusive scans also deliver the totals
+		len_nt[j] = 0;
+		len_k[j] = 0;
+		return;
+	}
+	const uint32_t i = order[j];
+	const uint64_t nk = sk_last[i] - sk_pos[i] + 1;
+	len_k[j] = nk;
+	len_nt[j] = nk + (uint64_t)k - 1;
+}
+
+// run boundaries of equal minimizers in the sorted super-k-mer list -> per-bucket [begin, end) in nt and in keys
+__global__ void k_bucket_runs(const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
+                              const uint64_t* __restrict__ key_start, uint64_t nsk, uint64_t* __restrict__ b_nt_begin,
+                              uint64_t* __restrict__ b_nt_end, uint64_t* __restrict__ b_key_begin, uint64_t* __restrict__ b_key_end)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nsk)
+		return;
+	const uint32_t mi = smini[j];
+	if (j == 0 || smini[j - 1] != mi) {
+		b_nt_begin[mi] = nt_start[j];
+		b_key_begin[mi] = key_start[j];
+	}
+	if (j + 1 == nsk || smini[j + 1] != mi) {
+		b_nt_end[mi] = nt_start[j + 1];
+		b_key_end[mi] = key_start[j + 1];
+	}
+}
+
+__global__ void k_bucket_finish(const uint64_t* __restrict__ b_nt_begin, const uint64_t* __restrict__ b_nt_end,
+                                const uint64_t* __restrict__ b_key_begin, const uint64_t* __restrict__ b_key_end, uint32_t nbuckets,
+                                uint64_t* __restrict__ b_nt, uint64_t* __restrict__ b_keys, int* __restrict__ err)
+{
+	const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > nbuckets)
+		return;
+	if (b == nbuckets) {
+		b_nt[b] = 0;
+		b_keys[b] = 0;
+		return;
+	}
+	const uint64_t nt = b_nt_end[b] - b_nt_begin[b];
+	if (nt > 0xffffffffull)  // bucket_minimizer::nuc_minimizer is uint32_t (blight.h:33)
+		atomicOr(err, kErrLimit);
+	b_nt[b] = nt;
+	b_keys[b] = b_key_end[b] - b_key_begin[b];
+}
+
+__global__ void k_bucket_table(const uint64_t* __restrict__ b_nt, const uint64_t* __restrict__ b_start, uint32_t nbuckets,
+                               BucketDesc* __restrict__ out)
+{
+	const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nbuckets)
+		return;
+	BucketDesc d;
+	d.start = b_start[b];
+	d.nt = (uint32_t)b_nt[b];
+	d.pad = 0;
+	out[b] = d;
+}
+
+// one wave per group: key count and largest bucket (blight.cpp:285-303)
+__global__ void k_group_tables(const uint64_t* __restrict__ b_nt, const uint64_t* __restrict__ b_key_prefix, uint32_t ngroups, int gshift,
+                               uint64_t* __restrict__ g_nkeys, uint64_t* __restrict__ g_prefix, uint32_t* __restrict__ g_max)
+{
+	const uint64_t gw = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t lane = threadIdx.x & 63;
+	if (gw >= ngroups)
+		return;
+	const uint64_t b0 = gw << gshift, b1 = (gw + 1) << gshift;
+	uint32_t mx = 0;
+	for (uint64_t b = b0 + lane; b < b1; b += 64)
+		mx = max(mx, (uint32_t)b_nt[b]);
+	for (int o = 32; o > 0; o >>= 1)
+		mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+	if (lane == 0) {
+		g_max[gw] = mx;
+		g_prefix[gw] = b_key_prefix[b0];
+		g_nkeys[gw] = b_key_prefix[b1] - b_key_prefix[b0];
+	}
+}
+
+// ---- K5 ----------------------------------------------------------------------------------------------------------------
+// str2bool (blight.cpp:311-324): copy the nucleotides of sorted super-k-mer j to its slot of the packed sequence.
+__global__ void k_scatter_pack(const uint64_t* __restrict__ src, const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
+                               const uint64_t* __restrict__ nt_start, uint64_t nsk, unsigned long long* __restrict__ seq)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nsk)
+		return;
+	const uint64_t p = sk_pos[order[j]];
+	const uint64_t d = nt_start[j], e = nt_start[j + 1];
+	for (uint64_t dw = d >> 5; dw <= (e - 1) >> 5; dw++) {
+		const uint64_t a = max(d, dw * 32), z = min(e, dw * 32 + 32);
+		const int cnt = (int)(z - a);
+		const uint64_t sp = p + (a - d);
+		uint64_t v = funnel_left(src[sp >> 5], src[(sp >> 5) + 1], 2 * (int)(sp & 31));
+		if (cnt < 32)
+			v &= ~0ull << (64 - 2 * cnt);
+		v >>= 2 * (a & 31);
+		atomicOr(&seq[dw], v);
+	}
+}
+
+// ---- K6 ----------------------------------------------------------------------------------------------------------------
+template <int KW>
+__global__ void k_expand_keys(const uint64_t* __restrict__ src, const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
+                              const uint64_t* __restrict__ key_start, uint64_t nsk, int k, uint64_t* __restrict__ keys)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nsk)
+		return;
+	const uint64_t p = sk_pos[order[j]];
+	const uint64_t ks = key_start[j], ke = key_start[j + 1];
+	for (uint64_t t = 0; t < ke - ks; t++) {
+		const Kmer<KW> c = kmer_canon<KW>(packed_kmer<KW>(src, p + t, k), k);
+		if constexpr (KW == 1) {
+			keys[ks + t] = c.lo;
+		} else {
+			keys[2 * (ks + t)] = c.lo;
+			keys[2 * (ks + t) + 1] = c.hi;
+		}
+	}
+}
+
+// ---- K7 ----------------------------------------------------------------------------------------------------------------
+struct BuildGroups {
+	const uint64_t* g_prefix;  // [ngroups + 1], exclusive key prefix
+	const GroupDesc* groups;   // wbase / size[]
+	const uint64_t* loff;      // [ngroups * 16] level offsets in bits
+	uint32_t ngroups;
+};
+
+// group of key index idx: prefix[g] <= idx < prefix[g+1] (empty groups are skipped by the upper bound)
+__device__ __forceinline__ uint32_t group_of_key(const uint64_t* __restrict__ prefix, uint32_t ngroups, uint64_t idx)
+{
+	uint32_t lo = 0, hi = ngroups;  // answer in [lo, hi)
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (prefix[mid] <= idx)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+template <int KW>
+__device__ __forceinline__ uint64_t level_bit_address(const BuildGroups& bg, const uint64_t* __restrict__ keys, uint64_t idx, int level,
+                                                      uint64_t& mask)
+{
+	const uint32_t g = group_of_key(bg.g_prefix, bg.ngroups, idx);
+	const uint64_t key = KW == 1 ? keys[idx] : keys[2 * idx];  // 128-bit keys: low 64 bits only (SURVEY C-7)
+	LevelHasher hs(key);
+	uint64_t h = 0;
+	for (int l = 0; l <= level; l++)
+		h = hs.next(l);
+	const GroupDesc* gd = &bg.groups[g];
+	const uint64_t bit = bg.loff[(uint64_t)g * kLevels + level] + reduce_level(h, gd->size[level]);
+	mask = 1ull << (bit & 63);
+	return gd->wbase + (bit >> 6);
+}
+
+// processLevel_ (bbhash.h:677-709): every surviving key test-and-sets its level bit; a second hit marks the collision map.
+template <int KW>
+__global__ void k_mphf_mark(BuildGroups bg, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ list, uint64_t count, int level,
+                            unsigned long long* __restrict__ bits, unsigned long long* __restrict__ coll)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= count)
+		return;
+	const uint64_t idx = list ? (uint64_t)list[t] : t;
+	uint64_t mask;
+	const uint64_t w = level_bit_address<KW>(bg, keys, idx, level, mask);
+	const unsigned long long old = atomicOr(&bits[w], mask);
+	if (old & mask)
+		atomicOr(&coll[w], mask);
+}
+
+// keys whose level bit collided go on to the next level (their bit is cleared when the lines are written)
+template <int KW>
+__global__ void k_mphf_survive(BuildGroups bg, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ list, uint64_t count,
+                               int level, const unsigned long long* __restrict__ coll, uint32_t* __restrict__ next,
+                               unsigned long long* __restrict__ next_count)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool survives = false;
+	uint64_t idx = 0;
+	if (t < count) {
+		idx = list ? (uint64_t)list[t] : t;
+		uint64_t mask;
+		const uint64_t w = level_bit_address<KW>(bg, keys, idx, level, mask);
+		survives = (coll[w] & mask) != 0;
+	}
+	const uint64_t slot = wave_append_slot(survives, next_count);
+	if (survives)
+		next[slot] = (uint32_t)idx;
+}
+
+// ---- K8 ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t group_of_line(const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t line)
+{
+	uint32_t lo = 0, hi = ngroups;
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (line_base[mid] <= line)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+// data words of line L: logical words wbase + 7*(L - line_base) .. +6, collisions cleared (bbhash.h:358-368)
+__global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
+                            const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
+                            uint64_t* __restrict__ linepc)
+{
+	const uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (L > nlines)
+		return;
+	if (L == nlines) {
+		linepc[L] = 0;
+		return;
+	}
+	const uint32_t g = group_of_line(line_base, ngroups, L);
+	const GroupDesc* gd = &groups[g];
+	const uint64_t first = (L - line_base[g]) * kLineData;
+	uint64_t pc = 0;
+	for (int s = 0; s < kLineData; s++) {
+		const uint64_t lw = first + s;
+		if (lw < gd->nwords)
+			pc += (uint64_t)__popcll(bits[gd->wbase + lw] & ~coll[gd->wbase + lw]);
+	}
+	linepc[L] = pc;
+}
+
+__global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
+                             const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
+                             const uint64_t* __restrict__ linepre, uint64_t* __restrict__ lines)
+{
+	const uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (L >= nlines)
+		return;
+	const uint32_t g = group_of_line(line_base, ngroups, L);
+	const GroupDesc* gd = &groups[g];
+	const uint64_t first = (L - line_base[g]) * kLineData;
+	uint64_t out[kLineWords];
+	out[0] = linepre[L] - linepre[line_base[g]];  // rank restarts at 0 in every group (bbhash.h:447-465)
+	for (int s = 0; s < kLineData; s++) {
+		const uint64_t lw = first + s;
+		out[1 + s] = (lw < gd->nwords) ? (bits[gd->wbase + lw] & ~coll[gd->wbase + lw]) : 0ull;
+	}
+	ulonglong2* o = reinterpret_cast<ulonglong2*>(lines + L * kLineWords);
+	o[0] = make_ulonglong2(out[0], out[1]);
+	o[1] = make_ulonglong2(out[2], out[3]);
+	o[2] = make_ulonglong2(out[4], out[5]);
+	o[3] = make_ulonglong2(out[6], out[7]);
+}
+
+// total set bits per group (= first fallback rank, bbhash.h:554)
+__global__ void k_group_popc(const uint64_t* __restrict__ line_base, const uint64_t* __restrict__ linepre, uint32_t ngroups,
+                             uint64_t* __restrict__ g_popc)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= ngroups)
+		return;
+	g_popc[g] = linepre[line_base[g + 1]] - linepre[line_base[g]];
+}
+
+// ---- K9: fallback -----------------------------------------------------------------------------------------------------
+// processFallbackLevel (bbhash.h:711-728): keys left after 16 levels, in input (key index) order, get ranks R, R+1, ...
+template <int KW>
+__global__ void k_fb_prepare(BuildGroups bg, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ fb_sorted, uint64_t F,
+                             const uint64_t* __restrict__ g_popc, uint64_t* __restrict__ fk, uint64_t* __restrict__ frank,
+                             uint32_t* __restrict__ fgrp)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= F)
+		return;
+	const uint64_t idx = fb_sorted[t];
+	const uint32_t g = group_of_key(bg.g_prefix, bg.ngroups, idx);
+	// first fallback entry of this group: lower bound of prefix[g] in the sorted index list
+	uint64_t lo = 0, hi = F;
+	const uint64_t first_key = bg.g_prefix[g];
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if ((uint64_t)fb_sorted[mid] < first_key)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	frank[t] = g_popc[g] + (t - lo);
+	fgrp[t] = g;
+	if constexpr (KW == 1) {
+		fk[t] = keys[idx];
+	} else {
+		fk[2 * t] = keys[2 * idx];
+		fk[2 * t + 1] = keys[2 * idx + 1];
+	}
+}
+
+template <int KW> struct FbLess {
+	const uint64_t* fk;
+	const uint32_t* fgrp;
+	__host__ __device__ bool operator()(uint32_t a, uint32_t b) const
+	{
+		if (fgrp[a] != fgrp[b])
+			return fgrp[a] < fgrp[b];
+		if (KW == 2 && fk[2 * a + 1] != fk[2 * b + 1])
+			return fk[2 * a + 1] < fk[2 * b + 1];
+		const uint64_t ka = KW == 1 ? fk[a] : fk[2 * a], kb = KW == 1 ? fk[b] : fk[2 * b];
+		if (ka != kb)
+			return ka < kb;
+		return a < b;  // input order: the last occurrence of a duplicated key ends its run
+	}
+};
+
+template <int KW>
+__global__ void k_fb_table(const uint32_t* __restrict__ perm, uint64_t F, const uint64_t* __restrict__ fk, const uint64_t* __restrict__ frank,
+                           const uint32_t* __restrict__ fgrp, uint64_t* __restrict__ tk, uint64_t* __restrict__ trank,
+                           uint32_t* __restrict__ tgrp, uint64_t* __restrict__ g_fb_start, uint32_t* __restrict__ g_fb_count)
+{
+	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= F)
+		return;
+	const uint32_t t = perm[e];
+	const uint32_t g = fgrp[t];
+	if constexpr (KW == 1) {
+		tk[e] = fk[t];
+	} else {
+		tk[2 * e] = fk[2 * t];
+		tk[2 * e + 1] = fk[2 * t + 1];
+	}
+	trank[e] = frank[t];
+	tgrp[e] = g;
+	if (e == 0 || fgrp[perm[e - 1]] != g)
+		g_fb_start[g] = e;
+	atomicAdd(&g_fb_count[g], 1u);
+}
+
+// ---- positions -----------------------------------------------------------------------------------------------------------
+// int_to_bool (blight.cpp:464-469): nbits-wide little-endian field at bit start + h*nbits (array is zero-initialised)
+__device__ __forceinline__ void write_position(unsigned long long* __restrict__ positions, uint64_t posstart, uint32_t nbits, uint64_t h,
+                                               uint64_t value)
+{
+	if (value == 0)
+		return;
+	const uint64_t o = posstart + h * (uint64_t)nbits;
+	const uint64_t w = o >> 6;
+	const uint32_t s = (uint32_t)o & 63u;
+	atomicOr(&positions[w], value << s);
+	if (s + nbits > 64)
+		atomicOr(&positions[w + 1], value >> (64 - s));
+}
+
+// fill_positions (blight.cpp:486-519): one lane per sorted super-k-mer walks its keys.  Keys that live in the fallback
+// table are written by k_fb_positions (a duplicated key keeps the position of its LAST occurrence: assignment order).
+template <int KW>
+__global__ void k_fill_positions(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
+                                 const uint64_t* __restrict__ key_start, uint64_t nsk, const uint64_t* __restrict__ keys,
+                                 unsigned long long* __restrict__ positions)
+{
+	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nsk)
+		return;
+	const uint32_t mi = smini[j];
+	const GroupDesc* gd = &v.groups[mi >> v.gshift];
+	const uint64_t pos0 = nt_start[j] - v.buckets[mi].start;
+	const uint64_t ks = key_start[j], ke = key_start[j + 1];
+	const uint64_t posstart = gd->posstart;
+	const uint32_t nbits = gd->nbits;
+	DeviceIndexView nofb = v;  // level bits only
+	for (uint64_t t = 0; t < ke - ks; t++) {
+		const Kmer<KW> x = load_kmer<KW>(keys, ks + t);
+		const uint64_t h = mphf_lookup_levels<KW>(nofb, gd, x);
+		if (h != kNotFound)
+			write_position(positions, posstart, nbits, h, (pos0 + t) >> v.b);
+	}
+}
+
+template <int KW>
+__global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ fb_sorted, uint64_t F,
+                               const uint64_t* __restrict__ tk, const uint64_t* __restrict__ trank, const uint32_t* __restrict__ tgrp,
+                               const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
+                               const uint64_t* __restrict__ key_start, uint64_t nsk, unsigned long long* __restrict__ positions)
+{
+	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= F)
+		return;
+	// winner = last entry of its (group, key) run
+	if (e + 1 < F && tgrp[e + 1] == tgrp[e] && load_kmer<KW>(tk, e + 1) == load_kmer<KW>(tk, e))
+		return;
+	const uint64_t idx = fb_sorted[perm[e]];
+	// super-k-mer of key idx: key_start[j] <= idx < key_start[j+1]
+	uint64_t lo = 0, hi = nsk;
+	while (hi - lo > 1) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (key_start[mid] <= idx)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const uint32_t mi = smini[lo];
+	const GroupDesc* gd = &v.groups[mi >> v.gshift];
+	const uint64_t pos = nt_start[lo] - v.buckets[mi].start + (idx - key_start[lo]);
+	write_position(positions, gd->posstart, gd->nbits, trank[e], pos >> v.b);
+}
+
+// ---- host orchestration ------------------------------------------------------------------------------------------------
+// mphf::configureLevels, bbhash.h:591-614: IEEE double + libm pow on the HOST (never recomputed on the device: a 1-ulp
+// difference in pow could move a level boundary by 64 bits).  gamma = 2 (blight.h:60).
+uint64_t configure_levels(uint64_t nelem, uint64_t sizes[kLevels])
+{
+	const double gamma = 2.0;
+	const double proba_collision = 1.0 - pow(((gamma * (double)nelem - 1) / (gamma * (double)nelem)), (double)(nelem - 1));
+	uint64_t total = 0;
+	const size_t hash_domain = (size_t)(ceil((double)nelem * gamma));
+	for (int ii = 0; ii < kLevels; ii++) {
+		sizes[ii] = (((uint64_t)((double)hash_domain * pow(proba_collision, (double)ii)) + 63) / 64) * 64;
+		if (sizes[ii] == 0)
+			sizes[ii] = 64;
+		total += sizes[ii];
+	}
+	return total;
+}
+
+struct Scratch {
+	DevBuf buf;
+	hipStream_t s;
+	void* get(size_t bytes)
+	{
+		if (bytes > buf.bytes)
+			BLMX_HIP(buf.alloc(bytes, false, s));
+		return buf.p;
+	}
+};
+
+template <typename InIt>
+void exclusive_scan_u64(Scratch& sc, InIt in, uint64_t* out, uint64_t n, hipStream_t s)
+{
+	size_t bytes = 0;
+	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+	void* tmp = sc.get(bytes);
+	BLMX_HIP(rocprim::exclusive_scan(tmp, bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+}
+
+template <typename T> T read_scalar(const T* d, hipStream_t s)
+{
+	T h;
+	BLMX_HIP(hipMemcpyAsync(&h, d, sizeof(T), hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	return h;
+}
+
+void check_build_err(const int* d_err, hipStream_t s)
+{
+	const int e = read_scalar(d_err, s);
+	if (e & kErrDna)
+		throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
+	if (e & kErrShort)
+		throw StatusError{BLMX_ESHORT, "a sequence is shorter than k"};
+	if (e & kErrLimit)
+		throw StatusError{BLMX_ELIMIT, "a minimizer bucket holds 2^32 or more nucleotides"};
+}
+
+template <int KW>
+void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
+{
+	const auto t_begin = std::chrono::steady_clock::now();
+	hipStream_t s = ix.stream;
+	const int k = (int)ix.prm.k, m = (int)ix.prm.m, n = (int)ix.prm.log2_mphf, b = (int)ix.prm.bits_saved;
+	const uint32_t nbuckets = ix.nbuckets, ngroups = ix.ngroups;
+	const int gshift = ix.gshift;
+	Scratch sc;
+	sc.s = s;
+	(void)n;
+
+	DevBuf d_err;
+	BLMX_HIP(d_err.alloc(sizeof(int), true, s));
+
+	// ---- K1: packed source + unitig-start bitmap
+	const uint64_t npos = total_len + 1;                      // positions 0 .. total_len
+	const uint64_t nbw = (uint64_t)grid_for(npos) * (kBlock / 64);  // bitmap words written by K2
+	const uint64_t src_words = (total_len + 31) / 32;
+	DevBuf d_src, d_ustart, d_Hb, d_Eb;
+	BLMX_HIP(d_src.alloc((src_words + 4) * 8, true, s));
+	BLMX_HIP(d_ustart.alloc((nbw + 4) * 8, true, s));
+	BLMX_HIP(d_Hb.alloc((nbw + 1) * 8, true, s));
+	BLMX_HIP(d_Eb.alloc((nbw + 1) * 8, true, s));
+	if (nseq) {
+		hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nseq)), dim3(kBlock), 0, s, d_offs, nseq, k, d_ustart.as<unsigned long long>(),
+		                   d_err.as<int>());
+		if ((reinterpret_cast<uintptr_t>(d_ascii) & 15) == 0)
+			hipLaunchKernelGGL((k_encode_pack<true>), dim3(grid_for(src_words)), dim3(kBlock), 0, s, d_ascii, total_len, src_words,
+			                   d_src.as<uint64_t>(), d_err.as<int>());
+		else
+			hipLaunchKernelGGL((k_encode_pack<false>), dim3(grid_for(src_words)), dim3(kBlock), 0, s, d_ascii, total_len, src_words,
+			                   d_src.as<uint64_t>(), d_err.as<int>());
+		BLMX_HIP(hipGetLastError());
+		check_build_err(d_err.as<int>(), s);
+	}
+
+	// ---- K2: super-k-mer head / end bitmaps
+	uint64_t nsk = 0;
+	DevBuf d_Hpre, d_Epre;
+	BLMX_HIP(d_Hpre.alloc((nbw + 1) * 8, false, s));
+	BLMX_HIP(d_Epre.alloc((nbw + 1) * 8, false, s));
+	if (nseq) {
+		hipLaunchKernelGGL((k_superkmer_flags<KW>), dim3(grid_for(npos)), dim3(kBlock), 0, s, d_src.as<uint64_t>(),
+		                   d_ustart.as<unsigned long long>(), total_len, k, m, d_Hb.as<unsigned long long>(),
+		                   d_Eb.as<unsigned long long>());
+		BLMX_HIP(hipGetLastError());
+		auto hin = rocprim::make_transform_iterator(d_Hb.as<unsigned long long>(), PopcU64());
+		auto ein = rocprim::make_transform_iterator(d_Eb.as<unsigned long long>(), PopcU64());
+		exclusive_scan_u64(sc, hin, d_Hpre.as<uint64_t>(), nbw + 1, s);
+		exclusive_scan_u64(sc, ein, d_Epre.as<uint64_t>(), nbw + 1, s);
+		nsk = read_scalar(d_Hpre.as<uint64_t>() + nbw, s);
+		const uint64_t nend = read_scalar(d_Epre.as<uint64_t>() + nbw, s);
+		if (nend != nsk)
+			throw StatusError{BLMX_EHIP, "internal: super-k-mer head/end count mismatch"};
+		if (nsk >= 0xffffffffull)
+			throw StatusError{BLMX_ELIMIT, "more than 2^32 super-k-mers"};
+	}
+	d_ustart.release();
+
+	// ---- K3: compact super-k-mers
+	DevBuf d_skpos, d_sklast, d_skmini;
+	BLMX_HIP(d_skpos.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(d_sklast.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(d_skmini.alloc((nsk + 1) * 4, false, s));
+	if (nsk) {
+		hipLaunchKernelGGL(k_collect, dim3(grid_for(nbw)), dim3(kBlock), 0, s, d_Hb.as<unsigned long long>(), d_Eb.as<unsigned long long>(),
+		                   d_Hpre.as<uint64_t>(), d_Epre.as<uint64_t>(), nbw, d_skpos.as<uint64_t>(), d_sklast.as<uint64_t>());
+		hipLaunchKernelGGL((k_sk_minis<KW>), dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_skpos.as<uint64_t>(), nsk, k, m,
+		                   d_skmini.as<uint32_t>());
+		BLMX_HIP(hipGetLastError());
+	}
+	d_Hb.release();
+	d_Eb.release();
+	d_Hpre.release();
+	d_Epre.release();
+
+	// ---- K4: stable sort by minimizer, offsets, bucket + group tables
+	DevBuf d_smini, d_order, d_lennt, d_lenk, d_ntstart, d_keystart;
+	BLMX_HIP(d_smini.alloc((nsk + 1) * 4, false, s));
+	BLMX_HIP(d_order.alloc((nsk + 1) * 4, false, s));
+	if (nsk) {
+		size_t bytes = 0;
+		rocprim::counting_iterator<uint32_t> iota(0);
+		BLMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_skmini.as<uint32_t>(), d_smini.as<uint32_t>(), iota, d_order.as<uint32_t>(),
+		                                   (size_t)nsk, 0u, (unsigned)(2 * m - 1), s));
+		void* tmp = sc.get(bytes);
+		BLMX_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_skmini.as<uint32_t>(), d_smini.as<uint32_t>(), iota, d_order.as<uint32_t>(),
+		                                   (size_t)nsk, 0u, (unsigned)(2 * m - 1), s));
+	}
+	d_skmini.release();
+	BLMX_HIP(d_lennt.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(d_lenk.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(d_ntstart.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(d_keystart.alloc((nsk + 1) * 8, false, s));
+	hipLaunchKernelGGL(k_sorted_lengths, dim3(grid_for(nsk + 1)), dim3(kBlock), 0, s, d_order.as<uint32_t>(), d_skpos.as<uint64_t>(),
+	                   d_sklast.as<uint64_t>(), nsk, k, d_lennt.as<uint64_t>(), d_lenk.as<uint64_t>());
+	BLMX_HIP(hipGetLastError());
+	exclusive_scan_u64(sc, d_lennt.as<uint64_t>(), d_ntstart.as<uint64_t>(), nsk + 1, s);
+	exclusive_scan_u64(sc, d_lenk.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk + 1, s);
+	const uint64_t total_nt = read_scalar(d_ntstart.as<uint64_t>() + nsk, s);
+	const uint64_t N = read_scalar(d_keystart.as<uint64_t>() + nsk, s);
+	d_lennt.release();
+	d_lenk.release();
+	d_sklast.release();
+	if (N >= 0xffffffffull)
+		throw StatusError{BLMX_ELIMIT, "more than 2^32 - 1 k-mers on one device"};
+
+	DevBuf d_bnb, d_bne, d_bkb, d_bke, d_bnt, d_bkeys, d_bstart, d_bkpre;
+	const size_t bb = ((size_t)nbuckets + 1) * 8;
+	BLMX_HIP(d_bnb.alloc(bb, true, s));
+	BLMX_HIP(d_bne.alloc(bb, true, s));
+	BLMX_HIP(d_bkb.alloc(bb, true, s));
+	BLMX_HIP(d_bke.alloc(bb, true, s));
+	BLMX_HIP(d_bnt.alloc(bb, false, s));
+	BLMX_HIP(d_bkeys.alloc(bb, false, s));
+	BLMX_HIP(d_bstart.alloc(bb, false, s));
+	BLMX_HIP(d_bkpre.alloc(bb, false, s));
+	if (nsk)
+		hipLaunchKernelGGL(k_bucket_runs, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
+		                   d_keystart.as<uint64_t>(), nsk, d_bnb.as<uint64_t>(), d_bne.as<uint64_t>(), d_bkb.as<uint64_t>(),
+		                   d_bke.as<uint64_t>());
+	hipLaunchKernelGGL(k_bucket_finish, dim3(grid_for((uint64_t)nbuckets + 1)), dim3(kBlock), 0, s, d_bnb.as<uint64_t>(), d_bne.as<uint64_t>(),
+	                   d_bkb.as<uint64_t>(), d_bke.as<uint64_t>(), nbuckets, d_bnt.as<uint64_t>(), d_bkeys.as<uint64_t>(), d_err.as<int>());
+	BLMX_HIP(hipGetLastError());
+	check_build_err(d_err.as<int>(), s);
+	exclusive_scan_u64(sc, d_bnt.as<uint64_t>(), d_bstart.as<uint64_t>(), (uint64_t)nbuckets + 1, s);
+	exclusive_scan_u64(sc, d_bkeys.as<uint64_t>(), d_bkpre.as<uint64_t>(), (uint64_t)nbuckets + 1, s);
+	d_bnb.release();
+	d_bne.release();
+	d_bkb.release();
+	d_bke.release();
+	BLMX_HIP(ix.buckets.alloc((size_t)nbuckets * sizeof(BucketDesc), false, s));
+	hipLaunchKernelGGL(k_bucket_table, dim3(grid_for(nbuckets)), dim3(kBlock), 0, s, d_bnt.as<uint64_t>(), d_bstart.as<uint64_t>(), nbuckets,
+	                   ix.buckets.as<BucketDesc>());
+	DevBuf d_gnk, d_gpre, d_gmax;
+	BLMX_HIP(d_gnk.alloc((size_t)ngroups * 8, false, s));
+	BLMX_HIP(d_gpre.alloc(((size_t)ngroups + 1) * 8, false, s));
+	BLMX_HIP(d_gmax.alloc((size_t)ngroups * 4, false, s));
+	hipLaunchKernelGGL(k_group_tables, dim3(grid_for((uint64_t)ngroups * 64)), dim3(kBlock), 0, s, d_bnt.as<uint64_t>(), d_bkpre.as<uint64_t>(),
+	                   ngroups, gshift, d_gnk.as<uint64_t>(), d_gpre.as<uint64_t>(), d_gmax.as<uint32_t>());
+	BLMX_HIP(hipGetLastError());
+	BLMX_HIP(hipMemcpyAsync(d_gpre.as<uint64_t>() + ngroups, &N, 8, hipMemcpyHostToDevice, s));
+	std::vector<uint64_t> h_gnk(ngroups), h_gpre(ngroups);
+	std::vector<uint32_t> h_gmax(ngroups);
+	BLMX_HIP(hipMemcpyAsync(h_gnk.data(), d_gnk.p, (size_t)ngroups * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipMemcpyAsync(h_gpre.data(), d_gpre.p, (size_t)ngroups * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipMemcpyAsync(h_gmax.data(), d_gmax.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	d_bnt.release();
+	d_bkeys.release();
+	d_bstart.release();
+	d_bkpre.release();
+	d_gnk.release();
+	d_gmax.release();
+
+	// ---- host: group descriptors (blight.cpp:292-303) and BBHash level tables (bbhash.h:591-614)
+	ix.h_groups.assign(ngroups, GroupDesc{});
+	std::vector<uint64_t> h_loff((size_t)ngroups * kLevels, 0), h_line_base((size_t)ngroups + 1, 0);
+	uint64_t total_pos = 0, wbase = 0, lbase = 0, largest_mphf = 0;
+	uint32_t largest_bucket = 0;
+	for (uint32_t g = 0; g < ngroups; g++) {
+		GroupDesc& gd = ix.h_groups[g];
+		int nb = (int)(ceil(log2((double)(uint32_t)(h_gmax[g] + 1))) - (double)b);
+		if (nb < 1)
+			nb = 1;
+		gd.nbits = (uint32_t)nb;
+		gd.posstart = total_pos;
+		total_pos += (uint64_t)nb * h_gnk[g] + 8;  // round_eight, blight.cpp:102-104
+		gd.prefix = h_gpre[g];
+		gd.nkeys = h_gnk[g];
+		gd.wbase = wbase;
+		gd.line_base = lbase;
+		h_line_base[g] = lbase;
+		if (h_gnk[g]) {
+			const uint64_t total_bits = configure_levels(h_gnk[g], gd.size);
+			uint64_t off = 0;
+			for (int l = 0; l < kLevels; l++) {
+				h_loff[(size_t)g * kLevels + l] = off;
+				off += gd.size[l];
+			}
+			gd.nwords = total_bits / 64;
+			wbase += gd.nwords;
+			lbase += (gd.nwords + kLineData - 1) / kLineData;
+		} else {
+			// no MPHF for an empty group (blight.cpp:452); size 64 keeps the probe arithmetic defined, never reached
+			for (int l = 0; l < kLevels; l++)
+				gd.size[l] = 64;
+			gd.nwords = 0;
+		}
+		largest_mphf = std::max(largest_mphf, h_gnk[g]);
+		largest_bucket = std::max(largest_bucket, h_gmax[g]);
+	}
+	h_line_base[ngroups] = lbase;
+	const uint64_t total_words = wbase, total_lines = lbase;
+
+	DevBuf d_loff, d_line_base, d_bgroups;
+	BLMX_HIP(d_loff.alloc(h_loff.size() * 8, false, s));
+	BLMX_HIP(d_line_base.alloc(h_line_base.size() * 8, false, s));
+	BLMX_HIP(d_bgroups.alloc((size_t)ngroups * sizeof(GroupDesc), false, s));
+	BLMX_HIP(hipMemcpyAsync(d_loff.p, h_loff.data(), h_loff.size() * 8, hipMemcpyHostToDevice, s));
+	BLMX_HIP(hipMemcpyAsync(d_line_base.p, h_line_base.data(), h_line_base.size() * 8, hipMemcpyHostToDevice, s));
+	BLMX_HIP(hipMemcpyAsync(d_bgroups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
+
+	// ---- K5: packed bucket sequence.  Padding: the 2^b scan may read NW words past the last k-mer (blight.cpp:738)
+	const uint64_t pad_words = ((1ull << std::min(b, 20)) + 64 * (uint64_t)KW + 64) / 32 + 4;
+	ix.seq_words = total_nt / 32 + pad_words;
+	BLMX_HIP(ix.seq.alloc(ix.seq_words * 8, true, s));
+	if (nsk)
+		hipLaunchKernelGGL(k_scatter_pack, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
+		                   d_skpos.as<uint64_t>(), d_ntstart.as<uint64_t>(), nsk, ix.seq.as<unsigned long long>());
+
+	// ---- K6: keys in (bucket, position) order
+	DevBuf d_keys;
+	BLMX_HIP(d_keys.alloc((N + 1) * 8 * KW, false, s));
+	if (nsk)
+		hipLaunchKernelGGL((k_expand_keys<KW>), dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
+		                   d_skpos.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, k, d_keys.as<uint64_t>());
+	BLMX_HIP(hipGetLastError());
+	BLMX_HIP(hipStreamSynchronize(s));
+	d_src.release();
+	d_skpos.release();
+	d_order.release();
+
+	// ---- K7: BBHash levels, all groups at once
+	DevBuf d_bits, d_coll, d_listA, d_listB, d_cnt;
+	BLMX_HIP(d_bits.alloc((total_words + 1) * 8, true, s));
+	BLMX_HIP(d_coll.alloc((total_words + 1) * 8, true, s));
+	BLMX_HIP(d_cnt.alloc(8, true, s));
+	BuildGroups bg{d_gpre.as<uint64_t>(), d_bgroups.as<GroupDesc>(), d_loff.as<uint64_t>(), ngroups};
+	uint64_t count = N;
+	const uint32_t* cur = nullptr;
+	uint32_t* nxt = nullptr;
+	int levels_used = 0;
+	uint64_t F = 0;
+	for (int level = 0; level < kLevels && count > 0; level++) {
+		levels_used = level + 1;
+		hipLaunchKernelGGL((k_mphf_mark<KW>), dim3(grid_for(count)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
+		                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>());
+		// survivors list: at most `count` entries
+		DevBuf& dst = (level & 1) ? d_listB : d_listA;
+		BLMX_HIP(dst.alloc((count + 1) * 4, false, s));
+		nxt = dst.as<uint32_t>();
+		BLMX_HIP(hipMemsetAsync(d_cnt.p, 0, 8, s));
+		hipLaunchKernelGGL((k_mphf_survive<KW>), dim3(grid_for(count)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
+		                   d_coll.as<unsigned long long>(), nxt, d_cnt.as<unsigned long long>());
+		BLMX_HIP(hipGetLastError());
+		count = read_scalar(d_cnt.as<unsigned long long>(), s);
+		cur = nxt;
+		if (level == kLevels - 1)
+			F = count;
+	}
+
+	// ---- K8: collisions cleared + ranks -> 64-B lines
+	DevBuf d_linepc, d_linepre, d_gpopc;
+	BLMX_HIP(d_linepc.alloc((total_lines + 1) * 8, false, s));
+	BLMX_HIP(d_linepre.alloc((total_lines + 1) * 8, false, s));
+	BLMX_HIP(d_gpopc.alloc(((size_t)ngroups + 1) * 8, false, s));
+	BLMX_HIP(ix.lines.alloc((total_lines + 1) * kLineWords * 8, true, s));
+	hipLaunchKernelGGL(k_line_popc, dim3(grid_for(total_lines + 1)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
+	                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>());
+	BLMX_HIP(hipGetLastError());
+	exclusive_scan_u64(sc, d_linepc.as<uint64_t>(), d_linepre.as<uint64_t>(), total_lines + 1, s);
+	if (total_lines)
+		hipLaunchKernelGGL(k_line_write, dim3(grid_for(total_lines)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
+		                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepre.as<uint64_t>(),
+		                   ix.lines.as<uint64_t>());
+	hipLaunchKernelGGL(k_group_popc, dim3(grid_for(ngroups)), dim3(kBlock), 0, s, d_line_base.as<uint64_t>(), d_linepre.as<uint64_t>(), ngroups,
+	                   d_gpopc.as<uint64_t>());
+	BLMX_HIP(hipGetLastError());
+	BLMX_HIP(hipStreamSynchronize(s));
+	d_bits.release();
+	d_coll.release();
+	d_linepc.release();
+
+	// ---- K9a: fallback table
+	DevBuf d_fbsorted, d_fk, d_frank, d_fgrp, d_perm, d_tgrp, d_gfbstart, d_gfbcount;
+	BLMX_HIP(ix.fb_keys.alloc((F + 1) * 8 * KW, true, s));
+	BLMX_HIP(ix.fb_ranks.alloc((F + 1) * 8, true, s));
+	ix.h_fb_group.clear();
+	if (F) {
+		BLMX_HIP(d_fbsorted.alloc(F * 4, false, s));
+		size_t bytes = 0;
+		BLMX_HIP(rocprim::radix_sort_keys(nullptr, bytes, cur, d_fbsorted.as<uint32_t>(), (size_t)F, 0u, 32u, s));
+		void* tmp = sc.get(bytes);
+		BLMX_HIP(rocprim::radix_sort_keys(tmp, bytes, cur, d_fbsorted.as<uint32_t>(), (size_t)F, 0u, 32u, s));
+		BLMX_HIP(d_fk.alloc(F * 8 * KW, false, s));
+		BLMX_HIP(d_frank.alloc(F * 8, false, s));
+		BLMX_HIP(d_fgrp.alloc(F * 4, false, s));
+		hipLaunchKernelGGL((k_fb_prepare<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), d_fbsorted.as<uint32_t>(), F,
+		                   d_gpopc.as<uint64_t>(), d_fk.as<uint64_t>(), d_frank.as<uint64_t>(), d_fgrp.as<uint32_t>());
+		BLMX_HIP(hipGetLastError());
+		BLMX_HIP(d_perm.alloc(F * 4, false, s));
+		rocprim::counting_iterator<uint32_t> iota(0);
+		FbLess<KW> less{d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>()};
+		bytes = 0;
+		BLMX_HIP(rocprim::merge_sort(nullptr, bytes, iota, d_perm.as<uint32_t>(), (size_t)F, less, s));
+		tmp = sc.get(bytes);
+		BLMX_HIP(rocprim::merge_sort(tmp, bytes, iota, d_perm.as<uint32_t>(), (size_t)F, less, s));
+		BLMX_HIP(d_tgrp.alloc(F * 4, false, s));
+		BLMX_HIP(d_gfbstart.alloc((size_t)ngroups * 8, true, s));
+		BLMX_HIP(d_gfbcount.alloc((size_t)ngroups * 4, true, s));
+		hipLaunchKernelGGL((k_fb_table<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, d_perm.as<uint32_t>(), F, d_fk.as<uint64_t>(),
+		                   d_frank.as<uint64_t>(), d_fgrp.as<uint32_t>(), ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(),
+		                   d_tgrp.as<uint32_t>(), d_gfbstart.as<uint64_t>(), d_gfbcount.as<uint32_t>());
+		BLMX_HIP(hipGetLastError());
+		std::vector<uint64_t> h_fs(ngroups);
+		std::vector<uint32_t> h_fc(ngroups);
+		ix.h_fb_group.resize(F);
+		BLMX_HIP(hipMemcpyAsync(h_fs.data(), d_gfbstart.p, (size_t)ngroups * 8, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipMemcpyAsync(h_fc.data(), d_gfbcount.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipMemcpyAsync(ix.h_fb_group.data(), d_tgrp.p, F * 4, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+		for (uint32_t g = 0; g < ngroups; g++) {
+			ix.h_groups[g].fb_start = h_fs[g];
+			ix.h_groups[g].fb_count = h_fc[g];
+		}
+	}
+	// final group table (with fallback ranges)
+	BLMX_HIP(ix.groups.alloc((size_t)ngroups * sizeof(GroupDesc), false, s));
+	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
+
+	// ---- K9b: positions
+	ix.positions_words = total_pos / 64 + 3;
+	BLMX_HIP(ix.positions.alloc(ix.positions_words * 8, true, s));
+	ix.st.total_nt = total_nt;
+	{
+		const DeviceIndexView v = ix.view();
+		if (nsk)
+			hipLaunchKernelGGL((k_fill_positions<KW>), dim3(grid_for(nsk)), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
+			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), ix.positions.as<unsigned long long>());
+		if (F)
+			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint32_t>(), F,
+			                   ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(),
+			                   d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, ix.positions.as<unsigned long long>());
+		BLMX_HIP(hipGetLastError());
+	}
+	BLMX_HIP(hipStreamSynchronize(s));
+
+	// ---- public counters (blight.h:52-59, recap blight.cpp:361-378)
+	ix.total_lines = total_lines;
+	ix.total_logical_words = total_words;
+	blmx_stats_t& st = ix.st;
+	st.number_kmer = N;
+	st.number_super_kmer = nsk;
+	st.largest_mphf = largest_mphf;
+	st.positions_total_size = total_pos;
+	st.total_nt = total_nt;
+	st.largest_bucket = largest_bucket;
+	st.mphf_bytes = total_lines * kLineWords * 8;
+	st.fallback_keys = F;
+	st.nbuckets = nbuckets;
+	st.ngroups = ngroups;
+	st.k = ix.prm.k;
+	st.m = ix.prm.m;
+	st.log2_mphf = ix.prm.log2_mphf;
+	st.bits_saved = ix.prm.bits_saved;
+	st.kmer_bytes = (uint32_t)(8 * KW);
+	st.max_levels_used = (uint32_t)levels_used;
+	st.device_bytes = ix.buckets.bytes + ix.groups.bytes + ix.seq.bytes + ix.positions.bytes + ix.lines.bytes + ix.fb_keys.bytes +
+	                  ix.fb_ranks.bytes;
+	st.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+}
+
+}  // namespace
+
+void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
+{
+	if (ix.KW == 1)
+		build_impl<1>(ix, d_ascii, d_offs, nseq, total_len);
+	else
+		build_impl<2>(ix, d_ascii, d_offs, nseq, total_len);
+}
+
+}  // namespace blmx

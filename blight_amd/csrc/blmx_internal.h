@@ -1,0 +1,156 @@
+// blmx_internal.h -- host-side structures shared by the build, query and API translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/blight_mi355x.h"
+#include "device_prims.h"
+
+namespace blmx {
+
+// ---- HBM layout of the finished index ------------------------------------------------------------------------------
+// One bucket_minimizer (reference blight.h:29-34) per minimizer value: 16 B so a lane fetches it with one dwordx4.
+struct alignas(16) BucketDesc {
+	uint64_t start;  // first nt of the bucket in the packed sequence
+	uint32_t nt;     // nuc_minimizer
+	uint32_t pad;
+};
+
+// One info_mphf (reference blight.h:39-44) + the BBHash level table of the group's MPHF (bbhash.h:780).
+// 192 B = three 64-B sectors; everything a positive query needs (prefix, posstart, line_base, nbits, sizes 0..2) sits
+// in the first sector.
+struct alignas(64) GroupDesc {
+	uint64_t prefix;     // ID base = number of keys in lower groups (mphf_size after blight.cpp:299-301)
+	uint64_t posstart;   // first bit of the group's slice of `positions` (info_mphf::start)
+	uint64_t line_base;  // first 64-B line of the group's MPHF in the line array
+	uint32_t nbits;      // bit_to_encode
+	uint32_t fb_count;   // entries of the group's fallback table
+	uint64_t fb_start;   // first entry in the fallback arrays
+	uint64_t size[kLevels];  // level sizes in bits (_hash_domains)
+	uint64_t nkeys;
+	uint64_t wbase;      // build time: first logical u64 word of the group's level bit array
+	uint64_t nwords;     // logical words (sum of sizes / 64)
+};
+static_assert(sizeof(GroupDesc) == 192 + 0, "GroupDesc must be 192 bytes");
+
+struct DeviceIndexView {
+	int k, m, n, b, gshift;
+	uint32_t nbuckets, ngroups;
+	const BucketDesc* buckets;
+	const GroupDesc* groups;
+	const uint64_t* seq;        // 2-bit packed, MSB-first
+	const uint64_t* positions;  // LSB-first bit fields
+	const uint64_t* lines;      // MPHF lines: [rank | 7 data words]
+	const uint64_t* fb_keys;    // fallback keys (KW words each), sorted by (group, key)
+	const uint64_t* fb_ranks;
+	uint64_t total_nt;
+};
+
+// ---- tiny RAII device buffer ---------------------------------------------------------------------------------------
+struct DevBuf {
+	void* p = nullptr;
+	size_t bytes = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	~DevBuf() { release(); }
+	void release()
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		bytes = 0;
+	}
+	hipError_t alloc(size_t n, bool zero, hipStream_t s)
+	{
+		release();
+		if (n == 0)
+			n = 16;
+		hipError_t e = hipMalloc(&p, n);
+		if (e != hipSuccess) {
+			p = nullptr;
+			return e;
+		}
+		bytes = n;
+		if (zero)
+			e = hipMemsetAsync(p, 0, n, s);
+		return e;
+	}
+	template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct StatusError {
+	int code;
+	std::string msg;
+};
+
+#define BLMX_HIP(expr)                                                                                         \
+	do {                                                                                                       \
+		hipError_t _e = (expr);                                                                                \
+		if (_e != hipSuccess)                                                                                  \
+			throw ::blmx::StatusError{_e == hipErrorOutOfMemory ? BLMX_ENOMEM : BLMX_EHIP,                      \
+			                          std::string(#expr) + ": " + hipGetErrorString(_e)};                      \
+	} while (0)
+
+struct Index {
+	blmx_params prm{};
+	int KW = 1;  // u64 words per k-mer
+	int gshift = 0;
+	uint32_t nbuckets = 0, ngroups = 0;
+	bool built = false;
+	hipStream_t stream = nullptr;
+	std::string err;
+	std::mutex mu;  // serialises host-buffer queries (shared staging buffers)
+
+	// finished index (HBM)
+	DevBuf buckets, groups, seq, positions, lines, fb_keys, fb_ranks;
+	// host mirror of the group table (export / stats)
+	std::vector<GroupDesc> h_groups;
+	std::vector<uint32_t> h_fb_group;
+	blmx_stats_t st{};
+	uint64_t positions_words = 0, seq_words = 0, total_lines = 0, total_logical_words = 0;
+
+	// staging for host-buffer queries
+	DevBuf q_in, q_aux, q_out;
+
+	DeviceIndexView view() const
+	{
+		DeviceIndexView v;
+		v.k = (int)prm.k;
+		v.m = (int)prm.m;
+		v.n = (int)prm.log2_mphf;
+		v.b = (int)prm.bits_saved;
+		v.gshift = gshift;
+		v.nbuckets = nbuckets;
+		v.ngroups = ngroups;
+		v.buckets = buckets.as<BucketDesc>();
+		v.groups = groups.as<GroupDesc>();
+		v.seq = seq.as<uint64_t>();
+		v.positions = positions.as<uint64_t>();
+		v.lines = lines.as<uint64_t>();
+		v.fb_keys = fb_keys.as<uint64_t>();
+		v.fb_ranks = fb_ranks.as<uint64_t>();
+		v.total_nt = st.total_nt;
+		return v;
+	}
+};
+
+// build (blmx_build.hip)
+void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
+
+// query (blmx_query.hip).  mode: 0 = IDs (query_kmer_hash / query_get_hash), 1 = positions (query_get_pos_unitig),
+// 2 = membership byte.  d_minis == nullptr -> minimizers are computed on the device.
+enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2 };
+void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
+                  hipStream_t s);
+void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s);
+// rolling canonical k-mers of ASCII sequences -> canonical k-mer array (KW words each); returns via d_err (BLMX_EDNA)
+void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, const uint64_t* d_kmer_offs,
+                           uint64_t nseq, uint64_t total_len, void* d_kmers_out, int* d_err, hipStream_t s);
+void launch_primitive(int op, int KW, const void* d_in, uint64_t n, int arg, int arg2, void* d_out, hipStream_t s);
+
+}  // namespace blmx

@@ -1,0 +1,380 @@
+// blmx_query.hip -- gfx950 query kernels of the Blight hot path.
+//
+// One lane answers one k-mer (reference query_kmer_hash -> query_get_hash, blight.cpp:545-550, 716-742):
+//   canonical k-mer -> minimizer (kmer.h:791-810) -> bucket descriptor (16 B) -> group descriptor -> BBHash probe
+//   (bbhash.h:561-577, 617-663; one 64-B line per probed level, rank word interleaved) -> position field
+//   (blight.cpp:473-482) -> 2^b window of the packed sequence (blight.cpp:729-739) compared in registers.
+// The path is a chain of ~4 dependent random 64-B sector reads per k-mer: HBM-latency/sector bound, no MFMA.
+#include <cstring>
+
+#include "blmx_internal.h"
+#include "index_device.h"
+
+namespace blmx {
+
+// The 2^b scan of query_get_hash / query_get_pos_unitig (blight.cpp:729-739 / 699-709).
+// canon(stored) == x  <=>  stored in {x, rc(x)} when x is canonical (x <= rc(x)); a non-canonical x never matches, so
+// no reverse complement is computed inside the loop.  The window is preloaded into registers (NW words) and walked with
+// a top-aligned shift register; like the reference the scan ignores super-k-mer and bucket boundaries.
+// Returns the index j of the first match in [0, 2^LOGP) or -1.
+template <int KW, int LOGP>
+__device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uint64_t g0, int k, Kmer<KW> x, Kmer<KW> xr)
+{
+	constexpr int P = 1 << LOGP;
+	constexpr int NSTREAM = ((P + 30) >> 5) + 1;  // stream words W[KW] .. W[KW+NSTREAM-1]
+	constexpr int NW = KW + NSTREAM;
+	const uint64_t w0 = g0 >> 5;
+	const int s0 = (int)(g0 & 31);
+	uint64_t W[NW];
+#pragma unroll
+	for (int i = 0; i < NW; i++)
+		W[i] = seq[w0 + i];
+	const int sh = 64 * KW - 2 * k;  // top-aligned compare: shift the query instead of every window
+	int j = 0;
+	if constexpr (KW == 1) {
+		const uint64_t M = ~0ull << sh;
+		const uint64_t X = x.lo << sh, XR = xr.lo << sh;
+		uint64_t cur = funnel_left(W[0], W[1], 2 * s0);
+#pragma unroll
+		for (int r = 0; r < NSTREAM; r++) {
+			uint64_t nxt = (r == 0) ? (W[1] << (2 * s0)) : W[1 + r];
+			const int cnt = (r == 0) ? (32 - s0) : 32;
+			for (int t = 0; t < cnt && j < P; t++, j++) {
+				const uint64_t c = cur & M;
+				if (c == X || c == XR)
+					return j;
+				cur = (cur << 2) | (nxt >> 62);
+				nxt <<= 2;
+			}
+		}
+	} else {
+		// 128-bit top-aligned window (hi:lo); sh in [2, 126]
+		uint64_t Mh, Ml, Xh, Xl, XRh, XRl;
+		if (sh >= 64) {
+			Mh = ~0ull << (sh - 64);
+			Ml = 0;
+			Xh = x.lo << (sh - 64);
+			Xl = 0;
+			XRh = xr.lo << (sh - 64);
+			XRl = 0;
+		} else {
+			Mh = ~0ull;
+			Ml = ~0ull << sh;
+			Xh = (x.hi << sh) | (sh ? (x.lo >> (64 - sh)) : 0ull);
+			Xl = x.lo << sh;
+			XRh = (xr.hi << sh) | (sh ? (xr.lo >> (64 - sh)) : 0ull);
+			XRl = xr.lo << sh;
+		}
+		uint64_t ch = funnel_left(W[0], W[1], 2 * s0), cl = funnel_left(W[1], W[2], 2 * s0);
+#pragma unroll
+		for (int r = 0; r < NSTREAM; r++) {
+			uint64_t nxt = (r == 0) ? (W[2] << (2 * s0)) : W[2 + r];
+			const int cnt = (r == 0) ? (32 - s0) : 32;
+			for (int t = 0; t < cnt && j < P; t++, j++) {
+				const uint64_t a = ch & Mh, b = cl & Ml;
+				if ((a == Xh && b == Xl) || (a == XRh && b == XRl))
+					return j;
+				ch = (ch << 2) | (cl >> 62);
+				cl = (cl << 2) | (nxt >> 62);
+				nxt <<= 2;
+			}
+		}
+	}
+	return -1;
+}
+
+template <int KW, int LOGP>
+__global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t* __restrict__ kmers,
+                                               const uint32_t* __restrict__ minis, uint64_t nq, void* __restrict__ out,
+                                               int mode)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq)
+		return;
+	const Kmer<KW> x = load_kmer<KW>(kmers, i);
+	const Kmer<KW> xr = kmer_rc<KW>(x, v.k);
+	int64_t id = -1;
+	int32_t posj = -1;
+	do {
+		uint32_t mini;
+		if (minis) {
+			mini = minis[i];
+			if (mini >= v.nbuckets)  // the reference reads all_buckets[] out of bounds here: defined as absent
+				break;
+		} else {
+			mini = kmer_minimizer<KW>(x, xr, v.k, v.m);
+		}
+		const uint4 bd4 = *reinterpret_cast<const uint4*>(&v.buckets[mini]);
+		const uint64_t bstart = (uint64_t)bd4.x | ((uint64_t)bd4.y << 32);
+		const uint32_t bnt = bd4.z;
+		if (bnt == 0)  // blight.cpp:719-720
+			break;
+		const GroupDesc* gd = &v.groups[mini >> v.gshift];
+		const uint64_t h = mphf_lookup<KW>(v, gd, x);
+		if (h == kNotFound)  // blight.cpp:725-726
+			break;
+		const uint64_t pos = read_position(v.positions, gd->posstart, gd->nbits, h, v.b);
+		if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bnt))  // blight.cpp:729
+			break;
+		if (xr < x)  // non-canonical query: canonR == canon can never hold (blight.cpp:733-735)
+			break;
+		const int j = scan_window<KW, LOGP>(v.seq, bstart + pos, v.k, x, xr);
+		if (j >= 0) {
+			id = (int64_t)(h + gd->prefix);       // blight.cpp:736
+			posj = (int32_t)(pos + (uint64_t)j);  // blight.cpp:706
+		}
+	} while (0);
+	if (mode == kQueryIds)
+		reinterpret_cast<int64_t*>(out)[i] = id;
+	else if (mode == kQueryPos)
+		reinterpret_cast<int32_t*>(out)[i] = posj;
+	else
+		reinterpret_cast<uint8_t*>(out)[i] = id >= 0 ? 1 : 0;
+}
+
+// Generic window for b > 8 (rare): same semantics, words fetched on demand.
+template <int KW>
+__global__ __launch_bounds__(256) void k_query_anyb(DeviceIndexView v, const uint64_t* __restrict__ kmers,
+                                                    const uint32_t* __restrict__ minis, uint64_t nq, void* __restrict__ out,
+                                                    int mode)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq)
+		return;
+	const Kmer<KW> x = load_kmer<KW>(kmers, i);
+	const Kmer<KW> xr = kmer_rc<KW>(x, v.k);
+	int64_t id = -1;
+	int32_t posj = -1;
+	do {
+		uint32_t mini;
+		if (minis) {
+			mini = minis[i];
+			if (mini >= v.nbuckets)
+				break;
+		} else {
+			mini = kmer_minimizer<KW>(x, xr, v.k, v.m);
+		}
+		const BucketDesc bd = v.buckets[mini];
+		if (bd.nt == 0)
+			break;
+		const GroupDesc* gd = &v.groups[mini >> v.gshift];
+		const uint64_t h = mphf_lookup<KW>(v, gd, x);
+		if (h == kNotFound)
+			break;
+		const uint64_t pos = read_position(v.positions, gd->posstart, gd->nbits, h, v.b);
+		if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bd.nt) || xr < x)
+			break;
+		const uint64_t P = 1ull << v.b;
+		for (uint64_t j = 0; j < P; j++) {
+			const Kmer<KW> s = packed_kmer<KW>(v.seq, bd.start + pos + j, v.k);
+			if (s == x || s == xr) {
+				id = (int64_t)(h + gd->prefix);
+				posj = (int32_t)(pos + j);
+				break;
+			}
+		}
+	} while (0);
+	if (mode == kQueryIds)
+		reinterpret_cast<int64_t*>(out)[i] = id;
+	else if (mode == kQueryPos)
+		reinterpret_cast<int32_t*>(out)[i] = posj;
+	else
+		reinterpret_cast<uint8_t*>(out)[i] = id >= 0 ? 1 : 0;
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void k_kmer_groups(int k, int m, int gshift, const uint64_t* __restrict__ kmers, uint64_t nq,
+                                                     uint32_t* __restrict__ groups)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq)
+		return;
+	const Kmer<KW> x = load_kmer<KW>(kmers, i);
+	groups[i] = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m) >> gshift;
+}
+
+// query_sequence_hash front end (blight.cpp:575-591): one lane per k-mer start; each lane encodes its own k
+// characters (str2num, kmer.h:90-98) -- the rolling update of the reference (updateK/updateRCK, blight.cpp:78-98)
+// yields exactly these values.  d_kmer_offs[s] = index of the first k-mer of sequence s in the output.
+template <int KW>
+__global__ __launch_bounds__(256) void k_sequence_kmers(int k, const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ offs,
+                                                        const uint64_t* __restrict__ kmer_offs, uint64_t nseq, uint64_t nk_total,
+                                                        uint64_t* __restrict__ out, int* __restrict__ err)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nk_total)
+		return;
+	// sequence of k-mer i: last s with kmer_offs[s] <= i
+	uint64_t lo = 0, hi = nseq;
+	while (hi - lo > 1) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (kmer_offs[mid] <= i)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const uint64_t p = offs[lo] + (i - kmer_offs[lo]);
+	Kmer<KW> x;
+	x.lo = 0;
+	if constexpr (KW == 2)
+		x.hi = 0;
+	bool bad = false;
+	for (int t = 0; t < k; t++) {
+		const uint32_t c = nuc_code(ascii[p + t]);
+		bad |= c > 3;
+		if constexpr (KW == 2)
+			x.hi = (x.hi << 2) | (x.lo >> 62);
+		x.lo = (x.lo << 2) | (c & 3u);
+	}
+	if constexpr (KW == 1) {
+		if (k < 32)
+			x.lo &= (1ull << (2 * k)) - 1ull;
+	}
+	if (bad)
+		atomicOr(err, 1);
+	const Kmer<KW> c = kmer_canon<KW>(x, k);
+	if constexpr (KW == 1) {
+		out[i] = c.lo;
+	} else {
+		out[2 * i] = c.lo;
+		out[2 * i + 1] = c.hi;
+	}
+}
+
+// ---- primitive KAT kernel (tests) ------------------------------------------------------------------------------------
+template <int KW>
+__global__ void k_primitive(int op, const void* __restrict__ in, uint64_t n, int arg, int arg2, void* __restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	switch (op) {
+	case 0:
+		reinterpret_cast<int32_t*>(out)[i] = revhash32(reinterpret_cast<const uint32_t*>(in)[i]);
+		break;
+	case 1: {  // rcb(uint32_t, m), kmer.h:236-251
+		const uint32_t x = reinterpret_cast<const uint32_t*>(in)[i];
+		reinterpret_cast<uint32_t*>(out)[i] = (uint32_t)(rc_digits64((uint64_t)x) >> (64 - 2 * arg));
+		break;
+	}
+	case 2: {  // ParityCanonical::canonize, kmer.h:480-482
+		const uint32_t x = reinterpret_cast<const uint32_t*>(in)[i];
+		const uint32_t r = (uint32_t)(rc_digits64((uint64_t)x) >> (64 - 2 * arg));
+		reinterpret_cast<uint32_t*>(out)[i] = ((__popc(x) & 1) ? x : r) >> 1;
+		break;
+	}
+	case 3: {
+		const Kmer<KW> x = load_kmer<KW>(reinterpret_cast<const uint64_t*>(in), i);
+		const Kmer<KW> r = kmer_rc<KW>(x, arg);
+		uint64_t* o = reinterpret_cast<uint64_t*>(out);
+		if constexpr (KW == 1) {
+			o[i] = r.lo;
+		} else {
+			o[2 * i] = r.lo;
+			o[2 * i + 1] = r.hi;
+		}
+		break;
+	}
+	case 4: {
+		const Kmer<KW> x = load_kmer<KW>(reinterpret_cast<const uint64_t*>(in), i);
+		reinterpret_cast<uint32_t*>(out)[i] = kmer_minimizer<KW>(x, kmer_rc<KW>(x, arg), arg, arg2);
+		break;
+	}
+	case 5: {
+		LevelHasher hs(reinterpret_cast<const uint64_t*>(in)[i]);
+		for (int l = 0; l < kLevels; l++)
+			reinterpret_cast<uint64_t*>(out)[i * kLevels + l] = hs.next(l);
+		break;
+	}
+	case 6:
+		reinterpret_cast<uint8_t*>(out)[i] = (uint8_t)nuc_code(reinterpret_cast<const uint8_t*>(in)[i]);
+		break;
+	default:
+		break;
+	}
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------
+static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+template <int KW>
+static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, int mode,
+                            hipStream_t s)
+{
+	const DeviceIndexView v = ix.view();
+	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	const unsigned grid = grid_for(nq, 256);
+#define BLMX_Q(LP)                                                                                  \
+	case LP:                                                                                        \
+		hipLaunchKernelGGL((k_query<KW, LP>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode); \
+		break;
+	switch (v.b) {
+		BLMX_Q(0)
+		BLMX_Q(1)
+		BLMX_Q(2)
+		BLMX_Q(3)
+		BLMX_Q(4)
+		BLMX_Q(5)
+		BLMX_Q(6)
+		BLMX_Q(7)
+		BLMX_Q(8)
+	default:
+		hipLaunchKernelGGL((k_query_anyb<KW>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode);
+		break;
+	}
+#undef BLMX_Q
+}
+
+void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
+                  hipStream_t s)
+{
+	if (nq == 0)
+		return;
+	if (ix.KW == 1)
+		launch_query_kw<1>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s);
+	else
+		launch_query_kw<2>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s)
+{
+	if (nq == 0)
+		return;
+	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_kmer_groups<1>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, (int)ix.prm.m, ix.gshift, km,
+		                   nq, d_groups);
+	else
+		hipLaunchKernelGGL((k_kmer_groups<2>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, (int)ix.prm.m, ix.gshift, km,
+		                   nq, d_groups);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, const uint64_t* d_kmer_offs,
+                           uint64_t nseq, uint64_t nk_total, void* d_kmers_out, int* d_err, hipStream_t s)
+{
+	if (nk_total == 0)
+		return;
+	uint64_t* out = reinterpret_cast<uint64_t*>(d_kmers_out);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_sequence_kmers<1>), dim3(grid_for(nk_total, 256)), dim3(256), 0, s, (int)ix.prm.k, d_ascii, d_offs,
+		                   d_kmer_offs, nseq, nk_total, out, d_err);
+	else
+		hipLaunchKernelGGL((k_sequence_kmers<2>), dim3(grid_for(nk_total, 256)), dim3(256), 0, s, (int)ix.prm.k, d_ascii, d_offs,
+		                   d_kmer_offs, nseq, nk_total, out, d_err);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_primitive(int op, int KW, const void* d_in, uint64_t n, int arg, int arg2, void* d_out, hipStream_t s)
+{
+	if (n == 0)
+		return;
+	if (KW == 1)
+		hipLaunchKernelGGL((k_primitive<1>), dim3(grid_for(n, 256)), dim3(256), 0, s, op, d_in, n, arg, arg2, d_out);
+	else
+		hipLaunchKernelGGL((k_primitive<2>), dim3(grid_for(n, 256)), dim3(256), 0, s, op, d_in, n, arg, arg2, d_out);
+	BLMX_HIP(hipGetLastError());
+}
+
+}  // namespace blmx

@@ -1,0 +1,216 @@
+// device_prims.h -- gfx950 device primitives of the Blight hot path (k-mer encoding, reverse complement, canonical
+// forms, minimizer order, BBHash level hashes).  Integer-only; every function cites the reference routine whose
+// results it must reproduce bit for bit (paths relative to the reference repository).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blmx {
+
+constexpr int kLevels = 16;                      // mphf<..., _nb_levels = 16>, bbhash.h:516
+constexpr uint64_t kNotFound = ~0ull;            // ULLONG_MAX, bbhash.h:574
+constexpr uint64_t kSeedH0 = 0xAAAAAAAA55555555ull;  // bbhash.h:221
+constexpr uint64_t kSeedH1 = 0x33333333CCCCCCCCull;  // bbhash.h:227
+constexpr int kLineWords = 8;                    // one 64-byte MPHF line = 1 rank word + 7 data words
+constexpr int kLineData = 7;
+
+// ---- k-mer value types -------------------------------------------------------------------------------------------
+// KW = 1: k <= 32 in one u64 (the reference's shipped kmer_t, kmer.h:18); KW = 2: k <= 63 in (hi, lo) = __uint128_t.
+template <int KW> struct Kmer;
+template <> struct Kmer<1> {
+	uint64_t lo;
+	__host__ __device__ __forceinline__ bool operator==(const Kmer& o) const { return lo == o.lo; }
+	__host__ __device__ __forceinline__ bool operator<=(const Kmer& o) const { return lo <= o.lo; }
+	__host__ __device__ __forceinline__ bool operator<(const Kmer& o) const { return lo < o.lo; }
+};
+template <> struct Kmer<2> {
+	uint64_t lo, hi;
+	__host__ __device__ __forceinline__ bool operator==(const Kmer& o) const { return lo == o.lo && hi == o.hi; }
+	__host__ __device__ __forceinline__ bool operator<=(const Kmer& o) const { return hi < o.hi || (hi == o.hi && lo <= o.lo); }
+	__host__ __device__ __forceinline__ bool operator<(const Kmer& o) const { return hi < o.hi || (hi == o.hi && lo < o.lo); }
+};
+
+// nuc2int, kmer.h:56-69: A0 C1 T2 G3 = (c >> 1) & 3, either case; returns 4 for anything else.
+__device__ __forceinline__ uint32_t nuc_code(uint8_t c)
+{
+	const uint32_t d = (uint32_t)c - 65u;
+	const bool ok = d <= 51u && ((0x0008004500080045ull >> d) & 1ull);
+	return ok ? ((c >> 1) & 3u) : 4u;
+}
+
+// revhash(uint32_t), kmer.h:102-108.  The minimizer order compares the result as SIGNED int32.
+__device__ __forceinline__ int32_t revhash32(uint32_t x)
+{
+	x = ((x >> 16) ^ x) * 0x2c1b3c6du;
+	x = ((x >> 16) ^ x) * 0x297a2d39u;
+	x = ((x >> 16) ^ x);
+	return (int32_t)x;
+}
+
+// Reverse all 32 2-bit digits of a u64 and complement each (XOR 0b10): v_bfrev + pair swap instead of the byte-swap
+// ladder of rcb(), kmer.h:218-232 -- same function.
+__device__ __forceinline__ uint64_t rc_digits64(uint64_t x)
+{
+	uint64_t r = __brevll(x);
+	r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+	return r ^ 0xAAAAAAAAAAAAAAAAull;
+}
+
+template <int KW> __device__ __forceinline__ Kmer<KW> kmer_rc(Kmer<KW> x, int k);
+template <> __device__ __forceinline__ Kmer<1> kmer_rc<1>(Kmer<1> x, int k)  // rcb(uint64_t, n), kmer.h:218-232
+{
+	Kmer<1> r;
+	r.lo = rc_digits64(x.lo) >> (64 - 2 * k);
+	return r;
+}
+template <> __device__ __forceinline__ Kmer<2> kmer_rc<2>(Kmer<2> x, int k)  // rcb(__uint128_t, n), kmer.h:191-214
+{
+	const uint64_t nh = rc_digits64(x.lo), nl = rc_digits64(x.hi);  // full 64-digit reverse: halves swap
+	const int s = 128 - 2 * k;                                       // 2..126 for k in 1..63
+	Kmer<2> r;
+	if (s >= 64) {
+		r.lo = nh >> (s - 64);
+		r.hi = 0;
+	} else {
+		r.lo = (nl >> s) | (nh << (64 - s));
+		r.hi = nh >> s;
+	}
+	return r;
+}
+
+// low 32 bits of (x >> s)
+__device__ __forceinline__ uint32_t kmer_shr32(Kmer<1> x, int s) { return (uint32_t)(x.lo >> s); }
+__device__ __forceinline__ uint32_t kmer_shr32(Kmer<2> x, int s)
+{
+	if (s >= 64)
+		return (uint32_t)(x.hi >> (s - 64));
+	return (uint32_t)((x.lo >> s) | (s ? (x.hi << (64 - s)) : 0ull));
+}
+
+// Minimizer of a k-mer = the parity-canonical m-mer with the smallest SIGNED revhash (minimizer_naive with fix P1,
+// kmer.h:791-810; ParityCanonical kmer.h:475-487).  The reverse-complement m-mers are read from the reverse-complement
+// k-mer (m-mer i of x pairs with m-mer k-m-i of rc(x)), so no per-window rcb is needed.  Ties imply equal values
+// (revhash is a bijection), so the scan order is irrelevant.
+template <int KW> __device__ __forceinline__ uint32_t kmer_minimizer(Kmer<KW> x, Kmer<KW> xr, int k, int m)
+{
+	const uint32_t mask = (m >= 16) ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+	const int w = k - m;
+	uint32_t f = kmer_shr32(x, 0) & mask, r = kmer_shr32(xr, 2 * w) & mask;
+	uint32_t best = ((__popc(f) & 1) ? f : r) >> 1;
+	int32_t best_h = revhash32(best);
+	for (int i = 1; i <= w; i++) {
+		f = kmer_shr32(x, 2 * i) & mask;
+		r = kmer_shr32(xr, 2 * (w - i)) & mask;
+		const uint32_t c = ((__popc(f) & 1) ? f : r) >> 1;
+		const int32_t h = revhash32(c);
+		if (h < best_h) {
+			best_h = h;
+			best = c;
+		}
+	}
+	return best;
+}
+
+// ---- 2-bit packed sequences: nt p lives in bits 63-2(p%32) .. 62-2(p%32) of word p/32 (first nt most significant) ----
+__device__ __forceinline__ uint64_t funnel_left(uint64_t hi, uint64_t lo, int s)  // top 64 bits of (hi:lo) << s, s in 0..63
+{
+	return s ? ((hi << s) | (lo >> (64 - s))) : hi;
+}
+
+template <int KW> __device__ __forceinline__ Kmer<KW> packed_kmer(const uint64_t* __restrict__ seq, uint64_t p, int k);
+template <> __device__ __forceinline__ Kmer<1> packed_kmer<1>(const uint64_t* __restrict__ seq, uint64_t p, int k)
+{
+	const uint64_t w = p >> 5;
+	const int s = 2 * (int)(p & 31);
+	Kmer<1> r;
+	r.lo = funnel_left(seq[w], seq[w + 1], s) >> (64 - 2 * k);
+	return r;
+}
+template <> __device__ __forceinline__ Kmer<2> packed_kmer<2>(const uint64_t* __restrict__ seq, uint64_t p, int k)
+{
+	const uint64_t w = p >> 5;
+	const int s = 2 * (int)(p & 31);
+	const uint64_t a = seq[w], b = seq[w + 1], c = seq[w + 2];
+	const uint64_t v0 = funnel_left(a, b, s), v1 = funnel_left(b, c, s);
+	const int sh = 128 - 2 * k;  // 2..62 for k in 33..63; up to 126 for small k
+	Kmer<2> r;
+	if (sh >= 64) {
+		r.lo = v0 >> (sh - 64);
+		r.hi = 0;
+	} else {
+		r.lo = (v1 >> sh) | (v0 << (64 - sh));
+		r.hi = v0 >> sh;
+	}
+	return r;
+}
+
+template <int KW> __device__ __forceinline__ Kmer<KW> kmer_canon(Kmer<KW> x, int k)  // min_k, blight.cpp:86-91
+{
+	const Kmer<KW> r = kmer_rc<KW>(x, k);
+	return (x <= r) ? x : r;
+}
+
+// ---- BBHash level hashes ---------------------------------------------------------------------------------------------
+// SingleHashFunctor::hash_bis, bbhash.h:172-185
+__device__ __forceinline__ uint64_t hash_bis(uint64_t key, uint64_t seed)
+{
+	uint64_t hash = seed;
+	hash ^= (hash << 7) ^ key * (hash >> 3) ^ (~((hash << 11) + (key ^ (hash >> 5))));
+	hash = (~hash) + (hash << 21);
+	hash = hash ^ (hash >> 24);
+	hash = (hash + (hash << 3)) + (hash << 8);
+	hash = hash ^ (hash >> 14);
+	hash = (hash + (hash << 2)) + (hash << 4);
+	hash = hash ^ (hash >> 28);
+	hash = hash + (hash << 31);
+	return hash;
+}
+
+// XorshiftHashFunctors::iter (bbhash.h:241-250) as a stateful stream: level 0 -> h0, level 1 -> h1, level >= 2 ->
+// xorshift128+ (bbhash.h:233-239) seeded with (h0, h1).  128-bit keys are hashed by their LOW 64 bits only
+// (bbhash.h:160-170: the __int128 overload is never selected -- SURVEY C-7).
+struct LevelHasher {
+	uint64_t s0, s1;
+	uint64_t key;
+	__device__ __forceinline__ explicit LevelHasher(uint64_t k) : s0(0), s1(0), key(k) {}
+	__device__ __forceinline__ uint64_t next(int level)
+	{
+		if (level == 0) {
+			s0 = hash_bis(key, kSeedH0);
+			return s0;
+		}
+		if (level == 1) {
+			s1 = hash_bis(key, kSeedH1);
+			return s1;
+		}
+		uint64_t a = s0;
+		const uint64_t b = s1;
+		s0 = b;
+		a ^= a << 23;
+		s1 = a ^ b ^ (a >> 17) ^ (b >> 26);
+		return s1 + b;
+	}
+};
+
+// fastmod64, bbhash.h:660-662
+__device__ __forceinline__ uint64_t reduce_level(uint64_t hash, uint64_t size) { return __umul64hi(hash, size); }
+
+// ---- wave helpers (wave64) -----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Wave-aggregated append: every lane with pred reserves one slot of *counter; one atomic per wave.
+__device__ __forceinline__ uint64_t wave_append_slot(bool pred, unsigned long long* counter)
+{
+	const uint64_t ballot = __ballot(pred);
+	if (ballot == 0)
+		return 0;
+	const uint32_t lane = lane_id();
+	const int leader = __ffsll((unsigned long long)ballot) - 1;
+	unsigned long long base = 0;
+	if ((int)lane == leader)
+		base = atomicAdd(counter, (unsigned long long)__popcll(ballot));
+	base = __shfl(base, leader);
+	return base + (uint64_t)__popcll(ballot & ((1ull << lane) - 1ull));
+}
+
+}  // namespace blmx

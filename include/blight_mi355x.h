@@ -1,0 +1,135 @@
+/*
+ * blight_mi355x.h -- C ABI of the MI355X-native Blight hot path (libblight_mi355x.so).
+ *
+ * This is the drop-in boundary: plain C types, caller-owned host buffers (or raw device pointers for the *_device
+ * entry points), no exceptions, no C++ or torch types.  The reference has no FFI layer -- its boundary is the public
+ * surface of `class kmer_Set_Light` (reference blight.h:15-136); each entry point below names the member it replaces.
+ * The source-compatible C++ facade that calls this ABI is include/blight.h.
+ *
+ * Semantics are those of the reference with the fixes P1/P2 of SURVEY.md App. B-1 (the shipped reference crashes in
+ * its query path and mis-encodes unitig starts), at -t 1; results (IDs, membership bits, positions) are bit-identical.
+ * All compute runs in hand-written HIP kernels on gfx950; there is no CPU fallback: every entry point that needs the
+ * GPU fails with BLMX_EHIP when no device is usable.
+ */
+#ifndef BLIGHT_MI355X_H
+#define BLIGHT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLMX_OK 0
+#define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
+#define BLMX_ESHORT (-2)  /* a sequence is shorter than k: UB/abort in the reference (blight.cpp:235, kmer.h:705)  */
+#define BLMX_EDNA (-3)    /* character outside ACGTacgt: std::domain_error("Invalid char in DNA"), kmer.h:68       */
+#define BLMX_EIO (-4)     /* file cannot be opened/read: std::runtime_error, blight.cpp:188-189                    */
+#define BLMX_EHIP (-5)    /* HIP runtime error / no usable GPU                                                     */
+#define BLMX_ENOMEM (-6)  /* host or device allocation failed                                                      */
+#define BLMX_ESTATE (-7)  /* call order: query before build, build twice                                           */
+#define BLMX_ELIMIT (-8)  /* input exceeds an implementation limit (e.g. a bucket of >= 2^32 nt, as in the reference) */
+
+typedef struct blmx_index blmx_index;
+
+/* kmer_Set_Light(k, minimizer_length, log2_mphfs_number, log2_superbuckets_number, cores_number, bits_to_save),
+ * reference blight.h:62.  log2_superbuckets / threads are validated like the reference and otherwise unused (no temp
+ * files, no host threads).  kmer_bytes selects the k-mer word: 8 = uint64_t (k <= 32, reference default kmer.h:18),
+ * 16 = __uint128_t (k <= 63, the reference's typedef switch); 0 = choose from k.  device = HIP device ordinal. */
+typedef struct blmx_params {
+	uint32_t k;
+	uint32_t m;
+	uint32_t log2_mphf;
+	uint32_t log2_superbuckets;
+	uint32_t threads;
+	uint32_t bits_saved;
+	uint32_t kmer_bytes;
+	int32_t device;
+} blmx_params;
+
+/* Public counters of kmer_Set_Light (reference blight.h:52-59) + array sizes of the recap (blight.cpp:361-378). */
+typedef struct blmx_stats_t {
+	uint64_t number_kmer;          /* blight.h:52 */
+	uint64_t number_super_kmer;    /* blight.h:53 */
+	uint64_t largest_mphf;         /* blight.h:54 largest_MPHF */
+	uint64_t positions_total_size; /* positions.size() in bits, blight.cpp:305 */
+	uint64_t number_query;         /* blight.h:56: incremented once per k-mer query */
+	uint64_t total_nt;             /* bucketSeq.size() / 2, blight.cpp:280 */
+	uint64_t largest_bucket;       /* largest_bucket_nuc_all, blight.h:59 */
+	uint64_t mphf_bytes;           /* MPHF lines in HBM (bit arrays + interleaved ranks) */
+	uint64_t fallback_keys;        /* entries of the per-group fallback tables (_final_hash, bbhash.h:781) */
+	uint64_t device_bytes;         /* total HBM held by the finished index */
+	uint32_t nbuckets;             /* 2^(2m-1), blight.h:70 */
+	uint32_t ngroups;              /* 2^log2_mphf, blight.h:68 */
+	uint32_t k, m, log2_mphf, bits_saved, kmer_bytes;
+	uint32_t max_levels_used;
+	double build_seconds;          /* wall time of the last build (device work + host orchestration) */
+} blmx_stats_t;
+
+/* ctor / dtor.  On failure *out is NULL and blmx_create_error() returns the reference's exception text
+ * ("kmer size too large", "minimizer_length must be odd", ... blight.h:77-92). */
+int blmx_create(const blmx_params* p, blmx_index** out);
+void blmx_destroy(blmx_index* ix);
+const char* blmx_create_error(void);
+const char* blmx_last_error(const blmx_index* ix);
+
+/* construct_index(file), reference blight.cpp:108-125: 2-line FASTA records (header line skipped, next line =
+ * sequence; blight.cpp:212-229), plain or gzip.  Every sequence must hold >= k nucleotides of ACGTacgt. */
+int blmx_build_from_fasta(blmx_index* ix, const char* path);
+/* Same, from memory: nseq sequences concatenated in `concat`, sequence i = concat[offsets[i] .. offsets[i+1]). */
+int blmx_build_from_sequences(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq);
+/* Same, input already resident in HBM (device pointers: ASCII bytes and nseq+1 offsets).  Used for large synthetic
+ * inputs generated on the device. */
+int blmx_build_from_device_sequences(blmx_index* ix, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq,
+                                     uint64_t total_len);
+
+/* query_kmer_hash(kmer_t canon), reference blight.cpp:545-550, for a batch: canon_kmers = nq little-endian words of
+ * kmer_bytes each (already canonical, as the reference requires); ids_out[i] = ID in [0, number_kmer) or -1. */
+int blmx_query_kmers(blmx_index* ix, const void* canon_kmers, uint64_t nq, int64_t* ids_out);
+/* query_get_hash(canon, minimizer), reference blight.cpp:716-742 (caller-supplied minimizers; minimizers outside
+ * [0, 2^(2m-1)) give -1 where the reference reads out of bounds). */
+int blmx_query_kmers_with_minimizer(blmx_index* ix, const void* canon_kmers, const uint32_t* minimizers, uint64_t nq,
+                                    int64_t* ids_out);
+/* query_get_pos_unitig(canon, minimizer), reference blight.cpp:686-712: bucket-relative position of the FIRST match
+ * in the 2^b window, or -1. */
+int blmx_query_positions(blmx_index* ix, const void* canon_kmers, const uint32_t* minimizers, uint64_t nq,
+                         int32_t* pos_out);
+/* query_kmer_bool, reference blight.cpp:537-541: present_out[i] = 1/0. */
+int blmx_query_membership(blmx_index* ix, const void* canon_kmers, uint64_t nq, uint8_t* present_out);
+/* query_sequence_hash for nseq sequences (reference blight.cpp:575-591): rolling canonical k-mers on the GPU.
+ * ids_out holds sum_i max(0, len_i - k + 1) entries, sequence after sequence; sequences shorter than k contribute
+ * nothing.  Returns BLMX_EDNA on an invalid character. */
+int blmx_query_sequences(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
+/* number of IDs blmx_query_sequences writes for these offsets */
+uint64_t blmx_sequence_kmer_count(const blmx_index* ix, const uint64_t* offsets, uint64_t nseq);
+
+/* Device-resident batch query: d_canon_kmers / d_ids_out are DEVICE pointers, `stream` a hipStream_t (NULL = the
+ * index's own stream).  Asynchronous with respect to the host when a stream is given. */
+int blmx_query_kmers_device(blmx_index* ix, const void* d_canon_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
+/* Minimizer -> owning MPHF group for a batch of canonical k-mers on the device (group = minimizer >> (2m-1-n),
+ * reference blight.cpp:692); used by the multi-GPU router to pick the destination rank. */
+int blmx_kmer_groups_device(blmx_index* ix, const void* d_canon_kmers, uint64_t nq, uint32_t* d_groups_out, void* stream);
+
+int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
+
+/* Copy index arrays back to the host for array-level parity checks (tests only; not needed by callers).
+ * which: 0 bucket_nt u32[nbuckets] | 1 bucket_start u64[nbuckets] | 2 packed sequence u64[ceil(total_nt/32)]
+ *        3 positions u64[ceil(bits/64)] | 4 group nkeys u64 | 5 group prefix u64 | 6 group posstart u64
+ *        7 group nbits u32 | 8 level sizes u64[ngroups*16] | 9 group logical word base u64[ngroups+1]
+ *        10 MPHF logical bit array u64[total words] (levels of all groups back to back, ranks stripped)
+ *        11 fallback keys (kmer_bytes each) | 12 fallback ranks u64 | 13 fallback group u32
+ * Returns the number of ELEMENTS available; copies min(cap, available) elements into out when out != NULL. */
+int64_t blmx_export(blmx_index* ix, int which, void* out, uint64_t cap);
+
+/* Primitive known-answer entry points (device kernels; tests only): op 0 revhash32(u32)->i32, 1 rc32 (arg m),
+ * 2 parity_canon (arg m), 3 kmer rc (arg k), 4 kmer minimizer (arg k, arg2 m) -> u32, 5 level hashes: 16 u64 per key,
+ * 6 nuc code of bytes -> u8 (4 = invalid).  in/out are host buffers. */
+int blmx_primitive(int op, int kmer_bytes, const void* in, uint64_t n, int arg, int arg2, void* out);
+
+const char* blmx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLIGHT_MI355X_H */

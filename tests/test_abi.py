@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/blight_mi355x.h
+declares, and parameter validation reproduces the reference's ctor errors (blight.h:75-92).  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "blight_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(blmx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import blight_amd
+    from blight_amd import build
+    build.build()
+    lib = C.CDLL(blight_amd.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), s
+    lib.blmx_version.restype = C.c_char_p
+    assert b"gfx950" in lib.blmx_version()
+
+
+def test_ctor_validation_messages():
+    import blight_amd
+    lib = blight_amd.load_library()
+    cases = [((33, 7, 5, 3, 1, 6, 8), "kmer size too large"), ((31, 10, 5, 3, 1, 6, 8), "minimizer_length must be odd"),
+             ((31, 17, 5, 3, 1, 6, 8), "minimizer_length size too large"),
+             ((31, 7, 14, 3, 1, 6, 8), "log2_mphfs_number must not be larger than 2*minimizer_length - 1"),
+             ((31, 7, 5, 6, 1, 6, 8), "log2_superbuckets_number must not be larger than log2_mphfs_number"),
+             ((64, 9, 7, 3, 1, 8, 16), "kmer size too large")]
+    for (k, m, n, s, t, b, kb), msg in cases:
+        h = C.c_void_p()
+        p = blight_amd.blmx_params(k, m, n, s, t, b, kb, 0)
+        rc = lib.blmx_create(C.byref(p), C.byref(h))
+        assert rc == blight_amd.BLMX_EINVAL and not h.value
+        assert lib.blmx_create_error().decode() == msg
+        with pytest.raises(ValueError, match=msg.replace("*", r"\*")):
+            blight_amd.kmer_Set_Light(k, m, n, s, t, b, kmer_bytes=kb)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product must fail loudly (BLMX_EHIP), never compute on the host."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    import blight_amd
+    with pytest.raises(blight_amd.BlightError) as e:
+        blight_amd.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    assert e.value.code == blight_amd.BLMX_EHIP
+
+
+def test_product_never_references_the_oracle():
+    """The shipped sources must not import / include / link anything under oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "blight_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"(import\s+oracle|from\s+oracle|oracle/|liborc|blight_oracle)", txt):
+                    bad.append(f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        if re.search(r"(liborc|blight_oracle)", open(os.path.join(ROOT, "include", f)).read()):
+            bad.append(f)
+    assert not bad, bad

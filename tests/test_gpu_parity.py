@@ -1,0 +1,209 @@
+"""GPU parity: the HIP build + query path (through the C ABI) against the golden vectors of the real reference and
+against the CPU oracle, bit for bit -- IDs, membership, positions, counters and every internal array."""
+import gzip
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import blight_amd
+    return blight_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _build(B, k, m, n, b, seqs, kmer_bytes=0):
+    ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kmer_bytes)
+    ix.construct_index_from_sequences(seqs)
+    return ix
+
+
+def test_device_primitives(B):
+    prim = G.primitives()
+    assert np.array_equal(B.primitive(0, prim["revhash_in"]), prim["revhash_out"])
+    for m in (5, 7, 9, 11, 13, 15):
+        assert np.array_equal(B.primitive(1, prim["mmer_in_m%d" % m], m), prim["rc32_m%d" % m])
+        assert np.array_equal(B.primitive(2, prim["mmer_in_m%d" % m], m), prim["parity_m%d" % m])
+    codes = B.primitive(6, np.arange(256, dtype=np.uint8))
+    want = np.where(prim["nuc2int"] < 0, 4, prim["nuc2int"]).astype(np.uint8)
+    assert np.array_equal(codes, want)
+    for kb, ks, ms in ((8, (15, 21, 25, 31, 32), (5, 7, 9)), (16, (33, 47, 63), (7, 9, 11))):
+        for k in ks:
+            x = prim["kmer_in_k%d" % k]
+            assert np.array_equal(B.primitive(3, x, k, kmer_bytes=kb).reshape(x.shape), prim["kmer_rc_k%d" % k])
+            if k == 32:
+                continue
+            for m in ms:
+                assert np.array_equal(B.primitive(4, x, k, m, kmer_bytes=kb), prim["mini_k%d_m%d" % (k, m)])
+    assert np.array_equal(B.primitive(5, prim["hash_keys"]), prim["hash_levels"])
+    assert np.array_equal(B.primitive(5, np.ascontiguousarray(prim["hash_keys128"][:, 0])), prim["hash_levels128"])
+
+
+def _check_against_oracle_arrays(ix, orc):
+    a = orc.arrays()
+    st = ix.stats()
+    for key in ("bucket_nt", "bucket_start", "seq", "positions", "g_nkeys", "g_prefix", "g_posstart"):
+        assert np.array_equal(ix.export(key), a[key]), key
+    assert np.array_equal(ix.export("g_nbits").astype(np.uint8), a["g_nbits"])
+    sizes = ix.export("level_sizes").reshape(-1, 16)
+    wbase = ix.export("g_wbase")
+    bits = ix.export("mphf_bits")
+    fbk, fbr, fbg = [], [], []
+    for g in range(st["ngroups"]):
+        mp = orc.mphf(g)
+        if mp["nwords"]:
+            assert np.array_equal(sizes[g], mp["sizes"]), g
+            assert np.array_equal(bits[int(wbase[g]):int(wbase[g + 1])], mp["bits"]), g
+        else:
+            assert wbase[g] == wbase[g + 1]
+        fbk += mp["fallback_keys"]
+        fbr += mp["fallback_ranks"]
+        fbg += [g] * len(mp["fallback_keys"])
+    # the device table keeps every occurrence of a duplicated key; winners (last of an equal run) = the map
+    dk = G.to_ints(ix.export("fb_keys"), ix.kmer_bytes)
+    dr = [int(x) for x in ix.export("fb_ranks")]
+    dg = [int(x) for x in ix.export("fb_group")]
+    win = [(dg[i], dk[i], dr[i]) for i in range(len(dk)) if i + 1 == len(dk) or (dg[i + 1], dk[i + 1]) != (dg[i], dk[i])]
+    assert win == list(zip(fbg, fbk, fbr))
+
+
+@pytest.mark.parametrize("name", G.case_names())
+def test_golden_case(B, O, name):
+    c = G.Case(name)
+    ix = _build(B, c.k, c.m, c.n, c.b, c.seqs)
+    st = ix.stats()
+    assert (st["number_kmer"], st["number_super_kmer"], st["total_nt"], st["largest_mphf"], st["largest_bucket"],
+            st["positions_total_size"]) == (c.number_kmer, c.number_super_kmer, c.total_nt, c.largest_mphf,
+                                            c.largest_bucket, c.positions_bits)
+    # IDs of every indexed k-mer, in file order (query_sequence_hash over all unitigs)
+    ids = ix.query_sequences_hash(c.seqs)
+    assert np.array_equal(ids, c.ids)
+    # negatives, positional variant, caller-supplied (wrong) minimizers, lower case / reverse complement queries
+    assert np.array_equal(ix.query_kmer_hash(c.neg_kmers), c.neg_ids)
+    assert np.array_equal(ix.query_kmer_bool(c.neg_kmers), c.neg_ids >= 0)
+    assert np.array_equal(ix.query_get_pos_unitig(c["pos_kmers"], c["pos_minis"]).astype(np.int64), c["pos_out"])
+    assert np.array_equal(ix.query_get_hash(c["pos_kmers"], c["wrongmini"]), c["wrongmini_out"])
+    for _, q, qids in c.extra_queries():
+        assert np.array_equal(ix.query_sequence_hash(q), qids)
+    # internal arrays: golden digests (from the real reference) ...
+    assert G.sha(ix.export("bucket_nt")) == str(c["bucket_nt_sha"])
+    assert G.sha(ix.export("bucket_start")) == str(c["bucket_start_sha"])
+    assert G.sha(ix.export("seq")) == str(c["seq_sha"])
+    assert G.sha(ix.export("positions")) == str(c["positions_sha"])
+    for key in ("g_nkeys", "g_prefix", "g_posstart"):
+        assert np.array_equal(ix.export(key), c[key]), key
+    assert np.array_equal(ix.export("g_nbits").astype(np.uint8), c["g_nbits"])
+    sizes = ix.export("level_sizes").reshape(-1, 16)
+    assert np.array_equal(sizes, c["level_sizes"])
+    assert hashlib.sha256(ix.export("mphf_bits").tobytes()).hexdigest() == str(c["mphf_bits_sha"])
+    # ... and element-wise against the oracle (incl. fallback tables)
+    orc = O.Oracle(c.k, c.m, c.n, c.b, c.seqs)
+    _check_against_oracle_arrays(ix, orc)
+    assert ix.number_query > 0
+    ix.close()
+
+
+def test_fasta_plain_gzip_and_reader_quirks(B, O, tmp_path):
+    """construct_index(file): plain and gzip, empty lines tolerated like blight.cpp:212-229."""
+    c = G.Case("lambda_k31_m7_n5_b6")
+    ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    ix.construct_index(G.LAMBDA)
+    assert np.array_equal(ix.query_sequences_hash(c.seqs), c.ids)
+    gz = tmp_path / "l.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(open(G.LAMBDA, "rb").read())
+    ix2 = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    ix2.construct_index(str(gz))
+    assert np.array_equal(ix2.query_sequences_hash(c.seqs), c.ids)
+    quirk = tmp_path / "q.fa"
+    quirk.write_text(">a\n%s\n\nskipped-line\n>b\n\n>c\n%s" % (c.seqs[0], c.seqs[2]))
+    want = O.read_fasta(str(quirk))
+    ix3 = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    ix3.construct_index(str(quirk))
+    orc = O.Oracle(31, 7, 5, 6, want)
+    assert ix3.number_kmer == orc.stats["number_kmer"]
+    assert np.array_equal(ix3.query_sequences_hash(want), np.concatenate([orc.query_sequence(s) for s in want]))
+    tp, fp = ix.file_query(G.LAMBDA)
+    assert (tp, fp) == (48462, 0)  # "Good kmer" / "Erroneous kmers" of the reference's self-query
+
+
+def test_errors(B, tmp_path):
+    ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    with pytest.raises(ValueError, match="Invalid char in DNA"):
+        ix.construct_index_from_sequences(["ACGT" * 10 + "N" + "ACGT" * 10])
+    ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    with pytest.raises(B.BlightError) as e:
+        ix.construct_index_from_sequences(["ACGTACGT"])
+    assert e.value.code == B.BLMX_ESHORT
+    ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    with pytest.raises(OSError):
+        ix.construct_index(str(tmp_path / "missing.fa"))
+    with pytest.raises(B.BlightError) as e:
+        ix.query_kmer_hash([1, 2, 3])
+    assert e.value.code == B.BLMX_ESTATE
+    ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    ix.construct_index_from_sequences(["ACGTTGCAACGTTGCAACGTTGCAACGTTGCA"])
+    assert ix.query_sequence_hash("ACGT").size == 0 and ix.query_sequence_bool("ACGT") == (0, 0)
+    with pytest.raises(ValueError, match="Invalid char in DNA"):
+        ix.query_sequence_hash("ACGTTGCAACGTTGCAACGTNGCAACGTTGCAAA")
+    # empty input: everything absent
+    ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    ix.construct_index_from_sequences([])
+    assert ix.number_kmer == 0 and ix.query_kmer_hash([0, 5, 77]).tolist() == [-1, -1, -1]
+
+
+def _rand_seq(rng, n, alphabet="ACGT"):
+    return "".join(alphabet[i] for i in rng.integers(0, len(alphabet), n))
+
+
+@pytest.mark.parametrize("k,m,n,b,kb", [(31, 9, 7, 6, 8), (31, 7, 3, 4, 8), (27, 11, 14, 5, 8), (63, 9, 7, 8, 16), (47, 7, 5, 3, 16),
+                                        (21, 5, 0, 9, 8), (31, 9, 7, 6, 16)])
+def test_random_vs_oracle(B, O, k, m, n, b, kb):
+    """seeded random unitigs incl. low-complexity ones (duplicates -> fallback, phantoms): everything vs the oracle."""
+    rng = np.random.default_rng(k * 100 + m)
+    seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 80))) for _ in range(1500)]
+    seqs += [_rand_seq(rng, k + int(rng.integers(0, 150)), "AC") for _ in range(60)]
+    seqs += ["A" * (k + 40), seqs[5], seqs[5].lower(), seqs[7][:k]]
+    ix = _build(B, k, m, n, b, seqs, kmer_bytes=kb)
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    st = ix.stats()
+    for f, g in (("number_kmer", "number_kmer"), ("number_super_kmer", "number_super_kmer"), ("total_nt", "total_nt"),
+                 ("largest_mphf", "largest_mphf"), ("largest_bucket", "largest_bucket"), ("positions_total_size", "positions_bits")):
+        assert st[f] == orc.stats[g], f
+    _check_against_oracle_arrays(ix, orc)
+    want = np.concatenate([orc.query_sequence(s) for s in seqs])
+    assert np.array_equal(ix.query_sequences_hash(seqs), want)
+    neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(20000)]
+    neg = [min(x, O.p_rc(x, k, kb)) for x in neg]
+    assert np.array_equal(ix.query_kmer_hash(neg), orc.query_kmers(neg))
+    # near misses: one substitution per sequence (2^b scan, junction phantoms)
+    mut = []
+    for s in seqs[:400]:
+        p = int(rng.integers(0, len(s)))
+        mut.append(s[:p] + "ACGT"[("ACGT".index(s[p].upper()) + 1) % 4] + s[p + 1:])
+    assert np.array_equal(ix.query_sequences_hash(mut), np.concatenate([orc.query_sequence(s) for s in mut]))
+    # non-canonical k-mers can never match (blight.cpp:733-735)
+    km = orc.canonical_kmers(seqs[0])
+    kl = G.to_ints(km, kb)[:50]
+    nonc = [O.p_rc(x, k, kb) for x in kl if O.p_rc(x, k, kb) != x]
+    assert np.array_equal(ix.query_kmer_hash(nonc), orc.query_kmers(nonc))
+
+
+def test_build_is_deterministic(B):
+    rng = np.random.default_rng(3)
+    seqs = [_rand_seq(rng, 31 + int(rng.integers(0, 300))) for _ in range(800)] + [_rand_seq(rng, 60, "AC") for _ in range(40)]
+    a = _build(B, 31, 9, 7, 6, seqs)
+    b = _build(B, 31, 9, 7, 6, seqs)
+    for key in ("seq", "positions", "mphf_bits", "fb_keys", "fb_ranks", "bucket_start"):
+        assert np.array_equal(a.export(key), b.export(key)), key
