@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mer ID queries/s of the MI355X-native Blight hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the query hot path (canonical k-mer -> minimizer -> bucket -> BBHash rank -> position field ->
+2^b window compare -> ID) over one batch of synthetic query k-mers that is already resident in HBM.  The index is a
+seeded synthetic unitig set (BASELINE has no offline genomes: only lambda ships with the reference) built on the GPU by
+the same library.  Rank 0 prints ONE JSON line.
+
+Workload naming: C3 = chr1-scale 2.3e8 31-mers (k31 m9 n7 b6), C4 = human-scale 2.5e9 31-mers
+(k31 m9 n14 b6); 50 % of the queries are indexed k-mers, 50 % uniform random 31-mers.
+
+N > 1: `--mode sharded` (default) partitions the MPHF groups (contiguous minimizer-bucket ranges) over the ranks and routes
+every query k-mer to its owner with an RCCL all-to-all over xGMI (and the IDs back); `--mode replicas` keeps a full index
+per GPU with no data-path collective (upper bound).  Per-GPU query batch is fixed: weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {31: 145, 63: 209}  # algorithmic bytes per query, SURVEY.md section 8(d): B(k=31,b=6)=145, B(k=63,b=8)=209
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+WORKLOADS = {
+    # name: (k, m, log2_mphf, b, indexed k-mers, queries per step per GPU)
+    "C2": (31, 9, 7, 6, 4_600_000, 4_600_000),
+    "C3": (31, 9, 7, 6, 230_000_000, 10_000_000),
+    "C3n14": (31, 9, 14, 6, 230_000_000, 10_000_000),
+    "C4": (31, 9, 14, 6, 2_500_000_000, 100_000_000),
+    "C5": (63, 9, 14, 8, 500_000_000, 100_000_000),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("BLIGHT_BENCH_WORKLOAD", "C4"), choices=sorted(WORKLOADS))
+    ap.add_argument("--kmers", type=int, default=0, help="override the number of indexed k-mers")
+    ap.add_argument("--queries", type=int, default=0, help="override the queries per step per GPU")
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--seed", type=int, default=4)
+    return ap.parse_args()
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def synth_unitigs(torch, dev, n_kmers, k, seed):
+    """Seeded random unitigs in HBM: lengths k-1+Geometric(mean 80), uniform ACGT.  Returns (ascii u8, offsets i64)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n_unitigs = max(1, n_kmers // 80)
+    extra = torch.empty(n_unitigs, device=dev, dtype=torch.float32).geometric_(1.0 / 80.0, generator=g).to(torch.int64)
+    # trim so that the k-mer total is exactly n_kmers
+    csum = torch.cumsum(extra, 0)
+    keep = int(torch.searchsorted(csum, torch.tensor([n_kmers], device=dev, dtype=torch.int64)).item()) + 1
+    keep = min(keep, n_unitigs)
+    extra = extra[:keep].clone()
+    over = int(csum[keep - 1].item()) - n_kmers
+    if over > 0:
+        extra[keep - 1] -= over
+    if int(extra[keep - 1].item()) < 1:
+        extra = extra[:keep - 1]
+    lens = extra + (k - 1)
+    offs = torch.zeros(lens.numel() + 1, device=dev, dtype=torch.int64)
+    torch.cumsum(lens, 0, out=offs[1:])
+    total = int(offs[-1].item())
+    ascii_ = torch.empty(total + 64, device=dev, dtype=torch.uint8)
+    chunk = 1 << 28
+    for s in range(0, total, chunk):
+        e = min(total, s + chunk)
+        c = torch.randint(0, 4, (e - s,), device=dev, dtype=torch.uint8, generator=g)
+        # 0,1,2,3 -> A C G T  (65 67 71 84)
+        ascii_[s:e] = 65 + 2 * c + 2 * (c == 2).to(torch.uint8) + 13 * (c == 3).to(torch.uint8)
+    ascii_[total:] = 0
+    return ascii_, offs, total
+
+
+def synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, seed, kmer_words):
+    """50 % indexed k-mers (uniform over positions), 50 % uniform random k-mers, shuffled; canonical, in HBM."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    npos = nq // 2
+    p = torch.randint(0, total, (npos,), device=dev, dtype=torch.int64, generator=g)
+    u = torch.searchsorted(offs, p, right=True) - 1
+    p = torch.minimum(p, offs[u + 1] - k)
+    q = torch.empty((nq, kmer_words), device=dev, dtype=torch.int64)
+    pos_k = torch.empty((npos, kmer_words), device=dev, dtype=torch.int64)
+    err = torch.zeros(1, device=dev, dtype=torch.int32)
+    ix.kmers_at_device(ascii_.data_ptr(), p.data_ptr(), npos, pos_k.data_ptr(), err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    neg = torch.randint(-(1 << 63), (1 << 63) - 1, (nq - npos, kmer_words), device=dev, dtype=torch.int64, generator=g)
+    ix.canonicalize_device(neg.data_ptr(), nq - npos, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    q[:npos] = pos_k
+    q[npos:] = neg
+    perm = torch.randperm(nq, device=dev, generator=g)
+    q = q[perm].contiguous()
+    is_pos = (perm < npos)
+    return q, is_pos
+
+
+def export_index(ix, st, k, b):
+    """D2H the finished index as numpy arrays for the oracle's CPU query path."""
+    import numpy as np
+    arrays = {name: ix.export(name) for name in ("bucket_nt", "bucket_start", "positions", "g_nkeys", "g_prefix", "g_posstart",
+                                                   "g_nbits", "level_sizes", "g_wbase", "mphf_bits", "fb_keys", "fb_ranks", "fb_group")}
+    seq = ix.export("seq")
+    pad = ((1 << b) + k) // 32 + 8
+    arrays["seq"] = np.concatenate([seq, np.zeros(pad, np.uint64)])
+    return arrays
+
+
+def cpu_baseline(ix, st, args_k, m, n, b, q_host, gpu_ids_host, budget_s):
+    """Time the CPU oracle (restated reference algorithm) on the box's host cores over a bounded sample of the same
+    queries on the same index (image exported from HBM) and cross-check the IDs element-wise with the GPU's."""
+    import numpy as np
+    from oracle import oracle as O
+    t0 = time.time()
+    arrays = export_index(ix, st, args_k, b)
+    orc = O.ImportedOracle(args_k, m, n, b, st["total_nt"], st["number_kmer"], st["positions_total_size"], arrays)
+    t_import = time.time() - t0
+    threads = len(os.sched_getaffinity(0))
+    batch = 200_000
+    done = 0
+    elapsed = 0.0
+    mismatches = 0
+    # 1-thread rate on a small slice (the reference is only valid at -t 1), then all cores
+    t = time.time()
+    ids1 = orc.query_kmers(q_host[:batch], threads=1)
+    t1 = time.time() - t
+    mismatches += int((ids1 != gpu_ids_host[:batch]).sum())
+    while elapsed < budget_s and done < q_host.shape[0]:
+        e = min(q_host.shape[0], done + batch * threads)
+        t = time.time()
+        ids = orc.query_kmers(q_host[done:e], threads=threads)
+        elapsed += time.time() - t
+        mismatches += int((ids != gpu_ids_host[done:e]).sum())
+        done = e
+    orc.close()
+    return {
+        "value": done / elapsed if elapsed > 0 else 0.0, "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": "first %d queries of the same batch on the same index (image exported from HBM, import %.1f s); "
+                  "oracle = plain-C restatement of the reference, OpenMP over queries" % (done, t_import),
+        "single_thread_value": batch / t1, "ids_equal_to_gpu": mismatches == 0, "mismatches": mismatches,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch  # first: one HIP runtime for torch and the library
+    import torch.distributed as dist
+    import blight_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Blight hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    effective_mode = "replicas"  # every rank holds the full index, no data-path collective
+    k, m, n, b, n_kmers, nq = WORKLOADS[args.workload]
+    n_kmers = args.kmers or n_kmers
+    nq = args.queries or nq
+    kw = 1 if k <= 32 else 2
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- index: seeded synthetic unitigs generated in HBM, built by the HIP pipeline
+    t0 = time.time()
+    ascii_, offs, total = synth_unitigs(torch, dev, n_kmers, k, args.seed)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    ix = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
+    t0 = time.time()
+    ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+    t_build = time.time() - t0
+    st = ix.stats()
+    if rank == 0:
+        log("workload %s: %d k-mers, %d super-k-mers, %d unitigs, %.2f GB index, gen %.1f s, build %.1f s (%.1f M k-mers/s)" % (
+            args.workload, st["number_kmer"], st["number_super_kmer"], offs.numel() - 1, st["device_bytes"] / 1e9, t_gen, t_build,
+            st["number_kmer"] / t_build / 1e6))
+
+    # ---- queries (per rank, resident in HBM)
+    q, is_pos = synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank, kw)
+    del ascii_
+    ids = torch.empty(nq, device=dev, dtype=torch.int64)
+    torch.cuda.synchronize()
+
+    def step():
+        ix.query_kmers_device(q.data_ptr(), nq, ids.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- sanity: every indexed query found, no random query found, IDs in range
+    found = ids >= 0
+    n_pos_found = int((found & is_pos).sum().item())
+    n_neg_found = int((found & ~is_pos).sum().item())
+    n_pos = int(is_pos.sum().item())
+    ok = n_pos_found == n_pos and int(ids.max().item()) < st["number_kmer"]
+
+    if rank == 0:
+        value = world * nq * args.steps / dt
+        algo = ALGO_BYTES.get(k, 145)
+        achieved = algo * nq / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "kmer_id_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64" if kw == 1 else "u128", "data": "synthetic",
+            "config": {"workload": "%s: %d indexed %d-mers (seeded synthetic unitigs, k%d m%d n%d b%d), %d queries/step/GPU, "
+                                   "50%% indexed / 50%% random" % (args.workload, st["number_kmer"], k, k, m, n, b, nq),
+                       "parallelism": "1 GPU" if world == 1 else ("%s x%d" % (effective_mode, world)),
+                       "index_bytes": st["device_bytes"], "build_seconds": t_build,
+                       "build_kmers_per_sec": st["number_kmer"] / t_build},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_query", "kernel_ms": kern_ms, "algorithmic_bytes_per_query": algo},
+            "checks": {"indexed_queries_found": n_pos_found, "indexed_queries": n_pos, "random_queries_found": n_neg_found,
+                       "ok": bool(ok)},
+        }
+        if world == 1 and args.cpu_seconds > 0 and kw == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(ix, st, k, m, n, b, q.cpu().numpy().view("uint64").reshape(-1),
+                                                   ids.cpu().numpy(), args.cpu_seconds)
+            except Exception as e:  # the baseline must never hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench sanity check failed")
+
+
+if __name__ == "__main__":
+    main()

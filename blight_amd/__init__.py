@@ -70,6 +70,8 @@ def load_library():
     lib.blmx_sequence_kmer_count.restype = C.c_uint64
     lib.blmx_query_kmers_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_kmer_groups_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.blmx_kmers_at_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.blmx_canonicalize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     lib.blmx_export.restype = C.c_int64
@@ -287,6 +289,12 @@ class kmer_Set_Light:
 
     def kmer_groups_device(self, d_kmers_ptr, nq, d_groups_ptr, stream=None):
         self._check(self._lib.blmx_kmer_groups_device(self._h, d_kmers_ptr, nq, d_groups_ptr, stream))
+
+    def kmers_at_device(self, d_ascii_ptr, d_positions_ptr, nq, d_kmers_out_ptr, d_err_ptr=None, stream=None):
+        self._check(self._lib.blmx_kmers_at_device(self._h, d_ascii_ptr, d_positions_ptr, nq, d_kmers_out_ptr, d_err_ptr, stream))
+
+    def canonicalize_device(self, d_kmers_ptr, nq, stream=None):
+        self._check(self._lib.blmx_canonicalize_device(self._h, d_kmers_ptr, nq, stream))
 
     # -- array export (tests)
     def export(self, name):

@@ -374,6 +374,30 @@ int blmx_kmer_groups_device(blmx_index* h, const void* d_kmers, uint64_t nq, uin
 	});
 }
 
+int blmx_kmers_at_device(blmx_index* h, const void* d_ascii, const uint64_t* d_positions, uint64_t nq, void* d_out, int* d_err, void* stream)
+{
+	if (!h || (nq && (!d_ascii || !d_positions || !d_out)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		launch_kmers_at(h->ix, reinterpret_cast<const uint8_t*>(d_ascii), d_positions, nq, d_out, d_err, s);
+		if (!stream)
+			BLMX_HIP(hipStreamSynchronize(s));
+	});
+}
+
+int blmx_canonicalize_device(blmx_index* h, void* d_kmers, uint64_t nq, void* stream)
+{
+	if (!h || (nq && !d_kmers))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		launch_canonicalize(h->ix, d_kmers, nq, s);
+		if (!stream)
+			BLMX_HIP(hipStreamSynchronize(s));
+	});
+}
+
 int blmx_stats(const blmx_index* h, blmx_stats_t* out)
 {
 	if (!h || !out)

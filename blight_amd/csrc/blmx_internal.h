@@ -151,6 +151,8 @@ void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint3
 // rolling canonical k-mers of ASCII sequences -> canonical k-mer array (KW words each); returns via d_err (BLMX_EDNA)
 void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, const uint64_t* d_kmer_offs,
                            uint64_t nseq, uint64_t total_len, void* d_kmers_out, int* d_err, hipStream_t s);
+void launch_kmers_at(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_pos, uint64_t nq, void* d_out, int* d_err, hipStream_t s);
+void launch_canonicalize(const Index& ix, void* d_kmers, uint64_t nq, hipStream_t s);
 void launch_primitive(int op, int KW, const void* d_in, uint64_t n, int arg, int arg2, void* d_out, hipStream_t s);
 
 }  // namespace blmx

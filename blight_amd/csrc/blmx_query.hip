@@ -241,6 +241,65 @@ __global__ __launch_bounds__(256) void k_sequence_kmers(int k, const uint8_t* __
 	}
 }
 
+// canonical k-mer starting at byte position pos[i] of an ASCII buffer (str2num, kmer.h:90-98 + min_k, blight.cpp:86-91)
+template <int KW>
+__global__ __launch_bounds__(256) void k_kmers_at(int k, const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ pos, uint64_t nq,
+                                                  uint64_t* __restrict__ out, int* __restrict__ err)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq)
+		return;
+	const uint64_t p = pos[i];
+	Kmer<KW> x;
+	x.lo = 0;
+	if constexpr (KW == 2)
+		x.hi = 0;
+	bool bad = false;
+	for (int t = 0; t < k; t++) {
+		const uint32_t c = nuc_code(ascii[p + t]);
+		bad |= c > 3;
+		if constexpr (KW == 2)
+			x.hi = (x.hi << 2) | (x.lo >> 62);
+		x.lo = (x.lo << 2) | (c & 3u);
+	}
+	if (bad && err)
+		atomicOr(err, 1);
+	const Kmer<KW> c = kmer_canon<KW>(x, k);
+	if constexpr (KW == 1) {
+		out[i] = c.lo;
+	} else {
+		out[2 * i] = c.lo;
+		out[2 * i + 1] = c.hi;
+	}
+}
+
+template <int KW> __global__ __launch_bounds__(256) void k_canonicalize(int k, uint64_t* __restrict__ kmers, uint64_t nq)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq)
+		return;
+	Kmer<KW> x = load_kmer<KW>(kmers, i);
+	if constexpr (KW == 1) {
+		if (k < 32)
+			x.lo &= (1ull << (2 * k)) - 1ull;
+	} else {
+		if (k <= 32) {
+			x.hi = 0;
+			if (k < 32)
+				x.lo &= (1ull << (2 * k)) - 1ull;
+		} else {
+			x.hi &= (1ull << (2 * k - 64)) - 1ull;
+		}
+	}
+	const Kmer<KW> c = kmer_canon<KW>(x, k);
+	if constexpr (KW == 1) {
+		kmers[i] = c.lo;
+	} else {
+		kmers[2 * i] = c.lo;
+		kmers[2 * i + 1] = c.hi;
+	}
+}
+
 // ---- primitive KAT kernel (tests) ------------------------------------------------------------------------------------
 template <int KW>
 __global__ void k_primitive(int op, const void* __restrict__ in, uint64_t n, int arg, int arg2, void* __restrict__ out)
@@ -363,6 +422,30 @@ void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64
 	else
 		hipLaunchKernelGGL((k_sequence_kmers<2>), dim3(grid_for(nk_total, 256)), dim3(256), 0, s, (int)ix.prm.k, d_ascii, d_offs,
 		                   d_kmer_offs, nseq, nk_total, out, d_err);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_kmers_at(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_pos, uint64_t nq, void* d_out, int* d_err, hipStream_t s)
+{
+	if (nq == 0)
+		return;
+	uint64_t* out = reinterpret_cast<uint64_t*>(d_out);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_kmers_at<1>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, d_ascii, d_pos, nq, out, d_err);
+	else
+		hipLaunchKernelGGL((k_kmers_at<2>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, d_ascii, d_pos, nq, out, d_err);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_canonicalize(const Index& ix, void* d_kmers, uint64_t nq, hipStream_t s)
+{
+	if (nq == 0)
+		return;
+	uint64_t* km = reinterpret_cast<uint64_t*>(d_kmers);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_canonicalize<1>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, km, nq);
+	else
+		hipLaunchKernelGGL((k_canonicalize<2>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, km, nq);
 	BLMX_HIP(hipGetLastError());
 }
 

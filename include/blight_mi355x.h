@@ -111,6 +111,15 @@ int blmx_query_kmers_device(blmx_index* ix, const void* d_canon_kmers, uint64_t 
  * reference blight.cpp:692); used by the multi-GPU router to pick the destination rank. */
 int blmx_kmer_groups_device(blmx_index* ix, const void* d_canon_kmers, uint64_t nq, uint32_t* d_groups_out, void* stream);
 
+/* Device utilities for callers that keep their data in HBM (bench, pipelines); all pointers are DEVICE pointers.
+ * blmx_kmers_at_device: canonical k-mer (str2num + min with rcb, reference kmer.h:90-98, blight.cpp:86-91) starting at
+ * each given byte position of an ASCII buffer; the caller guarantees position + k <= end of its sequence.  *d_err_flag
+ * (int, may be NULL) is OR-ed with 1 on a character outside ACGTacgt.
+ * blmx_canonicalize_device: in place, x -> min(x mod 4^k, rcb(x mod 4^k)) for arbitrary words (random negatives). */
+int blmx_kmers_at_device(blmx_index* ix, const void* d_ascii, const uint64_t* d_positions, uint64_t nq, void* d_kmers_out,
+                         int* d_err_flag, void* stream);
+int blmx_canonicalize_device(blmx_index* ix, void* d_kmers, uint64_t nq, void* stream);
+
 int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
 
 /* Copy index arrays back to the host for array-level parity checks (tests only; not needed by callers).
