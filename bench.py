@@ -112,6 +112,25 @@ def synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, seed, kmer_words):
     return q, is_pos
 
 
+def host_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives one GPU's
+    share of the host, not all of its cores)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def export_index(ix, st, k, b):
     """D2H the finished index as numpy arrays for the oracle's CPU query path."""
     import numpy as np
@@ -132,7 +151,7 @@ def cpu_baseline(ix, st, args_k, m, n, b, q_host, gpu_ids_host, budget_s):
     arrays = export_index(ix, st, args_k, b)
     orc = O.ImportedOracle(args_k, m, n, b, st["total_nt"], st["number_kmer"], st["positions_total_size"], arrays)
     t_import = time.time() - t0
-    threads = len(os.sched_getaffinity(0))
+    threads = host_cores()
     batch = 200_000
     done = 0
     elapsed = 0.0

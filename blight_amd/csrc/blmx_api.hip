@@ -489,17 +489,19 @@ int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
 			copy_out(v.data(), 8, v.size());
 			break;
 		}
-		case 10: {  // logical level bit arrays: strip the rank word of every 64-B line
-			std::vector<uint64_t> hl((size_t)ix.total_lines * kLineWords);
+		case 10: {  // logical level bit arrays: strip the rank word of every 16-B line
+			std::vector<uint32_t> hl((size_t)ix.total_lines * kLineWords32);
 			if (!hl.empty()) {
-				BLMX_HIP(hipMemcpyAsync(hl.data(), ix.lines.p, hl.size() * 8, hipMemcpyDeviceToHost, s));
+				BLMX_HIP(hipMemcpyAsync(hl.data(), ix.lines.p, hl.size() * 4, hipMemcpyDeviceToHost, s));
 				BLMX_HIP(hipStreamSynchronize(s));
 			}
 			std::vector<uint64_t> v((size_t)ix.total_logical_words);
 			for (uint32_t g = 0; g < ng; g++) {
 				const GroupDesc& gd = ix.h_groups[g];
-				for (uint64_t w = 0; w < gd.nwords; w++)
-					v[gd.wbase + w] = hl[(gd.line_base + w / kLineData) * kLineWords + 1 + w % kLineData];
+				for (uint64_t w32 = 0; w32 < 2 * gd.nwords; w32++) {
+					const uint64_t x = hl[(gd.line_base + w32 / kLineData32) * kLineWords32 + 1 + w32 % kLineData32];
+					v[gd.wbase + (w32 >> 1)] |= x << (32 * (w32 & 1));
+				}
 			}
 			copy_out(v.data(), 8, v.size());
 			break;

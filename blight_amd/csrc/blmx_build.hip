@@ -13,7 +13,7 @@
 //   K6  k_expand_keys                   canonical k-mer of every valid position, in (bucket, position) order (:421-451)
 //   K7  k_mphf_mark / k_mphf_survive    BBHash levels for ALL groups at once (bbhash.h:677-709): atomicOr test-and-set,
 //                                       collision bitmap, survivors compacted with wave-aggregated appends
-//   K8  k_line_popc / scan / k_line_write  clear collisions (bbhash.h:358-368) + ranks (bbhash.h:447-465) -> 64-B lines
+//   K8  k_line_popc / scan / k_line_write  clear collisions (bbhash.h:358-368) + ranks (bbhash.h:447-465) -> 16-B lines [u32 rank | 96 bits]
 //   K9  fallback table (bbhash.h:711-728) ; k_fill_positions (blight.cpp:486-519)
 //
 // All build-time atomics are ORs into zeroed arrays or order-independent appends that are sorted afterwards, so the
@@ -387,11 +387,38 @@ __global__ void k_mphf_mark(BuildGroups bg, const uint64_t* __restrict__ keys, c
 		atomicOr(&coll[w], mask);
 }
 
+// Block-aggregated append: every thread of the block calls this; ONE atomic per block reserves the slots (a single
+// hot counter serialises at ~12 ns per atomic on MI355X, so per-wave appends dominated the level time).
+__device__ __forceinline__ uint64_t block_append_slot(bool pred, unsigned long long* counter)
+{
+	__shared__ uint32_t s_wave_cnt[16];
+	__shared__ unsigned long long s_base;
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = (blockDim.x + 63) >> 6;
+	const uint64_t ballot = __ballot(pred);
+	if (lane == 0)
+		s_wave_cnt[wave] = (uint32_t)__popcll(ballot);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (uint32_t w = 0; w < nwaves; w++) {
+			const uint32_t c = s_wave_cnt[w];
+			s_wave_cnt[w] = total;
+			total += c;
+		}
+		s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+	}
+	__syncthreads();
+	return s_base + s_wave_cnt[wave] + (uint64_t)__popcll(ballot & ((1ull << lane) - 1ull));
+}
+
+constexpr unsigned kSurviveBlock = 1024;
+
 // keys whose level bit collided go on to the next level (their bit is cleared when the lines are written)
 template <int KW>
-__global__ void k_mphf_survive(BuildGroups bg, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ list, uint64_t count,
-                               int level, const unsigned long long* __restrict__ coll, uint32_t* __restrict__ next,
-                               unsigned long long* __restrict__ next_count)
+__global__ __launch_bounds__(kSurviveBlock) void k_mphf_survive(BuildGroups bg, const uint64_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ list, uint64_t count, int level,
+                                                                const unsigned long long* __restrict__ coll, uint32_t* __restrict__ next,
+                                                                unsigned long long* __restrict__ next_count)
 {
 	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	bool survives = false;
@@ -402,7 +429,7 @@ __global__ void k_mphf_survive(BuildGroups bg, const uint64_t* __restrict__ keys
 		const uint64_t w = level_bit_address<KW>(bg, keys, idx, level, mask);
 		survives = (coll[w] & mask) != 0;
 	}
-	const uint64_t slot = wave_append_slot(survives, next_count);
+	const uint64_t slot = block_append_slot(survives, next_count);
 	if (survives)
 		next[slot] = (uint32_t)idx;
 }
@@ -421,7 +448,18 @@ __device__ __forceinline__ uint32_t group_of_line(const uint64_t* __restrict__ l
 	return lo;
 }
 
-// data words of line L: logical words wbase + 7*(L - line_base) .. +6, collisions cleared (bbhash.h:358-368)
+// Level bits of line L of its group: logical 32-bit words 3*(L - line_base) .. +2 of the group's level array (the u64
+// build arrays viewed as little-endian u32 pairs), collisions cleared (bbhash.h:358-368).
+__device__ __forceinline__ uint32_t line_data_word(const GroupDesc* __restrict__ gd, const unsigned long long* __restrict__ bits,
+                                                   const unsigned long long* __restrict__ coll, uint64_t w32)
+{
+	if (w32 >= 2 * gd->nwords)
+		return 0u;
+	const uint64_t w = gd->wbase + (w32 >> 1);
+	const unsigned long long v = bits[w] & ~coll[w];
+	return (uint32_t)((w32 & 1) ? (v >> 32) : v);
+}
+
 __global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
                             const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
                             uint64_t* __restrict__ linepc)
@@ -435,37 +473,29 @@ __global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t
 	}
 	const uint32_t g = group_of_line(line_base, ngroups, L);
 	const GroupDesc* gd = &groups[g];
-	const uint64_t first = (L - line_base[g]) * kLineData;
+	const uint64_t first = (L - line_base[g]) * kLineData32;
 	uint64_t pc = 0;
-	for (int s = 0; s < kLineData; s++) {
-		const uint64_t lw = first + s;
-		if (lw < gd->nwords)
-			pc += (uint64_t)__popcll(bits[gd->wbase + lw] & ~coll[gd->wbase + lw]);
-	}
+	for (int s = 0; s < kLineData32; s++)
+		pc += (uint64_t)__popc(line_data_word(gd, bits, coll, first + s));
 	linepc[L] = pc;
 }
 
 __global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
                              const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
-                             const uint64_t* __restrict__ linepre, uint64_t* __restrict__ lines)
+                             const uint64_t* __restrict__ linepre, uint4* __restrict__ lines)
 {
 	const uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (L >= nlines)
 		return;
 	const uint32_t g = group_of_line(line_base, ngroups, L);
 	const GroupDesc* gd = &groups[g];
-	const uint64_t first = (L - line_base[g]) * kLineData;
-	uint64_t out[kLineWords];
-	out[0] = linepre[L] - linepre[line_base[g]];  // rank restarts at 0 in every group (bbhash.h:447-465)
-	for (int s = 0; s < kLineData; s++) {
-		const uint64_t lw = first + s;
-		out[1 + s] = (lw < gd->nwords) ? (bits[gd->wbase + lw] & ~coll[gd->wbase + lw]) : 0ull;
-	}
-	ulonglong2* o = reinterpret_cast<ulonglong2*>(lines + L * kLineWords);
-	o[0] = make_ulonglong2(out[0], out[1]);
-	o[1] = make_ulonglong2(out[2], out[3]);
-	o[2] = make_ulonglong2(out[4], out[5]);
-	o[3] = make_ulonglong2(out[6], out[7]);
+	const uint64_t first = (L - line_base[g]) * kLineData32;
+	uint4 o;
+	o.x = (uint32_t)(linepre[L] - linepre[line_base[g]]);  // rank restarts at 0 in every group (bbhash.h:447-465)
+	o.y = line_data_word(gd, bits, coll, first);
+	o.z = line_data_word(gd, bits, coll, first + 1);
+	o.w = line_data_word(gd, bits, coll, first + 2);
+	lines[L] = o;
 }
 
 // total set bits per group (= first fallback rank, bbhash.h:554)
@@ -857,7 +887,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			}
 			gd.nwords = total_bits / 64;
 			wbase += gd.nwords;
-			lbase += (gd.nwords + kLineData - 1) / kLineData;
+			lbase += (2 * gd.nwords + kLineData32 - 1) / kLineData32;
 		} else {
 			// no MPHF for an empty group (blight.cpp:452); size 64 keeps the probe arithmetic defined, never reached
 			for (int l = 0; l < kLevels; l++)
@@ -918,7 +948,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		BLMX_HIP(dst.alloc((count + 1) * 4, false, s));
 		nxt = dst.as<uint32_t>();
 		BLMX_HIP(hipMemsetAsync(d_cnt.p, 0, 8, s));
-		hipLaunchKernelGGL((k_mphf_survive<KW>), dim3(grid_for(count)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
+		hipLaunchKernelGGL((k_mphf_survive<KW>), dim3(grid_for(count, kSurviveBlock)), dim3(kSurviveBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
 		                   d_coll.as<unsigned long long>(), nxt, d_cnt.as<unsigned long long>());
 		BLMX_HIP(hipGetLastError());
 		count = read_scalar(d_cnt.as<unsigned long long>(), s);
@@ -927,12 +957,12 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			F = count;
 	}
 
-	// ---- K8: collisions cleared + ranks -> 64-B lines
+	// ---- K8: collisions cleared + ranks -> 16-B lines [u32 rank | 96 bits]
 	DevBuf d_linepc, d_linepre, d_gpopc;
 	BLMX_HIP(d_linepc.alloc((total_lines + 1) * 8, false, s));
 	BLMX_HIP(d_linepre.alloc((total_lines + 1) * 8, false, s));
 	BLMX_HIP(d_gpopc.alloc(((size_t)ngroups + 1) * 8, false, s));
-	BLMX_HIP(ix.lines.alloc((total_lines + 1) * kLineWords * 8, true, s));
+	BLMX_HIP(ix.lines.alloc((total_lines + 1) * kLineBytes, true, s));
 	hipLaunchKernelGGL(k_line_popc, dim3(grid_for(total_lines + 1)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
 	                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>());
 	BLMX_HIP(hipGetLastError());
@@ -940,7 +970,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	if (total_lines)
 		hipLaunchKernelGGL(k_line_write, dim3(grid_for(total_lines)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
 		                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepre.as<uint64_t>(),
-		                   ix.lines.as<uint64_t>());
+		                   ix.lines.as<uint4>());
 	hipLaunchKernelGGL(k_group_popc, dim3(grid_for(ngroups)), dim3(kBlock), 0, s, d_line_base.as<uint64_t>(), d_linepre.as<uint64_t>(), ngroups,
 	                   d_gpopc.as<uint64_t>());
 	BLMX_HIP(hipGetLastError());
@@ -1023,7 +1053,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	st.positions_total_size = total_pos;
 	st.total_nt = total_nt;
 	st.largest_bucket = largest_bucket;
-	st.mphf_bytes = total_lines * kLineWords * 8;
+	st.mphf_bytes = total_lines * kLineBytes;
 	st.fallback_keys = F;
 	st.nbuckets = nbuckets;
 	st.ngroups = ngroups;

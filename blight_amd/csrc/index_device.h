@@ -21,33 +21,27 @@ template <> __device__ __forceinline__ Kmer<2> load_kmer<2>(const uint64_t* __re
 }
 
 // level_finder_tmp + bitVector::rank (bbhash.h:617-663, 467-480): probe levels until a set bit is found and rank it.
-// One probe = one 64-B line (rank word + 7 data words), so the rank costs no second memory access.
+// One probe = ONE 16-B load: a line holds [u32 rank | 96 level bits], so the rank costs no second memory access.
+// Logical bit b of the group's level array lives in line (b>>5)/3, data word (b>>5)%3, bit b&31.
 template <int KW>
 __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, Kmer<KW> x)
 {
 	LevelHasher hs(x.lo);
-	const uint64_t line_base = gd->line_base;
+	const uint4* __restrict__ lines = reinterpret_cast<const uint4*>(v.lines) + gd->line_base;
 	uint64_t off = 0;
 	for (int lv = 0; lv < kLevels; lv++) {
 		const uint64_t size = gd->size[lv];
 		const uint64_t bit = off + reduce_level(hs.next(lv), size);
-		const uint64_t lw = bit >> 6;
-		const uint64_t line = lw / kLineData;
-		const uint32_t slot = (uint32_t)(lw - line * kLineData);
-		// the whole 64-B line in one go: rank word + 7 data words
-		const ulonglong2* L = reinterpret_cast<const ulonglong2*>(v.lines + (line_base + line) * kLineWords);
-		const ulonglong2 a = L[0], b = L[1], c = L[2], d = L[3];
-		const uint64_t wds[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-		uint64_t word = 0, before = 0;
-#pragma unroll
-		for (int s = 0; s < kLineData; s++) {
-			const uint64_t wv = wds[1 + s];
-			word = ((uint32_t)s == slot) ? wv : word;
-			before += ((uint32_t)s < slot) ? (uint64_t)__popcll(wv) : 0ull;
+		const uint64_t w32 = bit >> 5;
+		const uint64_t line = w32 / kLineData32;
+		const uint32_t slot = (uint32_t)(w32 - line * kLineData32);
+		const uint4 L = lines[line];
+		const uint32_t word = slot == 0 ? L.y : (slot == 1 ? L.z : L.w);
+		const uint32_t bi = (uint32_t)bit & 31u;
+		if ((word >> bi) & 1u) {
+			const uint32_t before = (slot > 0 ? __popc(L.y) : 0) + (slot > 1 ? __popc(L.z) : 0);
+			return (uint64_t)(L.x + before + __popc(word & ((1u << bi) - 1u)));
 		}
-		const uint32_t bi = (uint32_t)bit & 63u;
-		if ((word >> bi) & 1ull)
-			return wds[0] + before + (uint64_t)__popcll(word & ((1ull << bi) - 1ull));
 		off += size;
 	}
 	return kNotFound;
