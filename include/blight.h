@@ -1,0 +1,276 @@
+// blight.h -- source-compatible facade of the reference's `class kmer_Set_Light` (reference blight.h:15-136) over the
+// MI355X C ABI (blight_mi355x.h / libblight_mi355x.so).  A program written against the reference -- bench_blight.cpp,
+// the coloured / abundance de Bruijn graph snippets -- compiles against this header unchanged and links with
+// -lblight_mi355x instead of blight.o.
+//
+// What is kept: the constructor signature and its std::invalid_argument messages (blight.h:62-92), construct_index,
+// query_kmer_hash / query_kmer_bool / query_get_hash / single_query / query_sequence_hash / query_sequence_bool /
+// file_query, the public counters callers read (number_kmer, number_super_kmer, number_query, largest_MPHF,
+// positions_total_size, bit_per_kmer), and the typedefs kmer_t / minimizer_t / ksize_t / bitsize_t (kmer.h:15-19).
+// What is not: the reference's internal containers (bucketSeq, positions, all_buckets, all_mphf: the index lives in
+// HBM) and its declared-but-never-defined members.  Every query runs on the GPU; batch overloads (std::vector<kmer_t>)
+// are added because a scalar call pays one kernel launch per k-mer.
+//
+// Define BLIGHT_KMER_128 before including this header for k > 32 (the reference's `kmer_t = __uint128_t` switch).
+#ifndef BLIGHT_MI355X_FACADE_H
+#define BLIGHT_MI355X_FACADE_H
+
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdint>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "blight_mi355x.h"
+
+using nuc_t = uint_fast8_t;      // kmer.h:15
+using bitsize_t = uint_fast8_t;  // kmer.h:16
+using ksize_t = bitsize_t;       // kmer.h:17
+#ifdef BLIGHT_KMER_128
+using kmer_t = __uint128_t;  // kmer.h:18 (k <= 63)
+#else
+using kmer_t = uint64_t;  // kmer.h:18 (k <= 32)
+#endif
+using minimizer_t = uint32_t;  // kmer.h:19
+#ifndef _GNU_SOURCE
+typedef unsigned int uint;
+#endif
+
+class kmer_Set_Light {
+public:
+	const ksize_t _k, _minimizer_length;
+	const ksize_t _core_number;
+	const bitsize_t bit_saved_sub;
+
+	size_t number_kmer = 0;
+	size_t number_super_kmer = 0;
+	size_t largest_MPHF = 0;
+	size_t positions_total_size = 0;
+	size_t number_query = 0;
+	double bit_per_kmer = 0;
+	uint largest_bucket_nuc_all = 0;
+	const uint gammaFactor = 2;
+
+	// blight.h:62 -- same argument order and meaning; std::invalid_argument with the reference's messages
+	kmer_Set_Light(uint k, ksize_t minimizer_length, bitsize_t log2_mphfs_number, bitsize_t log2_superbuckets_number, uint cores_number,
+	               uint bits_to_save, int device = 0)
+	    : _k((ksize_t)k), _minimizer_length(minimizer_length), _core_number((ksize_t)cores_number), bit_saved_sub((bitsize_t)bits_to_save)
+	{
+		blmx_params p;
+		p.k = k;
+		p.m = minimizer_length;
+		p.log2_mphf = log2_mphfs_number;
+		p.log2_superbuckets = log2_superbuckets_number;
+		p.threads = cores_number;
+		p.bits_saved = bits_to_save;
+		p.kmer_bytes = (uint32_t)sizeof(kmer_t);
+		p.device = device;
+		const int rc = blmx_create(&p, &_h);
+		if (rc == BLMX_EINVAL)
+			throw std::invalid_argument(blmx_create_error());
+		if (rc != BLMX_OK)
+			throw std::runtime_error(blmx_create_error());
+	}
+	kmer_Set_Light(const kmer_Set_Light&) = delete;
+	kmer_Set_Light& operator=(const kmer_Set_Light&) = delete;
+	~kmer_Set_Light() { blmx_destroy(_h); }
+
+	// blight.cpp:108-125 (prints the reference's timing lines and index recap, blight.cpp:361-378)
+	void construct_index(const std::string& input_file)
+	{
+		const auto t1 = std::chrono::high_resolution_clock::now();
+		check(blmx_build_from_fasta(_h, input_file.c_str()));
+		refresh();
+		const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count();
+		std::cout << "Indexes created: " << secs << " seconds." << std::endl;
+		std::cout << "The whole indexing took me " << secs << " seconds." << std::endl;
+		std::cout << "----------------------INDEX RECAP----------------------------" << std::endl;
+		std::cout << "Kmer in graph: " << intToString(number_kmer) << std::endl;
+		std::cout << "Super Kmer in graph: " << intToString(number_super_kmer) << std::endl;
+		if (number_super_kmer)
+			std::cout << "Average size of Super Kmer: " << intToString(number_kmer / number_super_kmer) << std::endl;
+		std::cout << "Total size of the partitionned graph: " << intToString(_st.total_nt) << std::endl;
+		std::cout << "Largest MPHF: " << intToString(largest_MPHF) << std::endl;
+		std::cout << "Largest Bucket: " << intToString(largest_bucket_nuc_all) << std::endl;
+		if (number_kmer) {
+			std::cout << "Size of the partitionned graph (bit per kmer): " << (double)(2 * _st.total_nt) / number_kmer << std::endl;
+			std::cout << "Total Positions size (bit per kmer): " << (double)positions_total_size / number_kmer << std::endl;
+			std::cout << "TOTAL Bits per kmer (without bbhash): " << bit_per_kmer << std::endl;
+			std::cout << "MPHF size in HBM incl. ranks (bit per kmer): " << (double)(8 * _st.mphf_bytes) / number_kmer << std::endl;
+		}
+	}
+
+	// blight.cpp:545-550
+	int64_t query_kmer_hash(kmer_t canon)
+	{
+		int64_t id = -1;
+		check(blmx_query_kmers(_h, &canon, 1, &id));
+		number_query += 1;
+		return id;
+	}
+	std::vector<int64_t> query_kmer_hash(const std::vector<kmer_t>& canon)
+	{
+		std::vector<int64_t> ids(canon.size());
+		check(blmx_query_kmers(_h, canon.data(), canon.size(), ids.data()));
+		number_query += canon.size();
+		return ids;
+	}
+	// blight.cpp:537-541
+	bool query_kmer_bool(kmer_t canon) { return query_kmer_hash(canon) >= 0; }
+	// blight.cpp:716-742
+	int64_t query_get_hash(const kmer_t canon, uint32_t minimizer)
+	{
+		int64_t id = -1;
+		check(blmx_query_kmers_with_minimizer(_h, &canon, &minimizer, 1, &id));
+		number_query += 1;
+		return id;
+	}
+	// blight.cpp:686-712
+	int32_t query_get_pos_unitig(const kmer_t canon, minimizer_t minimizer)
+	{
+		int32_t pos = -1;
+		check(blmx_query_positions(_h, &canon, &minimizer, 1, &pos));
+		number_query += 1;
+		return pos;
+	}
+	// blight.cpp:658-660
+	bool single_query(minimizer_t minimizer, kmer_t kastor) { return query_get_pos_unitig(kastor, minimizer) >= 0; }
+
+	// blight.cpp:575-591
+	std::vector<int64_t> query_sequence_hash(const std::string& query)
+	{
+		const uint64_t offs[2] = {0, query.size()};
+		std::vector<int64_t> res(blmx_sequence_kmer_count(_h, offs, 1));
+		check(blmx_query_sequences(_h, query.data(), offs, 1, res.data()));
+		number_query += res.size();
+		return res;
+	}
+	// many sequences in one launch (ids of sequence i follow those of sequence i-1)
+	std::vector<int64_t> query_sequences_hash(const std::vector<std::string>& queries)
+	{
+		std::string concat;
+		std::vector<uint64_t> offs(1, 0);
+		for (const auto& q : queries) {
+			concat += q;
+			offs.push_back(concat.size());
+		}
+		std::vector<int64_t> res(blmx_sequence_kmer_count(_h, offs.data(), queries.size()));
+		check(blmx_query_sequences(_h, concat.data(), offs.data(), queries.size(), res.data()));
+		number_query += res.size();
+		return res;
+	}
+	// blight.cpp:554-571 -> (found, not found)
+	std::pair<uint32_t, uint32_t> query_sequence_bool(const std::string& query)
+	{
+		uint32_t res = 0, fail = 0;
+		for (int64_t id : query_sequence_hash(query))
+			(id >= 0 ? res : fail)++;
+		return std::make_pair(res, fail);
+	}
+
+	// blight.cpp:746-799: 2-line FASTA records in batches (BATCH_SIZE 512, blight.cpp:129), sequences shorter than k are
+	// skipped (:782), prints "QUERY RECAP 2"
+	void file_query(const std::string& query_file)
+	{
+		const auto t1 = std::chrono::high_resolution_clock::now();
+		gzFile f = gzopen(query_file.c_str(), "rb");
+		if (!f)
+			throw std::runtime_error("Problem with files opening");
+		uint64_t TP = 0, FP = 0;
+		std::vector<std::string> batch;
+		std::string line;
+		auto flush = [&]() {
+			if (batch.empty())
+				return;
+			for (int64_t id : query_sequences_hash(batch))
+				(id >= 0 ? TP : FP)++;
+			batch.clear();
+		};
+		for (;;) {
+			if (!read_line(f, line))
+				break;
+			if (line.empty()) {
+				if (!read_line(f, line))
+					break;
+				continue;
+			}
+			if (!read_line(f, line))
+				break;
+			if (line.empty())
+				continue;
+			if (line.size() >= _k)
+				batch.push_back(line);
+			if (batch.size() >= 4096)
+				flush();
+		}
+		flush();
+		gzclose(f);
+		std::cout << "-----------------------QUERY RECAP 2----------------------------" << std::endl;
+		std::cout << "Good kmer: " << intToString(TP) << std::endl;
+		std::cout << "Erroneous kmers: " << intToString(FP) << std::endl;
+		std::cout << "Query performed: " << intToString(number_query) << std::endl;
+		const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count();
+		std::cout << "The whole QUERY took me " << secs << " seconds." << std::endl;
+	}
+
+	blmx_index* handle() const { return _h; }
+
+private:
+	blmx_index* _h = nullptr;
+	blmx_stats_t _st{};
+
+	void check(int rc)
+	{
+		if (rc == BLMX_OK)
+			return;
+		const std::string msg = blmx_last_error(_h);
+		if (rc == BLMX_EINVAL)
+			throw std::invalid_argument(msg);
+		if (rc == BLMX_EDNA)
+			throw std::domain_error("Invalid char in DNA");  // kmer.h:68
+		throw std::runtime_error(msg.empty() ? "blight_mi355x error" : msg);
+	}
+	void refresh()
+	{
+		blmx_stats(_h, &_st);
+		number_kmer = _st.number_kmer;
+		number_super_kmer = _st.number_super_kmer;
+		largest_MPHF = _st.largest_mphf;
+		positions_total_size = _st.positions_total_size;
+		largest_bucket_nuc_all = (uint)_st.largest_bucket;
+		bit_per_kmer = number_kmer ? ((double)(2 * _st.total_nt) + (double)positions_total_size) / number_kmer : 0;  // blight.cpp:373-375
+	}
+	static bool read_line(gzFile f, std::string& line)
+	{
+		line.clear();
+		char buf[1 << 16];
+		bool got = false;
+		while (gzgets(f, buf, (int)sizeof buf)) {
+			got = true;
+			const size_t n = std::char_traits<char>::length(buf);
+			if (n && buf[n - 1] == '\n') {
+				line.append(buf, n - 1);
+				return true;
+			}
+			line.append(buf, n);
+		}
+		return got;
+	}
+	static std::string intToString(uint64_t n)  // blight.cpp:35-47: thousands separators
+	{
+		if (n < 1000)
+			return std::to_string(n);
+		std::string end(std::to_string(n % 1000));
+		if (end.size() == 3)
+			return intToString(n / 1000) + "," + end;
+		if (end.size() == 2)
+			return intToString(n / 1000) + ",0" + end;
+		return intToString(n / 1000) + ",00" + end;
+	}
+};
+
+#endif  // BLIGHT_MI355X_FACADE_H
