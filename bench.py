@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {31: 145, 63: 209}  # algorithmic bytes per query, SURVEY.md section 8(d): B(k=31,b=6)=145, B(k=63,b=8)=209
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# HBM bytes per k_query launch from rocprofv3 PMC passes of this same command (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; FETCH_SIZE
+# calibrated = 1.000 on random 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern):
+# profiles/r01_pmc_k_query_c4.txt.  Only quoted for the workload it was measured on.
+TRAFFIC_BYTES = {"C4": (3.70468e7 + 781250) * 1024}
 
 WORKLOADS = {
     # name: (k, m, log2_mphf, b, indexed k-mers, queries per step per GPU)
@@ -190,13 +194,20 @@ def main():
         log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Blight hot path has no CPU fallback")
+    # rehearsal on a ONE-GPU box: all ranks share cuda:0 and the collectives run over gloo through host memory
+    rehearsal = os.environ.get("BLIGHT_DIST_HOST_STAGING") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    effective_mode = "replicas"  # every rank holds the full index, no data-path collective
+    effective_mode = args.mode if world > 1 else "single"
     k, m, n, b, n_kmers, nq = WORKLOADS[args.workload]
     n_kmers = args.kmers or n_kmers
     nq = args.queries or nq
@@ -209,6 +220,8 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     ix = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
+    if effective_mode == "sharded":
+        ix.set_shard(rank, world)  # this rank keeps the MPHF groups it owns; IDs stay global
     t0 = time.time()
     ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
     t_build = time.time() - t0
@@ -224,8 +237,17 @@ def main():
     ids = torch.empty(nq, device=dev, dtype=torch.int64)
     torch.cuda.synchronize()
 
-    def step():
-        ix.query_kmers_device(q.data_ptr(), nq, ids.data_ptr(), stream)
+    if effective_mode == "sharded":
+        from blight_amd.dist import DeviceOps, ShardedQuerier
+        bounds = torch.from_numpy(ix.shard_bounds().astype("int32")).to(dev)
+        querier = ShardedQuerier(DeviceOps(ix, dev), bounds)
+
+        def step():
+            nonlocal ids
+            ids = querier.query(q)  # route -> all-to-all-v (RCCL/xGMI) -> owner's k_query -> all-to-all-v back -> un-permute
+    else:
+        def step():
+            ix.query_kmers_device(q.data_ptr(), nq, ids.data_ptr(), stream)
 
     for _ in range(args.warmup):
         step()
@@ -246,7 +268,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=("cpu" if rehearsal else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -256,6 +278,10 @@ def main():
     n_neg_found = int((found & ~is_pos).sum().item())
     n_pos = int(is_pos.sum().item())
     ok = n_pos_found == n_pos and int(ids.max().item()) < st["number_kmer"]
+    if world > 1:
+        okt = torch.tensor([1 if ok else 0], device=("cpu" if rehearsal else dev), dtype=torch.int32)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
 
     if rank == 0:
         value = world * nq * args.steps / dt
@@ -268,10 +294,11 @@ def main():
             "config": {"workload": "%s: %d indexed %d-mers (seeded synthetic unitigs, k%d m%d n%d b%d), %d queries/step/GPU, "
                                    "50%% indexed / 50%% random" % (args.workload, st["number_kmer"], k, k, m, n, b, nq),
                        "parallelism": "1 GPU" if world == 1 else ("%s x%d" % (effective_mode, world)),
-                       "index_bytes": st["device_bytes"], "build_seconds": t_build,
+                       "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
                        "build_kmers_per_sec": st["number_kmer"] / t_build},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_query", "kernel_ms": kern_ms, "algorithmic_bytes_per_query": algo},
+                         "traffic": TRAFFIC_BYTES.get(args.workload) if world == 1 else None, "kernel": "k_query",
+                         "kernel_ms": kern_ms if world == 1 else None, "algorithmic_bytes_per_query": algo},
             "checks": {"indexed_queries_found": n_pos_found, "indexed_queries": n_pos, "random_queries_found": n_neg_found,
                        "ok": bool(ok)},
         }

@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
+ABI_VERSION = 3  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 _u64p = C.POINTER(C.c_uint64)
@@ -31,7 +32,8 @@ class blmx_stats_t(C.Structure):
                                           "number_query", "total_nt", "largest_bucket", "mphf_bytes", "fallback_keys",
                                           "device_bytes")] + \
                [(n, C.c_uint32) for n in ("nbuckets", "ngroups", "k", "m", "log2_mphf", "bits_saved", "kmer_bytes",
-                                          "max_levels_used")] + [("build_seconds", C.c_double)]
+                                          "max_levels_used")] + [("build_seconds", C.c_double), ("local_number_kmer", C.c_uint64)] + \
+               [(n, C.c_uint32) for n in ("shard_rank", "shard_world", "shard_group_lo", "shard_group_hi")]
 
 
 _lib = None
@@ -72,10 +74,19 @@ def load_library():
     lib.blmx_kmer_groups_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_kmers_at_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.blmx_canonicalize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.blmx_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.blmx_shard_bounds.argtypes = [C.c_void_p, _u32p]
+    lib.blmx_route_count_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.blmx_route_scatter_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
+    lib.blmx_unpermute_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     lib.blmx_export.restype = C.c_int64
     lib.blmx_primitive.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+    if lib.blmx_abi_version() != ABI_VERSION:
+        raise ImportError("libblight_mi355x.so ABI version %d != binding %d: rebuild (python -m blight_amd.build)" % (
+            lib.blmx_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -295,6 +306,25 @@ class kmer_Set_Light:
 
     def canonicalize_device(self, d_kmers_ptr, nq, stream=None):
         self._check(self._lib.blmx_canonicalize_device(self._h, d_kmers_ptr, nq, stream))
+
+    # -- multi-GPU sharding
+    def set_shard(self, rank, world):
+        self._check(self._lib.blmx_set_shard(self._h, rank, world))
+
+    def shard_bounds(self):
+        world = self.stats()["shard_world"]
+        b = np.zeros(world + 1, dtype=np.uint32)
+        self._check(self._lib.blmx_shard_bounds(self._h, b.ctypes.data_as(_u32p)))
+        return b
+
+    def route_count_device(self, d_kmers, nq, d_bounds, world, d_dest, d_counts, stream=None):
+        self._check(self._lib.blmx_route_count_device(self._h, d_kmers, nq, d_bounds, world, d_dest, d_counts, stream))
+
+    def route_scatter_device(self, d_kmers, d_dest, nq, d_offsets, world, d_sorted, d_order, d_cursor, stream=None):
+        self._check(self._lib.blmx_route_scatter_device(self._h, d_kmers, d_dest, nq, d_offsets, world, d_sorted, d_order, d_cursor, stream))
+
+    def unpermute_device(self, d_vals, d_order, nq, d_out, stream=None):
+        self._check(self._lib.blmx_unpermute_device(self._h, d_vals, d_order, nq, d_out, stream))
 
     # -- array export (tests)
     def export(self, name):

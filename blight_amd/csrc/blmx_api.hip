@@ -146,6 +146,7 @@ void query_host(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_
 extern "C" {
 
 const char* blmx_version(void) { return "blight-mi355x 0.1 (gfx950)"; }
+int blmx_abi_version(void) { return BLMX_ABI_VERSION; }
 const char* blmx_create_error(void) { return g_create_err.c_str(); }
 const char* blmx_last_error(const blmx_index* ix) { return ix ? ix->ix.err.c_str() : g_create_err.c_str(); }
 
@@ -398,6 +399,66 @@ int blmx_canonicalize_device(blmx_index* h, void* d_kmers, uint64_t nq, void* st
 	});
 }
 
+int blmx_set_shard(blmx_index* h, uint32_t rank, uint32_t world)
+{
+	if (!h)
+		return BLMX_EINVAL;
+	if (h->ix.built)
+		return fail(h, BLMX_ESTATE, "blmx_set_shard must precede the build");
+	if (world == 0 || world > 255 || rank >= world)
+		return fail(h, BLMX_EINVAL, "need rank < world <= 255");
+	h->ix.shard_rank = rank;
+	h->ix.shard_world = world;
+	return BLMX_OK;
+}
+
+int blmx_shard_bounds(const blmx_index* h, uint32_t* bounds_out)
+{
+	if (!h || !bounds_out || !h->ix.built)
+		return BLMX_EINVAL;
+	for (size_t i = 0; i < h->ix.shard_bounds.size(); i++)
+		bounds_out[i] = h->ix.shard_bounds[i];
+	return BLMX_OK;
+}
+
+int blmx_route_count_device(blmx_index* h, const void* d_kmers, uint64_t nq, const uint32_t* d_bounds, uint32_t world, uint8_t* d_dest,
+                            uint64_t* d_counts, void* stream)
+{
+	if (!h || !d_bounds || !d_counts || world == 0 || world > 255 || (nq && (!d_kmers || !d_dest)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		launch_route_count(h->ix, d_kmers, nq, d_bounds, world, d_dest, d_counts, s);
+		if (!stream)
+			BLMX_HIP(hipStreamSynchronize(s));
+	});
+}
+
+int blmx_route_scatter_device(blmx_index* h, const void* d_kmers, const uint8_t* d_dest, uint64_t nq, const uint64_t* d_offsets, uint32_t world,
+                              void* d_sorted, uint32_t* d_order, uint64_t* d_cursor, void* stream)
+{
+	if (!h || !d_offsets || !d_cursor || world == 0 || world > 255 || nq >= 0xffffffffull || (nq && (!d_kmers || !d_dest || !d_sorted || !d_order)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		launch_route_scatter(h->ix, d_kmers, d_dest, nq, d_offsets, world, d_sorted, d_order, d_cursor, s);
+		if (!stream)
+			BLMX_HIP(hipStreamSynchronize(s));
+	});
+}
+
+int blmx_unpermute_device(blmx_index* h, const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, void* stream)
+{
+	if (!h || (nq && (!d_vals || !d_order || !d_out)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		launch_unpermute(d_vals, d_order, nq, d_out, s);
+		if (!stream)
+			BLMX_HIP(hipStreamSynchronize(s));
+	});
+}
+
 int blmx_stats(const blmx_index* h, blmx_stats_t* out)
 {
 	if (!h || !out)
@@ -410,6 +471,8 @@ int blmx_stats(const blmx_index* h, blmx_stats_t* out)
 	out->log2_mphf = h->ix.prm.log2_mphf;
 	out->bits_saved = h->ix.prm.bits_saved;
 	out->kmer_bytes = h->ix.prm.kmer_bytes;
+	out->shard_rank = h->ix.shard_rank;
+	out->shard_world = h->ix.shard_world;
 	return BLMX_OK;
 }
 

@@ -199,6 +199,25 @@ __global__ void k_sk_minis(const uint64_t* __restrict__ src, const uint64_t* __r
 	sk_mini[i] = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m);
 }
 
+// ---- sharding: per-group key histogram over ALL super-k-mers, then keep the owned ones -------------------------------
+__global__ void k_group_hist(const uint32_t* __restrict__ sk_mini, const uint64_t* __restrict__ sk_pos, const uint64_t* __restrict__ sk_last,
+                             uint64_t nsk, int gshift, unsigned long long* __restrict__ ghist)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nsk)
+		return;
+	atomicAdd(&ghist[sk_mini[i] >> gshift], (unsigned long long)(sk_last[i] - sk_pos[i] + 1));
+}
+
+__global__ void k_shard_flags(const uint32_t* __restrict__ sk_mini, uint64_t nsk, int gshift, uint32_t glo, uint32_t ghi, uint8_t* __restrict__ flags)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nsk)
+		return;
+	const uint32_t g = sk_mini[i] >> gshift;
+	flags[i] = (g >= glo && g < ghi) ? 1 : 0;
+}
+
 // ---- K4 ----------------------------------------------------------------------------------------------------------------
 __global__ void k_sorted_lengths(const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
                                  const uint64_t* __restrict__ sk_last, uint64_t nsk, int k, uint64_t* __restrict__ len_nt,
@@ -781,6 +800,70 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_Hpre.release();
 	d_Epre.release();
 
+	// ---- sharding: every rank sees the whole input, derives the same key-balanced group boundaries from the
+	// global per-group key histogram, and keeps only the super-k-mers of its own groups.  IDs stay global (id_base).
+	uint64_t id_base = 0, global_N = 0;
+	const uint64_t global_nsk = nsk;
+	const uint32_t world = ix.shard_world, rank = ix.shard_rank;
+	uint32_t glo = 0, ghi = ngroups;
+	ix.shard_bounds.assign((size_t)world + 1, 0);
+	ix.shard_bounds[world] = ngroups;
+	if (world > 1) {
+		DevBuf d_ghist;
+		BLMX_HIP(d_ghist.alloc((size_t)ngroups * 8, true, s));
+		if (nsk)
+			hipLaunchKernelGGL(k_group_hist, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_skmini.as<uint32_t>(), d_skpos.as<uint64_t>(),
+			                   d_sklast.as<uint64_t>(), nsk, gshift, d_ghist.as<unsigned long long>());
+		std::vector<uint64_t> h_hist(ngroups);
+		BLMX_HIP(hipMemcpyAsync(h_hist.data(), d_ghist.p, (size_t)ngroups * 8, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+		std::vector<uint64_t> pre((size_t)ngroups + 1, 0);
+		for (uint32_t g = 0; g < ngroups; g++)
+			pre[g + 1] = pre[g] + h_hist[g];
+		global_N = pre[ngroups];
+		for (uint32_t r = 1; r < world; r++) {
+			const uint64_t target = (uint64_t)(((unsigned __int128)global_N * r) / world);
+			ix.shard_bounds[r] = (uint32_t)(std::lower_bound(pre.begin(), pre.begin() + ngroups, target) - pre.begin());
+		}
+		glo = ix.shard_bounds[rank];
+		ghi = ix.shard_bounds[rank + 1];
+		id_base = pre[glo];
+		DevBuf d_flags, d_cnt, d_pos2, d_last2, d_mini2;
+		BLMX_HIP(d_flags.alloc(nsk + 1, false, s));
+		BLMX_HIP(d_cnt.alloc(8, true, s));
+		BLMX_HIP(d_pos2.alloc((nsk + 1) * 8, false, s));
+		BLMX_HIP(d_last2.alloc((nsk + 1) * 8, false, s));
+		BLMX_HIP(d_mini2.alloc((nsk + 1) * 4, false, s));
+		uint64_t kept = 0;
+		if (nsk) {
+			hipLaunchKernelGGL(k_shard_flags, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_skmini.as<uint32_t>(), nsk, gshift, glo, ghi,
+			                   d_flags.as<uint8_t>());
+			BLMX_HIP(hipGetLastError());
+			size_t bytes = 0;
+			BLMX_HIP(rocprim::select(nullptr, bytes, d_skpos.as<uint64_t>(), d_flags.as<uint8_t>(), d_pos2.as<uint64_t>(), d_cnt.as<uint64_t>(),
+			                         (size_t)nsk, s));
+			void* tmp = sc.get(bytes);
+			BLMX_HIP(rocprim::select(tmp, bytes, d_skpos.as<uint64_t>(), d_flags.as<uint8_t>(), d_pos2.as<uint64_t>(), d_cnt.as<uint64_t>(),
+			                         (size_t)nsk, s));
+			BLMX_HIP(rocprim::select(tmp, bytes, d_sklast.as<uint64_t>(), d_flags.as<uint8_t>(), d_last2.as<uint64_t>(), d_cnt.as<uint64_t>(),
+			                         (size_t)nsk, s));
+			size_t bytes32 = 0;
+			BLMX_HIP(rocprim::select(nullptr, bytes32, d_skmini.as<uint32_t>(), d_flags.as<uint8_t>(), d_mini2.as<uint32_t>(), d_cnt.as<uint64_t>(),
+			                         (size_t)nsk, s));
+			tmp = sc.get(std::max(bytes, bytes32));
+			BLMX_HIP(rocprim::select(tmp, bytes32, d_skmini.as<uint32_t>(), d_flags.as<uint8_t>(), d_mini2.as<uint32_t>(), d_cnt.as<uint64_t>(),
+			                         (size_t)nsk, s));
+			kept = read_scalar(d_cnt.as<uint64_t>(), s);
+		}
+		std::swap(d_skpos.p, d_pos2.p);
+		std::swap(d_skpos.bytes, d_pos2.bytes);
+		std::swap(d_sklast.p, d_last2.p);
+		std::swap(d_sklast.bytes, d_last2.bytes);
+		std::swap(d_skmini.p, d_mini2.p);
+		std::swap(d_skmini.bytes, d_mini2.bytes);
+		nsk = kept;
+	}
+
 	// ---- K4: stable sort by minimizer, offsets, bucket + group tables
 	DevBuf d_smini, d_order, d_lennt, d_lenk, d_ntstart, d_keystart;
 	BLMX_HIP(d_smini.alloc((nsk + 1) * 4, false, s));
@@ -1022,7 +1105,10 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			ix.h_groups[g].fb_count = h_fc[g];
 		}
 	}
-	// final group table (with fallback ranges)
+	// final group table (with fallback ranges); a shard's IDs are global: add the key count of all lower groups
+	if (id_base)
+		for (uint32_t g = 0; g < ngroups; g++)
+			ix.h_groups[g].prefix += id_base;
 	BLMX_HIP(ix.groups.alloc((size_t)ngroups * sizeof(GroupDesc), false, s));
 	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
 
@@ -1047,8 +1133,13 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	ix.total_lines = total_lines;
 	ix.total_logical_words = total_words;
 	blmx_stats_t& st = ix.st;
-	st.number_kmer = N;
-	st.number_super_kmer = nsk;
+	st.number_kmer = world > 1 ? global_N : N;
+	st.local_number_kmer = N;
+	st.number_super_kmer = world > 1 ? global_nsk : nsk;
+	st.shard_rank = rank;
+	st.shard_world = world;
+	st.shard_group_lo = glo;
+	st.shard_group_hi = ghi;
 	st.largest_mphf = largest_mphf;
 	st.positions_total_size = total_pos;
 	st.total_nt = total_nt;

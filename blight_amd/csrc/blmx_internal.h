@@ -102,6 +102,8 @@ struct Index {
 	int gshift = 0;
 	uint32_t nbuckets = 0, ngroups = 0;
 	bool built = false;
+	uint32_t shard_rank = 0, shard_world = 1;
+	std::vector<uint32_t> shard_bounds;  // world + 1 group boundaries (identical on every rank)
 	hipStream_t stream = nullptr;
 	std::string err;
 	std::mutex mu;  // serialises host-buffer queries (shared staging buffers)
@@ -153,6 +155,11 @@ void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64
                            uint64_t nseq, uint64_t total_len, void* d_kmers_out, int* d_err, hipStream_t s);
 void launch_kmers_at(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_pos, uint64_t nq, void* d_out, int* d_err, hipStream_t s);
 void launch_canonicalize(const Index& ix, void* d_kmers, uint64_t nq, hipStream_t s);
+void launch_route_count(const Index& ix, const void* d_kmers, uint64_t nq, const uint32_t* d_bounds, uint32_t world, uint8_t* d_dest,
+                        uint64_t* d_counts, hipStream_t s);
+void launch_route_scatter(const Index& ix, const void* d_kmers, const uint8_t* d_dest, uint64_t nq, const uint64_t* d_offsets, uint32_t world,
+                          void* d_sorted, uint32_t* d_order, uint64_t* d_cursor, hipStream_t s);
+void launch_unpermute(const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, hipStream_t s);
 void launch_primitive(int op, int KW, const void* d_in, uint64_t n, int arg, int arg2, void* d_out, hipStream_t s);
 
 }  // namespace blmx

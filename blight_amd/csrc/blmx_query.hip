@@ -300,6 +300,70 @@ template <int KW> __global__ __launch_bounds__(256) void k_canonicalize(int k, u
 	}
 }
 
+// ---- multi-GPU routing --------------------------------------------------------------------------------------
+// destination rank of a k-mer = the rank whose group range [bounds[r], bounds[r+1]) holds minimizer >> gshift
+template <int KW>
+__global__ __launch_bounds__(256) void k_route_count(int k, int m, int gshift, const uint64_t* __restrict__ kmers, uint64_t nq,
+                                                     const uint32_t* __restrict__ bounds, uint32_t world, uint8_t* __restrict__ dest,
+                                                     unsigned long long* __restrict__ counts)
+{
+	__shared__ uint32_t s_cnt[256];
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nq) {
+		const Kmer<KW> x = load_kmer<KW>(kmers, i);
+		const uint32_t g = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m) >> gshift;
+		uint32_t d = 0;
+		for (uint32_t r = 1; r < world; r++)
+			d += (g >= bounds[r]) ? 1u : 0u;
+		dest[i] = (uint8_t)d;
+		atomicAdd(&s_cnt[d], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < world && s_cnt[threadIdx.x])
+		atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void k_route_scatter(const uint64_t* __restrict__ kmers, const uint8_t* __restrict__ dest, uint64_t nq,
+                                                       const uint64_t* __restrict__ offsets, uint32_t world, uint64_t* __restrict__ sorted,
+                                                       uint32_t* __restrict__ order, unsigned long long* __restrict__ cursor)
+{
+	__shared__ uint32_t s_cnt[256];
+	__shared__ unsigned long long s_base[256];
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t d = 0, local = 0;
+	if (i < nq) {
+		d = dest[i];
+		local = atomicAdd(&s_cnt[d], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < world)
+		s_base[threadIdx.x] = offsets[threadIdx.x] + (s_cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]) : 0ull);
+	__syncthreads();
+	if (i < nq) {
+		const uint64_t p = s_base[d] + local;
+		if constexpr (KW == 1) {
+			sorted[p] = kmers[i];
+		} else {
+			sorted[2 * p] = kmers[2 * i];
+			sorted[2 * p + 1] = kmers[2 * i + 1];
+		}
+		order[p] = (uint32_t)i;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_unpermute(const int64_t* __restrict__ vals, const uint32_t* __restrict__ order, uint64_t nq,
+                                                   int64_t* __restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nq)
+		out[order[i]] = vals[i];
+}
+
 // ---- primitive KAT kernel (tests) ------------------------------------------------------------------------------------
 template <int KW>
 __global__ void k_primitive(int op, const void* __restrict__ in, uint64_t n, int arg, int arg2, void* __restrict__ out)
@@ -446,6 +510,48 @@ void launch_canonicalize(const Index& ix, void* d_kmers, uint64_t nq, hipStream_
 		hipLaunchKernelGGL((k_canonicalize<1>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, km, nq);
 	else
 		hipLaunchKernelGGL((k_canonicalize<2>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, km, nq);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_route_count(const Index& ix, const void* d_kmers, uint64_t nq, const uint32_t* d_bounds, uint32_t world, uint8_t* d_dest,
+                        uint64_t* d_counts, hipStream_t s)
+{
+	BLMX_HIP(hipMemsetAsync(d_counts, 0, (size_t)world * 8, s));
+	if (nq == 0)
+		return;
+	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	unsigned long long* cnt = reinterpret_cast<unsigned long long*>(d_counts);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_route_count<1>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, (int)ix.prm.m, ix.gshift, km, nq, d_bounds,
+		                   world, d_dest, cnt);
+	else
+		hipLaunchKernelGGL((k_route_count<2>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, (int)ix.prm.m, ix.gshift, km, nq, d_bounds,
+		                   world, d_dest, cnt);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_route_scatter(const Index& ix, const void* d_kmers, const uint8_t* d_dest, uint64_t nq, const uint64_t* d_offsets, uint32_t world,
+                          void* d_sorted, uint32_t* d_order, uint64_t* d_cursor, hipStream_t s)
+{
+	BLMX_HIP(hipMemsetAsync(d_cursor, 0, (size_t)world * 8, s));
+	if (nq == 0)
+		return;
+	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	unsigned long long* cur = reinterpret_cast<unsigned long long*>(d_cursor);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_route_scatter<1>), dim3(grid_for(nq, 256)), dim3(256), 0, s, km, d_dest, nq, d_offsets, world,
+		                   reinterpret_cast<uint64_t*>(d_sorted), d_order, cur);
+	else
+		hipLaunchKernelGGL((k_route_scatter<2>), dim3(grid_for(nq, 256)), dim3(256), 0, s, km, d_dest, nq, d_offsets, world,
+		                   reinterpret_cast<uint64_t*>(d_sorted), d_order, cur);
+	BLMX_HIP(hipGetLastError());
+}
+
+void launch_unpermute(const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, hipStream_t s)
+{
+	if (nq == 0)
+		return;
+	hipLaunchKernelGGL(k_unpermute, dim3(grid_for(nq, 256)), dim3(256), 0, s, d_vals, d_order, nq, d_out);
 	BLMX_HIP(hipGetLastError());
 }
 

@@ -1,0 +1,103 @@
+"""Sharded multi-GPU queries: one process per GPU, MPHF groups (contiguous minimizer-bucket ranges,
+reference blight.cpp:692) partitioned over the ranks by key count, and ONE exchange step per query batch:
+
+    local k-mers --route (minimizer -> group -> owner rank)--> all-to-all-v of k-mers  (RCCL over xGMI, `nccl` backend)
+                 owner runs the query kernel on its shard
+                 all-to-all-v of the 8-byte IDs back --> un-permute into the caller's order
+
+The reference has no communication at all (single process, OpenMP); this is the MI355X-native equivalent of its shared
+memory.  all-to-all-v uses every point-to-point xGMI link at once (each pairwise flow has its own link), payload is
+8 (16) B out + 8 B back per remote query.
+
+The exchange choreography lives in `ShardedQuerier.query()` and only talks to an `ops` object, so that it is exercised by
+the world_size-2 `gloo` CPU tests (tests/test_dist_gloo.py, with numpy ops and the CPU oracle as the per-rank engine) and
+runs unchanged on GPUs with `DeviceOps` (hand-written HIP routing kernels + the HIP query kernel).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DeviceOps:
+    """Per-rank operations on the GPU: everything is a kernel of libblight_mi355x.so on torch's current stream."""
+
+    def __init__(self, index, device):
+        self.ix = index
+        self.dev = device
+        self.kw = index.kmer_bytes // 8
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def empty_kmers(self, n):
+        return torch.empty((n, self.kw), device=self.dev, dtype=torch.int64)
+
+    def empty_ids(self, n):
+        return torch.empty(n, device=self.dev, dtype=torch.int64)
+
+    def route(self, kmers, bounds_dev, world):
+        """-> (k-mers grouped by destination rank, order, counts per destination [host list])"""
+        nq = kmers.shape[0]
+        dest = torch.empty(nq, device=self.dev, dtype=torch.uint8)
+        counts = torch.empty(world, device=self.dev, dtype=torch.int64)
+        self.ix.route_count_device(kmers.data_ptr(), nq, bounds_dev.data_ptr(), world, dest.data_ptr(), counts.data_ptr(), self._stream())
+        offsets = torch.cumsum(counts, 0) - counts
+        sorted_k = self.empty_kmers(nq)
+        order = torch.empty(nq, device=self.dev, dtype=torch.int32)
+        cursor = torch.empty(world, device=self.dev, dtype=torch.int64)
+        self.ix.route_scatter_device(kmers.data_ptr(), dest.data_ptr(), nq, offsets.data_ptr(), world, sorted_k.data_ptr(),
+                                     order.data_ptr(), cursor.data_ptr(), self._stream())
+        return sorted_k, order, counts
+
+    def query(self, kmers):
+        n = kmers.shape[0]
+        ids = self.empty_ids(n)
+        self.ix.query_kmers_device(kmers.data_ptr(), n, ids.data_ptr(), self._stream())
+        return ids
+
+    def unpermute(self, vals, order):
+        out = self.empty_ids(vals.shape[0])
+        self.ix.unpermute_device(vals.data_ptr(), order.data_ptr(), vals.shape[0], out.data_ptr(), self._stream())
+        return out
+
+
+class ShardedQuerier:
+    """query(kmers) -> IDs in the caller's order, with every k-mer answered by the rank that owns its MPHF group."""
+
+    def __init__(self, ops, bounds, group=None):
+        self.ops = ops
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        assert len(bounds) == self.world + 1
+        self.bounds = bounds  # tensor on the ops' device, uint32 stored as int32 bit pattern
+        # Rehearsal switch for boxes with ONE GPU shared by several ranks (RCCL refuses duplicate devices): run the
+        # collectives through host memory on the gloo backend.  Never set in production / by bench.py's driver path.
+        self.host_staging = os.environ.get("BLIGHT_DIST_HOST_STAGING") == "1"
+
+    def _a2a(self, out, inp, out_split=None, in_split=None):
+        if self.host_staging and out.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+
+    def query(self, kmers):
+        world = self.world
+        sorted_k, order, counts = self.ops.route(kmers, self.bounds, world)
+        # counts exchange: how many k-mers every peer sends me
+        recv_counts = torch.empty_like(counts)
+        self._a2a(recv_counts, counts)
+        send_split = [int(x) for x in counts.tolist()]
+        recv_split = [int(x) for x in recv_counts.tolist()]
+        # k-mers out (all-to-all-v; order-preserving per pair, so no index travels)
+        recv_k = self.ops.empty_kmers(sum(recv_split))
+        self._a2a(recv_k, sorted_k, recv_split, send_split)
+        # the owner answers
+        ids_remote = self.ops.query(recv_k)
+        # IDs back
+        ids_sorted = self.ops.empty_ids(sum(send_split))
+        self._a2a(ids_sorted, ids_remote, send_split, recv_split)
+        return self.ops.unpermute(ids_sorted, order)

@@ -60,6 +60,8 @@ public:
 	               uint bits_to_save, int device = 0)
 	    : _k((ksize_t)k), _minimizer_length(minimizer_length), _core_number((ksize_t)cores_number), bit_saved_sub((bitsize_t)bits_to_save)
 	{
+		if (blmx_abi_version() != BLMX_ABI_VERSION)
+			throw std::runtime_error("libblight_mi355x.so was built from a different blight_mi355x.h (ABI version mismatch): rebuild the caller");
 		blmx_params p;
 		p.k = k;
 		p.m = minimizer_length;

@@ -21,6 +21,10 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
+ * so a stale caller binary is detected instead of corrupting memory. */
+#define BLMX_ABI_VERSION 3
+
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
 #define BLMX_ESHORT (-2)  /* a sequence is shorter than k: UB/abort in the reference (blight.cpp:235, kmer.h:705)  */
@@ -65,6 +69,10 @@ typedef struct blmx_stats_t {
 	uint32_t k, m, log2_mphf, bits_saved, kmer_bytes;
 	uint32_t max_levels_used;
 	double build_seconds;          /* wall time of the last build (device work + host orchestration) */
+	/* sharding (blmx_set_shard): this index holds the MPHF groups [shard_group_lo, shard_group_hi) only; number_kmer stays
+	 * the GLOBAL count (IDs are global), local_number_kmer is what this shard holds */
+	uint64_t local_number_kmer;
+	uint32_t shard_rank, shard_world, shard_group_lo, shard_group_hi;
 } blmx_stats_t;
 
 /* ctor / dtor.  On failure *out is NULL and blmx_create_error() returns the reference's exception text
@@ -120,6 +128,20 @@ int blmx_kmers_at_device(blmx_index* ix, const void* d_ascii, const uint64_t* d_
                          int* d_err_flag, void* stream);
 int blmx_canonicalize_device(blmx_index* ix, void* d_kmers, uint64_t nq, void* stream);
 
+/* ---- multi-GPU sharding: ownership unit = MPHF group (a contiguous range of minimizer buckets, reference
+ * blight.cpp:692).  blmx_set_shard (before the build) makes this index keep only the groups of rank `rank` of `world`;
+ * every rank is given the SAME input, chops it, and derives the same key-balanced group boundaries, so no build-time
+ * exchange is needed and IDs stay global.  blmx_shard_bounds returns the world+1 group boundaries.
+ * Routing helpers (device pointers): count -> destination rank of every k-mer + per-destination counts; scatter -> k-mers
+ * grouped by destination (+ the permutation); unpermute -> out[order[i]] = vals[i]. */
+int blmx_set_shard(blmx_index* ix, uint32_t rank, uint32_t world);
+int blmx_shard_bounds(const blmx_index* ix, uint32_t* bounds_out);
+int blmx_route_count_device(blmx_index* ix, const void* d_canon_kmers, uint64_t nq, const uint32_t* d_bounds, uint32_t world,
+                            uint8_t* d_dest_out, uint64_t* d_counts_out, void* stream);
+int blmx_route_scatter_device(blmx_index* ix, const void* d_canon_kmers, const uint8_t* d_dest, uint64_t nq, const uint64_t* d_offsets,
+                              uint32_t world, void* d_sorted_kmers_out, uint32_t* d_order_out, uint64_t* d_cursor_scratch, void* stream);
+int blmx_unpermute_device(blmx_index* ix, const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, void* stream);
+
 int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
 
 /* Copy index arrays back to the host for array-level parity checks (tests only; not needed by callers).
@@ -137,6 +159,7 @@ int64_t blmx_export(blmx_index* ix, int which, void* out, uint64_t cap);
 int blmx_primitive(int op, int kmer_bytes, const void* in, uint64_t n, int arg, int arg2, void* out);
 
 const char* blmx_version(void);
+int blmx_abi_version(void);
 
 #ifdef __cplusplus
 }

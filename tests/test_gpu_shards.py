@@ -1,0 +1,68 @@
+"""Sharding on ONE GPU ("virtual shards"): S shard indexes built with blmx_set_shard + the HIP routing
+kernels must reproduce the unsharded index's IDs exactly; shard boundaries follow the key-balance rule on every rank."""
+import numpy as np
+import pytest
+
+import golden_util as G
+from test_dist_gloo import shard_bounds_from_counts
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_seq(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+
+@pytest.mark.parametrize("world,k,m,n,b", [(2, 31, 9, 7, 6), (3, 31, 7, 5, 4), (8, 31, 9, 14, 6), (4, 63, 9, 7, 8)])
+def test_virtual_shards(world, k, m, n, b):
+    import torch
+    import blight_amd as B
+    from oracle import oracle as O
+    rng = np.random.default_rng(world * 7 + k)
+    seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 80))) for _ in range(3000)]
+    full = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+    full.construct_index_from_sequences(seqs)
+    N = full.number_kmer
+    shards = []
+    for r in range(world):
+        ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+        ix.set_shard(r, world)
+        ix.construct_index_from_sequences(seqs)
+        shards.append(ix)
+    bounds = shards[0].shard_bounds()
+    assert np.array_equal(bounds, shard_bounds_from_counts(full.export("g_nkeys"), world))
+    for ix in shards:
+        assert np.array_equal(ix.shard_bounds(), bounds)
+        assert ix.number_kmer == N
+    assert sum(ix.stats()["local_number_kmer"] for ix in shards) == N
+    # queries: all indexed k-mers (via the oracle's rolling encoder) + random negatives
+    kb = full.kmer_bytes
+    orc = O.Oracle(k, m, n, b, seqs[:400], kmer_bytes=kb)
+    pos = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs[:400]])
+    neg = rng.integers(0, 1 << 62, size=(5000, kb // 8), dtype=np.uint64)
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(np.concatenate([pos, neg]).view(np.int64)).to(dev)
+    nq = q.shape[0]
+    full.canonicalize_device(q.data_ptr(), nq, torch.cuda.current_stream().cuda_stream)
+    want = torch.empty(nq, device=dev, dtype=torch.int64)
+    full.query_kmers_device(q.data_ptr(), nq, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    # route on shard 0's handle, answer segment r on shard r, un-permute
+    from blight_amd.dist import DeviceOps
+    ops = [DeviceOps(ix, dev) for ix in shards]
+    bt = torch.from_numpy(bounds.astype(np.int32)).to(dev)
+    sorted_k, order, counts = ops[0].route(q, bt, world)
+    split = [int(x) for x in counts.tolist()]
+    assert sum(split) == nq
+    parts, o = [], 0
+    for r in range(world):
+        parts.append(ops[r].query(sorted_k[o:o + split[r]].contiguous()))
+        o += split[r]
+    got = ops[0].unpermute(torch.cat(parts), order)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert int((want >= 0).sum().item()) >= pos.shape[0]
+    # a shard answers nothing outside its groups
+    alone = ops[0].query(q)
+    torch.cuda.synchronize()
+    own = alone >= 0
+    assert torch.equal(alone[own], want[own]) and int(own.sum().item()) < int((want >= 0).sum().item())
