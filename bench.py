@@ -28,10 +28,11 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {31: 145, 63: 209}  # algorithmic bytes per query, SURVEY.md section 8(d): B(k=31,b=6)=145, B(k=63,b=8)=209
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# HBM bytes per k_query launch from rocprofv3 PMC passes of this same command (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; FETCH_SIZE
-# calibrated = 1.000 on random 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern):
-# profiles/r01_pmc_k_query_c4.txt.  Only quoted for the workload it was measured on.
-TRAFFIC_BYTES = {"C4": (3.70468e7 + 781250) * 1024}
+# HBM bytes per step (all kernels of the query pipeline: k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids) from
+# rocprofv3 PMC passes of this same command (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; FETCH_SIZE calibrated = 1.000 on random
+# 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern): profiles/r01_pmc_pipeline_c4.txt.
+# Only quoted for the workload it was measured on.
+TRAFFIC_BYTES = {"C4": (20.995e6 + 5.540e6) * 1024}
 
 WORKLOADS = {
     # name: (k, m, log2_mphf, b, indexed k-mers, queries per step per GPU)
@@ -297,7 +298,7 @@ def main():
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
                        "build_kmers_per_sec": st["number_kmer"] / t_build},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES.get(args.workload) if world == 1 else None, "kernel": "k_query",
+                         "traffic": TRAFFIC_BYTES.get(args.workload) if world == 1 else None, "kernel": "query pipeline: k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids (k_query = 2/3 of it)",
                          "kernel_ms": kern_ms if world == 1 else None, "algorithmic_bytes_per_query": algo},
             "checks": {"indexed_queries_found": n_pos_found, "indexed_queries": n_pos, "random_queries_found": n_neg_found,
                        "ok": bool(ok)},

@@ -80,6 +80,7 @@ def load_library():
     lib.blmx_route_scatter_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p]
     lib.blmx_unpermute_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.blmx_set_query_binning.argtypes = [C.c_void_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     lib.blmx_export.restype = C.c_int64
@@ -306,6 +307,10 @@ class kmer_Set_Light:
 
     def canonicalize_device(self, d_kmers_ptr, nq, stream=None):
         self._check(self._lib.blmx_canonicalize_device(self._h, d_kmers_ptr, nq, stream))
+
+    def set_query_binning(self, policy):
+        """0 automatic, 1 always partition large batches by minimizer prefix before querying, -1 never"""
+        self._check(self._lib.blmx_set_query_binning(self._h, policy))
 
     # -- multi-GPU sharding (SURVEY 8e)
     def set_shard(self, rank, world):

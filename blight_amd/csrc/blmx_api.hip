@@ -135,7 +135,10 @@ void query_host(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_
 		BLMX_HIP(hipMemcpyAsync(ix.q_aux.p, minis, nq * 4, hipMemcpyHostToDevice, ix.stream));
 		d_minis = ix.q_aux.as<uint32_t>();
 	}
-	launch_query(ix, ix.q_in.p, d_minis, nq, ix.q_out.p, mode, ix.stream);
+	if (mode == kQueryIds && !d_minis)
+		launch_query_ids_auto(ix, ix.q_in.p, nq, ix.q_out.as<int64_t>(), ix.stream);
+	else
+		launch_query(ix, ix.q_in.p, d_minis, nq, ix.q_out.p, mode, ix.stream);
 	BLMX_HIP(hipMemcpyAsync(out, ix.q_out.p, nq * ob, hipMemcpyDeviceToHost, ix.stream));
 	BLMX_HIP(hipStreamSynchronize(ix.stream));
 	ix.st.number_query += nq;  // blight.cpp:717-718
@@ -356,7 +359,7 @@ int blmx_query_kmers_device(blmx_index* h, const void* d_kmers, uint64_t nq, int
 		if (!h->ix.built)
 			throw StatusError{BLMX_ESTATE, "index not built"};
 		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
-		launch_query(h->ix, d_kmers, nullptr, nq, d_ids, kQueryIds, s);
+		launch_query_ids_auto(h->ix, d_kmers, nq, d_ids, s);
 		if (!stream)
 			BLMX_HIP(hipStreamSynchronize(s));
 		h->ix.st.number_query += nq;
@@ -457,6 +460,14 @@ int blmx_unpermute_device(blmx_index* h, const int64_t* d_vals, const uint32_t* 
 		if (!stream)
 			BLMX_HIP(hipStreamSynchronize(s));
 	});
+}
+
+int blmx_set_query_binning(blmx_index* h, int policy)
+{
+	if (!h)
+		return BLMX_EINVAL;
+	h->ix.bin_policy = policy < 0 ? -1 : (policy > 0 ? 1 : 0);
+	return BLMX_OK;
 }
 
 int blmx_stats(const blmx_index* h, blmx_stats_t* out)

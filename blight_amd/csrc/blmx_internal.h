@@ -118,6 +118,10 @@ struct Index {
 
 	// staging for host-buffer queries
 	DevBuf q_in, q_aux, q_out;
+	// scratch of the locality-binned batch query (grow-only; guarded by bin_mu)
+	DevBuf b_bins, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp;
+	std::mutex bin_mu;
+	int bin_policy = 0;  // 0 = automatic, 1 = always bin, -1 = never (BLIGHT_QUERY_BINNING env / blmx_set_query_binning)
 
 	DeviceIndexView view() const
 	{
@@ -149,6 +153,9 @@ void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs
 enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2 };
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
                   hipStream_t s);
+// Large batches: partition the queries by the top bits of their minimizer first (one counting pass), run the query
+// kernel on the partitioned batch, gather the IDs back into the caller's order.
+void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s);
 void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s);
 // rolling canonical k-mers of ASCII sequences -> canonical k-mer array (KW words each); returns via d_err (BLMX_EDNA)
 void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, const uint64_t* d_kmer_offs,

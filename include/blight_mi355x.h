@@ -142,6 +142,12 @@ int blmx_route_scatter_device(blmx_index* ix, const void* d_canon_kmers, const u
                               uint32_t world, void* d_sorted_kmers_out, uint32_t* d_order_out, uint64_t* d_cursor_scratch, void* stream);
 int blmx_unpermute_device(blmx_index* ix, const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, void* stream);
 
+/* Batch-query strategy of blmx_query_kmers / blmx_query_kmers_device: 0 = automatic (large batches on large indexes are first
+ * partitioned by the top bits of their minimizer so that concurrently running blocks share a slice of the index in
+ * L2 / Infinity Cache; results are identical and in the caller's order), 1 = always partition, -1 = never.
+ * Environment override when 0: BLIGHT_QUERY_BINNING=1|-1. */
+int blmx_set_query_binning(blmx_index* ix, int policy);
+
 int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
 
 /* Copy index arrays back to the host for array-level parity checks (tests only; not needed by callers).

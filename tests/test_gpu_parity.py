@@ -207,3 +207,29 @@ def test_build_is_deterministic(B):
     b = _build(B, 31, 9, 7, 6, seqs)
     for key in ("seq", "positions", "mphf_bits", "fb_keys", "fb_ranks", "bucket_start"):
         assert np.array_equal(a.export(key), b.export(key)), key
+
+
+@pytest.mark.parametrize("k,m,n,b,kb", [(31, 9, 7, 6, 8), (63, 9, 7, 8, 16), (21, 3, 2, 3, 8), (31, 7, 13, 0, 8)])
+def test_binned_batch_query_equals_direct(B, O, k, m, n, b, kb):
+    """The locality-binned batch path (partition by minimizer prefix -> query -> gather back) returns exactly the direct
+    kernel's IDs, in the caller's order, and both equal the oracle."""
+    rng = np.random.default_rng(k + m)
+    seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 60))) for _ in range(2500)]
+    seqs += [_rand_seq(rng, k + 30, "AC") for _ in range(30)]
+    ix = _build(B, k, m, n, b, seqs, kmer_bytes=kb)
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    pos = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
+    neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(30000)]
+    neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
+    q = np.concatenate([pos, neg])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    ix.set_query_binning(-1)
+    direct = ix.query_kmer_hash(q.reshape(-1))
+    ix.set_query_binning(1)
+    binned = ix.query_kmer_hash(q.reshape(-1))
+    assert np.array_equal(direct, binned)
+    assert np.array_equal(direct, orc.query_kmers(q.reshape(-1) if kb == 8 else q))
+    assert int((direct >= 0).sum()) >= len(pos)
+    # tiny and empty batches through the binned path
+    assert np.array_equal(ix.query_kmer_hash(q[:3].reshape(-1)), direct[:3])
+    assert ix.query_kmer_hash(np.zeros(0, np.uint64)).size == 0

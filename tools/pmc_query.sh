@@ -13,7 +13,7 @@ i=0
 while read -r counters; do
 	[ -z "$counters" ] && continue
 	i=$((i + 1))
-	timeout -k 10 240 rocprofv3 --pmc $counters --kernel-include-regex "k_query" --output-format csv -d "$OUT/p$i" -- \
+	timeout -k 10 240 rocprofv3 --pmc $counters --kernel-include-regex "k_query|k_bin_hist|k_bin_scatter|k_gather_ids|rocprim" --output-format csv -d "$OUT/p$i" -- \
 		python3 "$R/bench.py" $ARGS >"$OUT/p$i.json" 2>"$OUT/p$i.log" || echo "pass $i failed" >>"$OUT/summary.txt"
 done <<'LIST'
 FETCH_SIZE
@@ -31,9 +31,9 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Counter_Name"] + " " + r["Kernel_Name"].split("(")[0][-40:]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "a") as fh:
     for k, v in acc.items():
-        fh.write("%-40s launches=%d mean=%.6g min=%.6g max=%.6g\n" % (k, len(v), sum(v) / len(v), min(v), max(v)))
+        fh.write("%-90s launches=%d mean=%.6g min=%.6g max=%.6g\n" % (k, len(v), sum(v) / len(v), min(v), max(v)))
 print(open(out + "/summary.txt").read())
 PY
