@@ -67,7 +67,7 @@ def synth_unitigs(torch, dev, n_kmers, k, seed):
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     n_unitigs = max(1, n_kmers // 80)
-    extra = torch.empty(n_unitigs, device=dev, dtype=torch.float32).geometric_(1.0 / 80.0, generator=g).to(torch.int64)
+    extra = torch.empty(n_unitigs, device=dev, dtype=torch.float32).geometric_(1.0 / 80.0, generator=g).to(torch.int64).clamp_(min=1)
     # trim so that the k-mer total is exactly n_kmers
     csum = torch.cumsum(extra, 0)
     keep = int(torch.searchsorted(csum, torch.tensor([n_kmers], device=dev, dtype=torch.int64)).item()) + 1
@@ -112,7 +112,10 @@ def synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, seed, kmer_words):
     q[:npos] = pos_k
     q[npos:] = neg
     perm = torch.randperm(nq, device=dev, generator=g)
-    q = q[perm].contiguous()
+    # shuffle word column by word column on contiguous 1-D tensors (a 2-D row gather of a (1e8, 2) int64 tensor returned
+    # wrong rows on this torch/ROCm build; the 1-D gather is the well-trodden path)
+    cols = [q[:, w].contiguous()[perm] for w in range(kmer_words)]
+    q = torch.stack(cols, dim=1).contiguous()
     is_pos = (perm < npos)
     return q, is_pos
 

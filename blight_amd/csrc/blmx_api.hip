@@ -224,6 +224,9 @@ void blmx_destroy(blmx_index* h)
 	if (!h)
 		return;
 	(void)hipSetDevice(h->ix.prm.device);
+	(void)hipDeviceSynchronize();  // device-pointer calls may still be running on the caller's streams
+	if (h->ix.bin_done)
+		(void)hipEventDestroy(h->ix.bin_done);
 	if (h->ix.stream) {
 		(void)hipStreamSynchronize(h->ix.stream);
 		(void)hipStreamDestroy(h->ix.stream);
@@ -258,6 +261,7 @@ int blmx_build_from_device_sequences(blmx_index* h, const void* d_concat, const 
 		if (h->ix.built)
 			throw StatusError{BLMX_ESTATE, "index already built"};
 		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		BLMX_HIP(hipDeviceSynchronize());  // the build runs on the library's own stream: wait for whoever produced the input
 		build_from_device(h->ix, reinterpret_cast<const uint8_t*>(d_concat), d_offsets, nseq, total_len);
 		h->ix.built = true;
 	});
@@ -358,10 +362,8 @@ int blmx_query_kmers_device(blmx_index* h, const void* d_kmers, uint64_t nq, int
 	return guarded(h, [&] {
 		if (!h->ix.built)
 			throw StatusError{BLMX_ESTATE, "index not built"};
-		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_query_ids_auto(h->ix, d_kmers, nq, d_ids, s);
-		if (!stream)
-			BLMX_HIP(hipStreamSynchronize(s));
 		h->ix.st.number_query += nq;
 	});
 }
@@ -371,10 +373,8 @@ int blmx_kmer_groups_device(blmx_index* h, const void* d_kmers, uint64_t nq, uin
 	if (!h || (nq && (!d_kmers || !d_groups)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
-		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_kmer_groups(h->ix, d_kmers, nq, d_groups, s);
-		if (!stream)
-			BLMX_HIP(hipStreamSynchronize(s));
 	});
 }
 
@@ -383,10 +383,8 @@ int blmx_kmers_at_device(blmx_index* h, const void* d_ascii, const uint64_t* d_p
 	if (!h || (nq && (!d_ascii || !d_positions || !d_out)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
-		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_kmers_at(h->ix, reinterpret_cast<const uint8_t*>(d_ascii), d_positions, nq, d_out, d_err, s);
-		if (!stream)
-			BLMX_HIP(hipStreamSynchronize(s));
 	});
 }
 
@@ -395,10 +393,8 @@ int blmx_canonicalize_device(blmx_index* h, void* d_kmers, uint64_t nq, void* st
 	if (!h || (nq && !d_kmers))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
-		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_canonicalize(h->ix, d_kmers, nq, s);
-		if (!stream)
-			BLMX_HIP(hipStreamSynchronize(s));
 	});
 }
 
@@ -430,10 +426,8 @@ int blmx_route_count_device(blmx_index* h, const void* d_kmers, uint64_t nq, con
 	if (!h || !d_bounds || !d_counts || world == 0 || world > 255 || (nq && (!d_kmers || !d_dest)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
-		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_route_count(h->ix, d_kmers, nq, d_bounds, world, d_dest, d_counts, s);
-		if (!stream)
-			BLMX_HIP(hipStreamSynchronize(s));
 	});
 }
 
@@ -443,10 +437,8 @@ int blmx_route_scatter_device(blmx_index* h, const void* d_kmers, const uint8_t*
 	if (!h || !d_offsets || !d_cursor || world == 0 || world > 255 || nq >= 0xffffffffull || (nq && (!d_kmers || !d_dest || !d_sorted || !d_order)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
-		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_route_scatter(h->ix, d_kmers, d_dest, nq, d_offsets, world, d_sorted, d_order, d_cursor, s);
-		if (!stream)
-			BLMX_HIP(hipStreamSynchronize(s));
 	});
 }
 
@@ -455,10 +447,8 @@ int blmx_unpermute_device(blmx_index* h, const int64_t* d_vals, const uint32_t* 
 	if (!h || (nq && (!d_vals || !d_order || !d_out)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
-		hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : h->ix.stream;
+		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_unpermute(d_vals, d_order, nq, d_out, s);
-		if (!stream)
-			BLMX_HIP(hipStreamSynchronize(s));
 	});
 }
 

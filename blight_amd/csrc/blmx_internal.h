@@ -121,6 +121,9 @@ struct Index {
 	// scratch of the locality-binned batch query (grow-only; guarded by bin_mu)
 	DevBuf b_bins, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp;
 	std::mutex bin_mu;
+	hipEvent_t bin_done = nullptr;       // recorded after each binned pipeline: a call on another stream waits for it
+	hipStream_t bin_last_stream = nullptr;
+	bool bin_used = false;
 	int bin_policy = 0;  // 0 = automatic, 1 = always bin, -1 = never (BLIGHT_QUERY_BINNING env / blmx_set_query_binning)
 
 	DeviceIndexView view() const

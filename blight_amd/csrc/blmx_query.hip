@@ -557,6 +557,12 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 		return;
 	}
 	std::lock_guard<std::mutex> lock(ix.bin_mu);
+	// the scratch buffers are shared by all calls on this index: order this pipeline after the previous one when it was
+	// enqueued on a different stream
+	if (!ix.bin_done)
+		BLMX_HIP(hipEventCreateWithFlags(&ix.bin_done, hipEventDisableTiming));
+	if (ix.bin_used && ix.bin_last_stream != s)
+		BLMX_HIP(hipStreamWaitEvent(s, ix.bin_done, 0));
 	const int tbits = mbits < kBinBitsMax ? mbits : kBinBitsMax;
 	const uint32_t nbins = 1u << tbits;
 	const int bin_shift = mbits - tbits;
@@ -590,6 +596,9 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 	launch_query(ix, ix.b_sorted.p, nullptr, nq, ix.b_ids.p, kQueryIds, s);
 	hipLaunchKernelGGL(k_gather_ids, dim3(grid_for(nq, 256)), dim3(256), 0, s, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out);
 	BLMX_HIP(hipGetLastError());
+	BLMX_HIP(hipEventRecord(ix.bin_done, s));
+	ix.bin_last_stream = s;
+	ix.bin_used = true;
 }
 
 void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s)

@@ -88,7 +88,7 @@ int blmx_build_from_fasta(blmx_index* ix, const char* path);
 /* Same, from memory: nseq sequences concatenated in `concat`, sequence i = concat[offsets[i] .. offsets[i+1]). */
 int blmx_build_from_sequences(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq);
 /* Same, input already resident in HBM (device pointers: ASCII bytes and nseq+1 offsets).  Used for large synthetic
- * inputs generated on the device. */
+ * inputs generated on the device.  Synchronous; the device is synchronised first, so inputs produced on any stream are seen. */
 int blmx_build_from_device_sequences(blmx_index* ix, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq,
                                      uint64_t total_len);
 
@@ -112,8 +112,10 @@ int blmx_query_sequences(blmx_index* ix, const char* concat, const uint64_t* off
 /* number of IDs blmx_query_sequences writes for these offsets */
 uint64_t blmx_sequence_kmer_count(const blmx_index* ix, const uint64_t* offsets, uint64_t nseq);
 
-/* Device-resident batch query: d_canon_kmers / d_ids_out are DEVICE pointers, `stream` a hipStream_t (NULL = the
- * index's own stream).  Asynchronous with respect to the host when a stream is given. */
+/* Device-resident entry points (all *_device functions): pointers are DEVICE pointers and `stream` is the hipStream_t the
+ * work is enqueued on -- NULL is HIP's null stream, treated like any other stream.  The calls are asynchronous: they
+ * return after enqueueing and are ordered with the caller's other work on that stream; the caller synchronises.
+ * Calls on one index from several streams are serialised internally where they share scratch memory. */
 int blmx_query_kmers_device(blmx_index* ix, const void* d_canon_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
 /* Minimizer -> owning MPHF group for a batch of canonical k-mers on the device (group = minimizer >> (2m-1-n),
  * reference blight.cpp:692); used by the multi-GPU router to pick the destination rank. */
