@@ -627,12 +627,12 @@ __global__ void k_fill_positions(DeviceIndexView v, const uint32_t* __restrict__
 	const GroupDesc* gd = &v.groups[mi >> v.gshift];
 	const uint64_t pos0 = nt_start[j] - v.buckets[mi].start;
 	const uint64_t ks = key_start[j], ke = key_start[j + 1];
-	const uint64_t posstart = gd->posstart;
-	const uint32_t nbits = gd->nbits;
-	DeviceIndexView nofb = v;  // level bits only
+	const GroupHead gh = load_group_head(gd);
+	const uint64_t posstart = gh.posstart;
+	const uint32_t nbits = gh.nbits;
 	for (uint64_t t = 0; t < ke - ks; t++) {
 		const Kmer<KW> x = load_kmer<KW>(keys, ks + t);
-		const uint64_t h = mphf_lookup_levels<KW>(nofb, gd, x);
+		const uint64_t h = mphf_lookup_levels<KW>(v, gd, gh, x);
 		if (h != kNotFound)
 			write_position(positions, posstart, nbits, h, (pos0 + t) >> v.b);
 	}
@@ -969,6 +969,8 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 				off += gd.size[l];
 			}
 			gd.nwords = total_bits / 64;
+			if (gd.nwords >= (1ull << 31))  // the query kernel indexes a group's level array with 32-bit word numbers
+				throw StatusError{BLMX_ELIMIT, "an MPHF group holds more than 2^37 level bits"};
 			wbase += gd.nwords;
 			lbase += (2 * gd.nwords + kLineData32 - 1) / kLineData32;
 		} else {

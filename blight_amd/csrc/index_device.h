@@ -20,28 +20,96 @@ template <> __device__ __forceinline__ Kmer<2> load_kmer<2>(const uint64_t* __re
 	return x;
 }
 
-// level_finder_tmp + bitVector::rank (bbhash.h:617-663, 467-480): probe levels until a set bit is found and rank it.
-// One probe = ONE 16-B load: a line holds [u32 rank | 96 level bits], so the rank costs no second memory access.
+// One BBHash probe = ONE 16-B load: a line holds [u32 rank | 96 level bits], so the rank costs no second memory access.
 // Logical bit b of the group's level array lives in line (b>>5)/3, data word (b>>5)%3, bit b&31.
+// Returns true and sets `rank` when the bit is set (level_finder_tmp + bitVector::rank, bbhash.h:617-663, 467-480).
+__device__ __forceinline__ bool mphf_probe(const uint4* __restrict__ lines, uint64_t bit, uint64_t& rank)
+{
+	const uint32_t w32 = (uint32_t)(bit >> 5);  // a group's level array is < 2^37 bits (checked at build time)
+	const uint32_t line = w32 / kLineData32;
+	const uint32_t slot = w32 - line * kLineData32;
+	const uint4 L = lines[line];
+	// select without control flow so that the load stays one dwordx4
+	const uint32_t word = (slot == 0 ? L.y : 0u) | (slot == 1 ? L.z : 0u) | (slot == 2 ? L.w : 0u);
+	const uint32_t bi = (uint32_t)bit & 31u;
+	const uint32_t before = (slot > 0 ? __popc(L.y) : 0) + (slot > 1 ? __popc(L.z) : 0);
+	rank = (uint64_t)(L.x + before + __popc(word & ((1u << bi) - 1u)));
+	return (word >> bi) & 1u;
+}
+
+// The first 64-B sector of a GroupDesc, fetched with four back-to-back 16-B loads and ONE wait: everything a query
+// needs besides the level sizes 3..15 (which only 6 % of present and a third of absent k-mers reach).
+struct GroupHead {
+	uint64_t prefix, posstart, line_base, fb_start;
+	uint32_t nbits, fb_count;
+	uint64_t size0, size1, size2;
+};
+__device__ __forceinline__ GroupHead unpack_group_head(const uint4 a, const uint4 b, const uint4 c, const uint4 d)
+{
+	GroupHead h;
+	h.prefix = (uint64_t)a.x | ((uint64_t)a.y << 32);
+	h.posstart = (uint64_t)a.z | ((uint64_t)a.w << 32);
+	h.line_base = (uint64_t)b.x | ((uint64_t)b.y << 32);
+	h.nbits = b.z;
+	h.fb_count = b.w;
+	h.fb_start = (uint64_t)c.x | ((uint64_t)c.y << 32);
+	h.size0 = (uint64_t)c.z | ((uint64_t)c.w << 32);
+	h.size1 = (uint64_t)d.x | ((uint64_t)d.y << 32);
+	h.size2 = (uint64_t)d.z | ((uint64_t)d.w << 32);
+	return h;
+}
+__device__ __forceinline__ GroupHead load_group_head(const GroupDesc* __restrict__ gd)
+{
+	const uint4* p = reinterpret_cast<const uint4*>(gd);
+	return unpack_group_head(p[0], p[1], p[2], p[3]);
+}
+
+// Bucket descriptor (16 B) + group head (64 B) in ONE memory round trip: both addresses depend only on the minimizer.
+// hipcc splits and sinks plain loads behind the empty-bucket test (turning one round trip into three dependent ones),
+// so the five 16-B loads are issued from one asm statement and drained by its own s_waitcnt (the statement counts and
+// waits for its own loads; no compiler-tracked load is outstanding across it that the kernel relies on).
+__device__ __forceinline__ GroupHead load_bucket_and_head(const BucketDesc* __restrict__ bp, const GroupDesc* __restrict__ gp, uint64_t& bstart,
+                                                          uint32_t& bnt)
+{
+	uint4 bd, a, b, c, d;
+	asm volatile(
+	    "global_load_dwordx4 %0, %5, off\n\t"
+	    "global_load_dwordx4 %1, %6, off\n\t"
+	    "global_load_dwordx4 %2, %6, off offset:16\n\t"
+	    "global_load_dwordx4 %3, %6, off offset:32\n\t"
+	    "global_load_dwordx4 %4, %6, off offset:48\n\t"
+	    "s_waitcnt vmcnt(0)"
+	    : "=&v"(bd), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+	    : "v"(bp), "v"(gp)
+	    : "memory");
+	bstart = (uint64_t)bd.x | ((uint64_t)bd.y << 32);
+	bnt = bd.z;
+	return unpack_group_head(a, b, c, d);
+}
+
+// mphf::lookup restricted to the level bit arrays (bbhash.h:561-566): probe levels until a set bit is found and rank it.
+// Levels 0..2 use the sizes that came with the group head; deeper levels read their size on demand.
 template <int KW>
-__device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, Kmer<KW> x)
+__device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh,
+                                                        Kmer<KW> x)
 {
 	LevelHasher hs(x.lo);
-	const uint4* __restrict__ lines = reinterpret_cast<const uint4*>(v.lines) + gd->line_base;
+	const uint4* __restrict__ lines = reinterpret_cast<const uint4*>(v.lines) + gh.line_base;
+	uint64_t rank;
 	uint64_t off = 0;
-	for (int lv = 0; lv < kLevels; lv++) {
+	if (mphf_probe(lines, reduce_level(hs.next(0), gh.size0), rank))
+		return rank;
+	off = gh.size0;
+	if (mphf_probe(lines, off + reduce_level(hs.next(1), gh.size1), rank))
+		return rank;
+	off += gh.size1;
+	if (mphf_probe(lines, off + reduce_level(hs.next(2), gh.size2), rank))
+		return rank;
+	off += gh.size2;
+	for (int lv = 3; lv < kLevels; lv++) {
 		const uint64_t size = gd->size[lv];
-		const uint64_t bit = off + reduce_level(hs.next(lv), size);
-		const uint64_t w32 = bit >> 5;
-		const uint64_t line = w32 / kLineData32;
-		const uint32_t slot = (uint32_t)(w32 - line * kLineData32);
-		const uint4 L = lines[line];
-		const uint32_t word = slot == 0 ? L.y : (slot == 1 ? L.z : L.w);
-		const uint32_t bi = (uint32_t)bit & 31u;
-		if ((word >> bi) & 1u) {
-			const uint32_t before = (slot > 0 ? __popc(L.y) : 0) + (slot > 1 ? __popc(L.z) : 0);
-			return (uint64_t)(L.x + before + __popc(word & ((1u << bi) - 1u)));
-		}
+		if (mphf_probe(lines, off + reduce_level(hs.next(lv), size), rank))
+			return rank;
 		off += size;
 	}
 	return kNotFound;
@@ -49,14 +117,14 @@ __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v,
 
 // mphf::lookup (bbhash.h:561-577): levels first, then the group's fallback table.
 template <int KW>
-__device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, Kmer<KW> x)
+__device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x)
 {
-	const uint64_t r = mphf_lookup_levels<KW>(v, gd, x);
-	if (r != kNotFound || gd->fb_count == 0)
+	const uint64_t r = mphf_lookup_levels<KW>(v, gd, gh, x);
+	if (r != kNotFound || gh.fb_count == 0)
 		return r;
 	// _final_hash.find(elem), bbhash.h:567-575.  The table is sorted by (group, key, input order) and keeps every
 	// occurrence of a duplicated key; the map's "last assignment wins" (bbhash.h:724) = the LAST entry of an equal run.
-	uint64_t lo = gd->fb_start, hi = lo + gd->fb_count;
+	uint64_t lo = gh.fb_start, hi = lo + gh.fb_count;
 	const uint64_t begin = lo;
 	while (lo < hi) {  // upper bound
 		const uint64_t mid = (lo + hi) >> 1;
