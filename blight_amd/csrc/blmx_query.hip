@@ -519,7 +519,7 @@ void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis,
 // work on the same ~1/1024 slice of the index, which L2 / Infinity Cache then serve: measured 13.4 -> 7.2 ms per 1e8
 // queries on the human-scale index.  One LSD counting pass (per-block LDS histograms, bin-major scan, scatter); the
 // IDs are gathered back through the inverse permutation, whose 1024 streams are each (nearly) sequential.
-constexpr int kBinThreads = 512;
+constexpr int kBinThreads = 1024;  // 16 waves per CU: the scatter holds 92 KB of LDS, so one block per CU
 constexpr int kBinBitsMax = 10;
 // queries per block in the partition passes: the scatter stages a whole tile (k-mers + bin ids) in LDS
 template <int KW> struct BinTile { static constexpr int value = 8192 / KW; };
@@ -564,12 +564,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 	__shared__ uint32_t s_cur[kNB];
 	__shared__ uint32_t s_gstart[kNB];  // first global slot of this tile's run of each bin
 	__shared__ uint32_t s_wsum[kBinThreads / 64];
-	// tile-local exclusive scan of this block's bin counts (2 bins per thread, wave scan, wave totals through LDS)
+	// tile-local exclusive scan of this block's bin counts (one bin per thread: wave scan, wave totals through LDS)
+	static_assert(kBinThreads == (1 << kBinBitsMax), "one bin per thread");
 	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const uint32_t b0 = 2 * t, b1 = 2 * t + 1;
-	const uint32_t c0 = b0 < nbins ? hist[(uint64_t)b0 * nblk + blockIdx.x] : 0u;
-	const uint32_t c1 = b1 < nbins ? hist[(uint64_t)b1 * nblk + blockIdx.x] : 0u;
-	uint32_t v = c0 + c1;
+	const uint32_t c0 = t < nbins ? hist[(uint64_t)t * nblk + blockIdx.x] : 0u;
+	uint32_t v = c0;
 	for (int o = 1; o < 64; o <<= 1) {
 		const uint32_t u = __shfl_up(v, o);
 		if ((int)lane >= o)
@@ -581,16 +580,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 	uint32_t wbase = 0;
 	for (uint32_t w = 0; w < wave; w++)
 		wbase += s_wsum[w];
-	const uint32_t excl = wbase + v - (c0 + c1);
-	if (b0 < nbins) {
-		s_lstart[b0] = excl;
-		s_cur[b0] = excl;
-		s_gstart[b0] = offs[(uint64_t)b0 * nblk + blockIdx.x];
-	}
-	if (b1 < nbins) {
-		s_lstart[b1] = excl + c0;
-		s_cur[b1] = excl + c0;
-		s_gstart[b1] = offs[(uint64_t)b1 * nblk + blockIdx.x];
+	const uint32_t excl = wbase + v - c0;
+	if (t < nbins) {
+		s_lstart[t] = excl;
+		s_cur[t] = excl;
+		s_gstart[t] = offs[(uint64_t)t * nblk + blockIdx.x];
 	}
 	__syncthreads();
 	const uint64_t base = (uint64_t)blockIdx.x * kTile;
@@ -623,12 +617,18 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 	}
 }
 
-__global__ __launch_bounds__(256) void k_gather_ids(const int64_t* __restrict__ ids_sorted, const uint32_t* __restrict__ inv, uint64_t nq,
-                                                    int64_t* __restrict__ out)
+// out[i] = ids_sorted[inv[i]].  One block per partition TILE: the (tile, bin) runs written by k_bin_scatter are consumed by
+// the block that covers the same tile, so each 64-B line of ids_sorted is fetched once by one CU instead of by many.
+template <int TILE>
+__global__ __launch_bounds__(kBinThreads) void k_gather_ids(const int64_t* __restrict__ ids_sorted, const uint32_t* __restrict__ inv, uint64_t nq,
+                                                            int64_t* __restrict__ out)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < nq)
-		out[i] = ids_sorted[inv[i]];
+	const uint64_t base = (uint64_t)blockIdx.x * TILE;
+	for (int it = 0; it < TILE / kBinThreads; it++) {
+		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
+		if (i < nq)
+			out[i] = ids_sorted[inv[i]];
+	}
 }
 
 static void ensure_buf(DevBuf& b, size_t bytes, hipStream_t s)
@@ -698,7 +698,12 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 	// (storing each ID straight into the caller's slot from k_query was measured 2.8 ms SLOWER per 1e8 queries than this
 	// separate gather: 1e8 scattered 8-B stores cost more than reading the IDs back through the inverse permutation)
 	launch_query(ix, ix.b_sorted.p, nullptr, nq, ix.b_ids.p, kQueryIds, s);
-	hipLaunchKernelGGL(k_gather_ids, dim3(grid_for(nq, 256)), dim3(256), 0, s, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_gather_ids<BinTile<1>::value>), dim3(nblk), dim3(kBinThreads), 0, s, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq,
+		                   d_out);
+	else
+		hipLaunchKernelGGL((k_gather_ids<BinTile<2>::value>), dim3(nblk), dim3(kBinThreads), 0, s, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq,
+		                   d_out);
 	BLMX_HIP(hipGetLastError());
 	BLMX_HIP(hipEventRecord(ix.bin_done, s));
 	ix.bin_last_stream = s;
