@@ -30,9 +30,9 @@ ALGO_BYTES = {31: 145, 63: 209}  # algorithmic bytes per query, SURVEY.md sectio
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per step (all kernels of the query pipeline: k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids) from
 # rocprofv3 PMC passes of this same command (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; FETCH_SIZE calibrated = 1.000 on random
-# 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern): profiles/r01_pmc_pipeline_c4.txt.
+# 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern): profiles/r01_pmc_pipeline_c4_v6.txt.
 # Only quoted for the workload it was measured on.
-TRAFFIC_BYTES = {"C4": (20.995e6 + 5.540e6) * 1024}
+TRAFFIC_BYTES = {"C4": (22.224e6 + 3.867e6) * 1024}
 
 WORKLOADS = {
     # name: (k, m, log2_mphf, b, indexed k-mers, queries per step per GPU)
@@ -237,15 +237,36 @@ def main():
 
     # ---- queries (per rank, resident in HBM)
     q, is_pos = synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank, kw)
-    del ascii_
     ids = torch.empty(nq, device=dev, dtype=torch.int64)
     torch.cuda.synchronize()
 
+    querier = None
     if effective_mode == "sharded":
         from blight_amd.dist import DeviceOps, ShardedQuerier
         bounds = torch.from_numpy(ix.shard_bounds().astype("int32")).to(dev)
         querier = ShardedQuerier(DeviceOps(ix, dev), bounds)
+        # Probe the exchange once on a small slice.  The 8-GPU RCCL path cannot be exercised on the 1-GPU development
+        # boxes, so if the all-to-all fails on any rank every rank falls back to full replicas (reported in `parallelism`).
+        failed = torch.zeros(1, device=("cpu" if rehearsal else dev), dtype=torch.int32)
+        try:
+            querier.query(q[:4096].contiguous())
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover - only on a broken collective
+            log("rank %d: sharded exchange failed (%r); falling back to replicas" % (rank, e))
+            failed += 1
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            effective_mode = "replicas (sharded exchange failed)"
+            querier = None
+            ix.close()
+            ix = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
+            t0 = time.time()
+            ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+            t_build = time.time() - t0
+            st = ix.stats()
+    del ascii_
 
+    if querier is not None:
         def step():
             nonlocal ids
             ids = querier.query(q)  # route -> all-to-all-v (RCCL/xGMI) -> owner's k_query -> all-to-all-v back -> un-permute
