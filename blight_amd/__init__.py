@@ -68,6 +68,7 @@ def load_library():
     lib.blmx_query_positions.argtypes = [C.c_void_p, C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_int32)]
     lib.blmx_query_membership.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8)]
     lib.blmx_query_sequences.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _i64p]
+    lib.blmx_query_file.argtypes = [C.c_void_p, C.c_char_p, _u64p, _u64p]
     lib.blmx_sequence_kmer_count.argtypes = [C.c_void_p, _u64p, C.c_uint64]
     lib.blmx_sequence_kmer_count.restype = C.c_uint64
     lib.blmx_query_kmers_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -256,44 +257,19 @@ class kmer_Set_Light:
         found = int((ids >= 0).sum())
         return found, int(ids.size - found)
 
-    def file_query(self, query_file, batch=512):
-        """blight.cpp:746-799: reads 2-line FASTA records, skips sequences shorter than k, prints the recap."""
-        import gzip
+    def file_query(self, query_file):
+        """blight.cpp:746-799: streams the 2-line FASTA records through the GPU (blmx_query_file), skips sequences shorter
+        than k, prints the reference's recap and returns (good, erroneous)."""
         import time
         t0 = time.time()
-        tp = fp = 0
-        opener = gzip.open if open(query_file, "rb").read(2) == b"\x1f\x8b" else open
-        seqs = []
-
-        def flush():
-            nonlocal tp, fp
-            if seqs:
-                ids = self.query_sequences_hash(seqs)
-                f = int((ids >= 0).sum())
-                tp += f
-                fp += int(ids.size - f)
-                seqs.clear()
-
-        with opener(query_file, "rb") as fh:
-            lines = iter(fh)
-            for hdr in lines:
-                if hdr.rstrip(b"\n") == b"":
-                    next(lines, None)
-                    continue
-                seq = next(lines, b"").rstrip(b"\n")
-                if not seq:
-                    continue
-                if len(seq) >= self._k:
-                    seqs.append(seq)
-                if len(seqs) >= batch:
-                    flush()
-        flush()
+        tp, fp = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.blmx_query_file(self._h, os.fsencode(query_file), C.byref(tp), C.byref(fp)))
         print("-----------------------QUERY RECAP 2----------------------------")
-        print("Good kmer: %d" % tp)
-        print("Erroneous kmers: %d" % fp)
+        print("Good kmer: %d" % tp.value)
+        print("Erroneous kmers: %d" % fp.value)
         print("Query performed: %d" % self.number_query)
         print("The whole QUERY took me %g seconds." % (time.time() - t0))
-        return tp, fp
+        return tp.value, fp.value
 
     # -- device-resident batch API (bench / pipelines): raw device pointers + hipStream_t
     def query_kmers_device(self, d_kmers_ptr, nq, d_ids_ptr, stream=None):

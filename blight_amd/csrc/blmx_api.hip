@@ -42,52 +42,6 @@ template <typename F> int guarded(blmx_index* h, F&& f)
 	}
 }
 
-// 2-line FASTA reader, blight.cpp:212-229: read a header line; if it is empty, swallow one more line and start over;
-// read the sequence line; skip it if empty.  gzopen reads plain and gzip transparently (the reference uses zstr).
-bool read_line(gzFile f, std::string& line)
-{
-	line.clear();
-	char buf[1 << 16];
-	bool got = false;
-	while (gzgets(f, buf, (int)sizeof buf)) {
-		got = true;
-		const size_t n = strlen(buf);
-		if (n && buf[n - 1] == '\n') {
-			line.append(buf, n - 1);
-			return true;
-		}
-		line.append(buf, n);
-	}
-	return got;
-}
-
-int read_fasta(const char* path, std::string& concat, std::vector<uint64_t>& offs)
-{
-	gzFile f = gzopen(path, "rb");
-	if (!f)
-		return BLMX_EIO;
-	gzbuffer(f, 1 << 20);
-	std::string line;
-	offs.assign(1, 0);
-	for (;;) {
-		if (!read_line(f, line))
-			break;
-		if (line.empty()) {
-			if (!read_line(f, line))
-				break;
-			continue;
-		}
-		if (!read_line(f, line))
-			break;
-		if (line.empty())
-			continue;
-		concat += line;
-		offs.push_back(concat.size());
-	}
-	gzclose(f);
-	return BLMX_OK;
-}
-
 void ensure(DevBuf& b, size_t bytes, hipStream_t s)
 {
 	if (bytes > b.bytes)
@@ -240,7 +194,7 @@ int blmx_build_from_fasta(blmx_index* h, const char* path)
 		return BLMX_EINVAL;
 	std::string concat;
 	std::vector<uint64_t> offs;
-	const int rc = read_fasta(path, concat, offs);
+	const int rc = read_fasta_records(path, concat, offs);
 	if (rc)
 		return fail(h, rc, "Problem with files opening");  // blight.cpp:188-189
 	return guarded(h, [&] { build_host(h, concat.data(), offs.data(), offs.size() - 1); });
@@ -352,6 +306,16 @@ int blmx_query_sequences(blmx_index* h, const char* concat, const uint64_t* offs
 		if (e)
 			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
 		ix.st.number_query += nk;
+	});
+}
+
+int blmx_query_file(blmx_index* h, const char* path, uint64_t* good, uint64_t* erroneous)
+{
+	if (!h || !path || !good || !erroneous)
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		std::lock_guard<std::mutex> lock(h->ix.mu);
+		query_file(h->ix, path, *good, *erroneous);
 	});
 }
 

@@ -170,6 +170,9 @@ void launch_route_count(const Index& ix, const void* d_kmers, uint64_t nq, const
 void launch_route_scatter(const Index& ix, const void* d_kmers, const uint8_t* d_dest, uint64_t nq, const uint64_t* d_offsets, uint32_t world,
                           void* d_sorted, uint32_t* d_order, uint64_t* d_cursor, hipStream_t s);
 void launch_unpermute(const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, hipStream_t s);
+// streaming front end (blmx_stream.hip)
+int read_fasta_records(const char* path, std::string& concat, std::vector<uint64_t>& offs);
+void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);
 void launch_primitive(int op, int KW, const void* d_in, uint64_t n, int arg, int arg2, void* d_out, hipStream_t s);
 
 }  // namespace blmx

@@ -15,8 +15,6 @@
 #ifndef BLIGHT_MI355X_FACADE_H
 #define BLIGHT_MI355X_FACADE_H
 
-#include <zlib.h>
-
 #include <chrono>
 #include <cstdint>
 #include <iostream>
@@ -174,43 +172,14 @@ public:
 		return std::make_pair(res, fail);
 	}
 
-	// blight.cpp:746-799: 2-line FASTA records in batches (BATCH_SIZE 512, blight.cpp:129), sequences shorter than k are
-	// skipped (:782), prints "QUERY RECAP 2"
+	// blight.cpp:746-799: streamed through the GPU by blmx_query_file (sequences shorter than k are skipped, :782);
+	// prints "QUERY RECAP 2"
 	void file_query(const std::string& query_file)
 	{
 		const auto t1 = std::chrono::high_resolution_clock::now();
-		gzFile f = gzopen(query_file.c_str(), "rb");
-		if (!f)
-			throw std::runtime_error("Problem with files opening");
 		uint64_t TP = 0, FP = 0;
-		std::vector<std::string> batch;
-		std::string line;
-		auto flush = [&]() {
-			if (batch.empty())
-				return;
-			for (int64_t id : query_sequences_hash(batch))
-				(id >= 0 ? TP : FP)++;
-			batch.clear();
-		};
-		for (;;) {
-			if (!read_line(f, line))
-				break;
-			if (line.empty()) {
-				if (!read_line(f, line))
-					break;
-				continue;
-			}
-			if (!read_line(f, line))
-				break;
-			if (line.empty())
-				continue;
-			if (line.size() >= _k)
-				batch.push_back(line);
-			if (batch.size() >= 4096)
-				flush();
-		}
-		flush();
-		gzclose(f);
+		check(blmx_query_file(_h, query_file.c_str(), &TP, &FP));
+		number_query += TP + FP;
 		std::cout << "-----------------------QUERY RECAP 2----------------------------" << std::endl;
 		std::cout << "Good kmer: " << intToString(TP) << std::endl;
 		std::cout << "Erroneous kmers: " << intToString(FP) << std::endl;
@@ -245,22 +214,6 @@ private:
 		positions_total_size = _st.positions_total_size;
 		largest_bucket_nuc_all = (uint)_st.largest_bucket;
 		bit_per_kmer = number_kmer ? ((double)(2 * _st.total_nt) + (double)positions_total_size) / number_kmer : 0;  // blight.cpp:373-375
-	}
-	static bool read_line(gzFile f, std::string& line)
-	{
-		line.clear();
-		char buf[1 << 16];
-		bool got = false;
-		while (gzgets(f, buf, (int)sizeof buf)) {
-			got = true;
-			const size_t n = std::char_traits<char>::length(buf);
-			if (n && buf[n - 1] == '\n') {
-				line.append(buf, n - 1);
-				return true;
-			}
-			line.append(buf, n);
-		}
-		return got;
 	}
 	static std::string intToString(uint64_t n)  // blight.cpp:35-47: thousands separators
 	{

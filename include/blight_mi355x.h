@@ -109,6 +109,10 @@ int blmx_query_membership(blmx_index* ix, const void* canon_kmers, uint64_t nq, 
  * ids_out holds sum_i max(0, len_i - k + 1) entries, sequence after sequence; sequences shorter than k contribute
  * nothing.  Returns BLMX_EDNA on an invalid character. */
 int blmx_query_sequences(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
+/* file_query(file), reference blight.cpp:746-799: streams the 2-line FASTA records of `path` (plain or gzip) through the
+ * GPU in pinned double-buffered batches (parse | H2D | kernels | 16-byte D2H overlap), skips sequences shorter than k
+ * (blight.cpp:782) and returns the recap counters "Good kmer" / "Erroneous kmers".  Only the two counters cross PCIe back. */
+int blmx_query_file(blmx_index* ix, const char* path, uint64_t* good_out, uint64_t* erroneous_out);
 /* number of IDs blmx_query_sequences writes for these offsets */
 uint64_t blmx_sequence_kmer_count(const blmx_index* ix, const uint64_t* offsets, uint64_t nseq);
 

@@ -129,3 +129,33 @@ def test_shards_union_equals_unsharded(big):
         sh.close()
     assert local == ix.number_kmer
     assert torch.equal(got, want)
+
+
+def test_streaming_file_query_multi_batch(tmp_path):
+    """blmx_query_file on a 130 MB FASTA (several pinned batches in flight): the recap counters must equal the counts
+    computed from the known composition of the file (indexed records, foreign records, records shorter than k, blank lines)."""
+    import blight_amd as B
+    k = 31
+    rng = np.random.default_rng(12)
+    n_idx, n_other, L = 300_000, 900_000, 100
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = letters[rng.integers(0, 4, size=(n_idx + n_other, L), dtype=np.uint8)]
+    fa = tmp_path / "big.fa"
+    with open(fa, "wb") as f:
+        rows = np.empty((n_idx + n_other, 3 + L + 1), dtype=np.uint8)  # ">x\n" + seq + "\n"
+        rows[:, 0] = ord(">")
+        rows[:, 1] = ord("u")
+        rows[:, 2] = ord("\n")
+        rows[:, 3:3 + L] = seqs
+        rows[:, 3 + L] = ord("\n")
+        perm = rng.permutation(n_idx + n_other)
+        f.write(rows[perm].tobytes())
+        f.write(b">short\nACGTACGT\n\n\n>tail-without-newline\n" + bytes(seqs[0]))  # short record, blank header, no final newline
+    ix = B.kmer_Set_Light(k, 9, 7, 6, 1, 6)
+    ix.construct_index_from_sequences([bytes(s) for s in seqs[:n_idx]])
+    per = L - k + 1
+    assert ix.number_kmer == n_idx * per
+    good, bad = ix.file_query(str(fa))
+    assert good == (n_idx + 1) * per  # + the tail record, a copy of an indexed sequence
+    assert bad == n_other * per
+    assert ix.number_query == good + bad
