@@ -358,6 +358,7 @@ struct BuildGroups {
 	const GroupDesc* groups;   // wbase / size[]
 	const uint64_t* loff;      // [ngroups * 16] level offsets in bits
 	uint32_t ngroups;
+	const uint8_t* small;      // per group: 1 = built by the LDS-staged kernel (the global kernels skip its keys), may be null
 };
 
 // group of key index idx: prefix[g] <= idx < prefix[g+1] (empty groups are skipped by the upper bound)
@@ -376,9 +377,9 @@ __device__ __forceinline__ uint32_t group_of_key(const uint64_t* __restrict__ pr
 
 template <int KW>
 __device__ __forceinline__ uint64_t level_bit_address(const BuildGroups& bg, const uint64_t* __restrict__ keys, uint64_t idx, int level,
-                                                      uint64_t& mask)
+                                                      uint64_t& mask, uint32_t& g)
 {
-	const uint32_t g = group_of_key(bg.g_prefix, bg.ngroups, idx);
+	g = group_of_key(bg.g_prefix, bg.ngroups, idx);
 	const uint64_t key = KW == 1 ? keys[idx] : keys[2 * idx];  // 128-bit keys: low 64 bits only (SURVEY C-7)
 	LevelHasher hs(key);
 	uint64_t h = 0;
@@ -400,7 +401,10 @@ __global__ void k_mphf_mark(BuildGroups bg, const uint64_t* __restrict__ keys, c
 		return;
 	const uint64_t idx = list ? (uint64_t)list[t] : t;
 	uint64_t mask;
-	const uint64_t w = level_bit_address<KW>(bg, keys, idx, level, mask);
+	uint32_t g;
+	const uint64_t w = level_bit_address<KW>(bg, keys, idx, level, mask, g);
+	if (bg.small && bg.small[g])
+		return;
 	const unsigned long long old = atomicOr(&bits[w], mask);
 	if (old & mask)
 		atomicOr(&coll[w], mask);
@@ -445,12 +449,129 @@ __global__ __launch_bounds__(kSurviveBlock) void k_mphf_survive(BuildGroups bg, 
 	if (t < count) {
 		idx = list ? (uint64_t)list[t] : t;
 		uint64_t mask;
-		const uint64_t w = level_bit_address<KW>(bg, keys, idx, level, mask);
-		survives = (coll[w] & mask) != 0;
+		uint32_t g;
+		const uint64_t w = level_bit_address<KW>(bg, keys, idx, level, mask, g);
+		survives = !(bg.small && bg.small[g]) && (coll[w] & mask) != 0;
 	}
 	const uint64_t slot = block_append_slot(survives, next_count);
 	if (survives)
 		next[slot] = (uint32_t)idx;
+}
+
+// ---- K7 (LDS-staged): one workgroup builds ALL levels of one MPHF group ------------------------------------------------
+// Global atomicOr executes at the memory side (~20 G scattered atomics/s chip-wide), which made the level kernels above
+// the most expensive part of the build.  A group's level-i bit array (2n bits at level 0 for gamma = 2) fits the 160 KB
+// LDS for groups of up to ~295 K keys, so one 1024-thread workgroup per group keeps the current level's bit and
+// collision arrays in LDS (ds atomics), compacts the survivors into the group's own slice of two global lists, and
+// writes the finished level (bits & ~collisions) with plain coalesced stores.  Keys are read once per level they reach.
+constexpr uint32_t kLdsLevelWords = 18432;                 // 32-bit words per LDS array: 72 KB each, two arrays
+constexpr uint64_t kLdsLevelBits = (uint64_t)kLdsLevelWords * 32;  // level-0 size limit for the LDS path (589,824 bits)
+constexpr unsigned kGroupBlock = 1024;
+
+template <int KW>
+__global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, const uint64_t* __restrict__ keys, uint32_t* __restrict__ listA,
+                                                                uint32_t* __restrict__ listB, uint32_t* __restrict__ gbits32,
+                                                                uint32_t* __restrict__ fb_count, int* __restrict__ levels_max)
+{
+	__shared__ uint32_t s_bits[kLdsLevelWords];
+	__shared__ uint32_t s_coll[kLdsLevelWords];
+	__shared__ uint32_t s_cnt;
+	const uint32_t g = blockIdx.x;
+	if (!bg.small[g])
+		return;
+	const GroupDesc* gd = &bg.groups[g];
+	const uint64_t kb = bg.g_prefix[g];
+	const uint32_t n = (uint32_t)gd->nkeys;
+	uint32_t* cur = listA + kb;
+	uint32_t* nxt = listB + kb;
+	uint32_t count = n;
+	uint64_t loff = 0;
+	int level = 0;
+	for (; level < kLevels && count > 0; level++) {
+		const uint64_t size = gd->size[level];
+		const uint32_t words = (uint32_t)(size >> 5);
+		for (uint32_t w = threadIdx.x; w < words; w += kGroupBlock) {
+			s_bits[w] = 0;
+			s_coll[w] = 0;
+		}
+		if (threadIdx.x == 0)
+			s_cnt = 0;
+		__syncthreads();
+		// mark: test-and-set, a second hit marks the collision map (processLevel_, bbhash.h:677-709)
+		for (uint32_t i = threadIdx.x; i < count; i += kGroupBlock) {
+			const uint32_t j = level == 0 ? i : cur[i];
+			LevelHasher hs(KW == 1 ? keys[kb + j] : keys[2 * (kb + j)]);
+			uint64_t h = 0;
+			for (int l = 0; l <= level; l++)
+				h = hs.next(l);
+			const uint32_t b = (uint32_t)reduce_level(h, size);
+			const uint32_t m = 1u << (b & 31);
+			if (atomicOr(&s_bits[b >> 5], m) & m)
+				atomicOr(&s_coll[b >> 5], m);
+		}
+		__syncthreads();
+		// survivors (wave-aggregated append into the group's slice of the next list)
+		const uint32_t rounds = (count + kGroupBlock - 1) / kGroupBlock;
+		for (uint32_t r = 0; r < rounds; r++) {
+			const uint32_t i = r * kGroupBlock + threadIdx.x;
+			bool surv = false;
+			uint32_t j = 0;
+			if (i < count) {
+				j = level == 0 ? i : cur[i];
+				LevelHasher hs(KW == 1 ? keys[kb + j] : keys[2 * (kb + j)]);
+				uint64_t h = 0;
+				for (int l = 0; l <= level; l++)
+					h = hs.next(l);
+				const uint32_t b = (uint32_t)reduce_level(h, size);
+				surv = (s_coll[b >> 5] >> (b & 31)) & 1u;
+			}
+			const unsigned long long bal = __ballot(surv);
+			if (bal) {
+				const uint32_t lane = threadIdx.x & 63;
+				uint32_t base = 0;
+				const int leader = __ffsll(bal) - 1;
+				if ((int)lane == leader)
+					base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
+				base = __shfl(base, leader);
+				if (surv)
+					nxt[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = j;
+			}
+		}
+		__syncthreads();
+		// the finished level: bits that exactly one key claimed (clearCollisions, bbhash.h:358-368)
+		uint32_t* out = gbits32 + 2 * gd->wbase + (loff >> 5);
+		for (uint32_t w = threadIdx.x; w < words; w += kGroupBlock)
+			out[w] = s_bits[w] & ~s_coll[w];
+		const uint32_t c = s_cnt;
+		__syncthreads();
+		count = c;
+		loff += size;
+		uint32_t* t = cur;
+		cur = nxt;
+		nxt = t;
+	}
+	if (threadIdx.x == 0) {
+		fb_count[g] = count;  // keys left after 16 levels stay in `cur` (their positions in the group)
+		atomicMax(levels_max, level);
+	}
+	// leave the survivors where the host-side merge expects them: listA slice
+	if (count > 0 && cur != listA + kb) {
+		for (uint32_t i = threadIdx.x; i < count; i += kGroupBlock)
+			listA[kb + i] = cur[i];
+	}
+}
+
+// fallback keys of the LDS-built groups -> global key indices appended to the fallback list
+__global__ void k_fb_collect(const uint64_t* __restrict__ g_prefix, const uint32_t* __restrict__ fb_count, const uint64_t* __restrict__ fb_off,
+                             const uint32_t* __restrict__ listA, uint32_t ngroups, uint32_t* __restrict__ fb_list)
+{
+	const uint32_t g = blockIdx.x;
+	if (g >= ngroups)
+		return;
+	const uint32_t c = fb_count[g];
+	const uint64_t kb = g_prefix[g];
+	for (uint32_t i = threadIdx.x; i < c; i += blockDim.x)
+		fb_list[fb_off[g] + i] = (uint32_t)(kb + listA[kb + i]);
 }
 
 // ---- K8 ----------------------------------------------------------------------------------------------------------------
@@ -1013,24 +1134,69 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_skpos.release();
 	d_order.release();
 
-	// ---- K7: BBHash levels, all groups at once
-	DevBuf d_bits, d_coll, d_listA, d_listB, d_cnt;
+	// ---- K7: BBHash levels.  Groups whose level-0 array fits the LDS budget are built by one workgroup each
+	// (k_mphf_group_lds); the others go through the global level kernels, which skip the keys of the LDS-built groups.
+	DevBuf d_bits, d_coll, d_listA, d_listB, d_cnt, d_small, d_fbcnt, d_fboff, d_lvmax, d_fball;
 	BLMX_HIP(d_bits.alloc((total_words + 1) * 8, true, s));
 	BLMX_HIP(d_coll.alloc((total_words + 1) * 8, true, s));
 	BLMX_HIP(d_cnt.alloc(8, true, s));
-	BuildGroups bg{d_gpre.as<uint64_t>(), d_bgroups.as<GroupDesc>(), d_loff.as<uint64_t>(), ngroups};
-	uint64_t count = N;
+	std::vector<uint8_t> h_small(ngroups, 0);
+	uint64_t n_small = 0, keys_large = 0;
+	const char* lds_env = getenv("BLIGHT_BUILD_NO_LDS");  // test hook: force the global level kernels for every group
+	const bool lds_off = lds_env && atoi(lds_env) != 0;
+	for (uint32_t g = 0; g < ngroups; g++) {
+		const GroupDesc& gd = ix.h_groups[g];
+		if (gd.nkeys && !lds_off && gd.size[0] <= kLdsLevelBits) {
+			h_small[g] = 1;
+			n_small++;
+		} else {
+			keys_large += gd.nkeys;
+		}
+	}
+	BLMX_HIP(d_small.alloc((size_t)ngroups, false, s));
+	BLMX_HIP(hipMemcpyAsync(d_small.p, h_small.data(), ngroups, hipMemcpyHostToDevice, s));
+	BuildGroups bg{d_gpre.as<uint64_t>(), d_bgroups.as<GroupDesc>(), d_loff.as<uint64_t>(), ngroups, d_small.as<uint8_t>()};
+	int levels_used = 0;
+	uint64_t F_lds = 0;
+	std::vector<uint64_t> h_fboff;
+	if (n_small) {
+		DevBuf d_lA, d_lB;
+		BLMX_HIP(d_lA.alloc((N + 1) * 4, false, s));
+		BLMX_HIP(d_lB.alloc((N + 1) * 4, false, s));
+		BLMX_HIP(d_fbcnt.alloc((size_t)ngroups * 4, true, s));
+		BLMX_HIP(d_lvmax.alloc(4, true, s));
+		hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3(ngroups), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(), d_lA.as<uint32_t>(),
+		                   d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>());
+		BLMX_HIP(hipGetLastError());
+		std::vector<uint32_t> h_fbcnt(ngroups);
+		BLMX_HIP(hipMemcpyAsync(h_fbcnt.data(), d_fbcnt.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
+		levels_used = read_scalar(d_lvmax.as<int>(), s);
+		h_fboff.assign(ngroups, 0);
+		for (uint32_t g = 0; g < ngroups; g++) {
+			h_fboff[g] = F_lds;
+			F_lds += h_fbcnt[g];
+		}
+		if (F_lds) {
+			BLMX_HIP(d_fboff.alloc((size_t)ngroups * 8, false, s));
+			BLMX_HIP(hipMemcpyAsync(d_fboff.p, h_fboff.data(), (size_t)ngroups * 8, hipMemcpyHostToDevice, s));
+			BLMX_HIP(d_fball.alloc((F_lds + 1) * 4, false, s));
+			hipLaunchKernelGGL(k_fb_collect, dim3(ngroups), dim3(256), 0, s, d_gpre.as<uint64_t>(), d_fbcnt.as<uint32_t>(), d_fboff.as<uint64_t>(),
+			                   d_lA.as<uint32_t>(), ngroups, d_fball.as<uint32_t>());
+			BLMX_HIP(hipGetLastError());
+		}
+		BLMX_HIP(hipStreamSynchronize(s));
+	}
+	uint64_t count = keys_large ? N : 0;
 	const uint32_t* cur = nullptr;
 	uint32_t* nxt = nullptr;
-	int levels_used = 0;
 	uint64_t F = 0;
 	for (int level = 0; level < kLevels && count > 0; level++) {
-		levels_used = level + 1;
+		levels_used = std::max(levels_used, level + 1);
 		hipLaunchKernelGGL((k_mphf_mark<KW>), dim3(grid_for(count)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
 		                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>());
-		// survivors list: at most `count` entries
+		// survivors list: at most `count` entries (level 0 walks all keys and skips those of the LDS-built groups)
 		DevBuf& dst = (level & 1) ? d_listB : d_listA;
-		BLMX_HIP(dst.alloc((count + 1) * 4, false, s));
+		BLMX_HIP(dst.alloc((std::min(count, keys_large) + 1) * 4, false, s));
 		nxt = dst.as<uint32_t>();
 		BLMX_HIP(hipMemsetAsync(d_cnt.p, 0, 8, s));
 		hipLaunchKernelGGL((k_mphf_survive<KW>), dim3(grid_for(count, kSurviveBlock)), dim3(kSurviveBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
@@ -1040,6 +1206,19 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		cur = nxt;
 		if (level == kLevels - 1)
 			F = count;
+	}
+	// one fallback list: the global path's survivors followed by those of the LDS-built groups (sorted by key index below)
+	if (F_lds) {
+		DevBuf d_merge;
+		BLMX_HIP(d_merge.alloc((F + F_lds + 1) * 4, false, s));
+		if (F)
+			BLMX_HIP(hipMemcpyAsync(d_merge.p, cur, F * 4, hipMemcpyDeviceToDevice, s));
+		BLMX_HIP(hipMemcpyAsync(d_merge.as<uint32_t>() + F, d_fball.p, F_lds * 4, hipMemcpyDeviceToDevice, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+		std::swap(d_fball.p, d_merge.p);
+		std::swap(d_fball.bytes, d_merge.bytes);
+		cur = d_fball.as<uint32_t>();
+		F += F_lds;
 	}
 
 	// ---- K8: collisions cleared + ranks -> 16-B lines [u32 rank | 96 bits]
@@ -1142,6 +1321,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	st.shard_world = world;
 	st.shard_group_lo = glo;
 	st.shard_group_hi = ghi;
+	st.mphf_groups_lds_built = (uint32_t)n_small;
 	st.largest_mphf = largest_mphf;
 	st.positions_total_size = total_pos;
 	st.total_nt = total_nt;

@@ -233,3 +233,27 @@ def test_binned_batch_query_equals_direct(B, O, k, m, n, b, kb):
     # tiny and empty batches through the binned path
     assert np.array_equal(ix.query_kmer_hash(q[:3].reshape(-1)), direct[:3])
     assert ix.query_kmer_hash(np.zeros(0, np.uint64)).size == 0
+
+
+def test_both_mphf_build_paths(B, O, monkeypatch):
+    """BBHash levels are built either by one workgroup per group in LDS (groups of up to ~295 K keys) or by the global level
+    kernels (larger groups); both must give the oracle's arrays, alone and mixed inside one index."""
+    c = G.Case("dup_k31_m7_n5_b6")  # exercises 16 levels + fallback
+    for no_lds in ("0", "1"):
+        monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", no_lds)
+        ix = _build(B, c.k, c.m, c.n, c.b, c.seqs)
+        assert (ix.stats()["mphf_groups_lds_built"] > 0) == (no_lds == "0")
+        assert np.array_equal(ix.query_sequences_hash(c.seqs), c.ids)
+        _check_against_oracle_arrays(ix, O.Oracle(c.k, c.m, c.n, c.b, c.seqs))
+    monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", "0")
+    # mixed: a 3-letter source skews the minimizers, so some of the 4 groups exceed the LDS budget and some do not
+    rng = np.random.default_rng(21)
+    seqs = [_rand_seq(rng, 31 + int(rng.integers(20, 400)), "ACG") for _ in range(7000)]
+    k, m, n, b = 31, 9, 2, 6
+    ix = _build(B, k, m, n, b, seqs)
+    st = ix.stats()
+    orc = O.Oracle(k, m, n, b, seqs)
+    nk = orc.arrays()["g_nkeys"]
+    assert 0 < st["mphf_groups_lds_built"] < int((nk > 0).sum()), (st["mphf_groups_lds_built"], nk.tolist())
+    _check_against_oracle_arrays(ix, orc)
+    assert np.array_equal(ix.query_sequences_hash(seqs[:500]), np.concatenate([orc.query_sequence(s) for s in seqs[:500]]))
