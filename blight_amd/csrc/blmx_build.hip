@@ -107,43 +107,68 @@ __device__ __forceinline__ uint64_t bitmap_window(const unsigned long long* __re
 //   head bit q = valid(q) && !cont(q)          -> a super-k-mer starts at q
 //   end  bit q = valid(q-1) && !cont(q)        -> a super-k-mer's last k-mer is q-1
 // Each wave covers one aligned 64-position word of both bitmaps and writes it with one ballot.
+//
+// Rolling minimizer (SuperKChopper::update_mini, kmer.h:734-781, is a monotone deque over the m-mer hashes): here every
+// lane hashes ONE m-mer (the one starting at its position: parity-canonical form, signed revhash) into LDS and the
+// window minimum over the w = k-m+1 m-mers of each k-mer is assembled from power-of-two prefix minima
+// (M_{p+1}[i] = min(M_p[i], M_p[i+2^p]); the window is the disjoint union of the blocks given by the binary digits of w):
+// ceil(log2 w)+1 LDS rounds instead of w hashes per k-mer.  revhash is a bijection, so two k-mers have the same
+// minimizer VALUE iff their window-minimum hashes are equal: the comparison is done on the hashes.
 template <int KW>
 __global__ __launch_bounds__(kBlock) void k_superkmer_flags(const uint64_t* __restrict__ src, const unsigned long long* __restrict__ ustart,
                                                             uint64_t total_len, int k, int m, unsigned long long* __restrict__ Hb,
                                                             unsigned long long* __restrict__ Eb)
 {
-	__shared__ uint32_t sm_mini[kBlock + 1];
-	__shared__ uint8_t sm_valid[kBlock + 1];
+	constexpr int kMaxW = 64;
+	__shared__ int32_t s_pow[2][kBlock + kMaxW + 2];  // prefix minima over blocks of 2^p m-mers, double buffered
+	__shared__ int32_t s_min[kBlock + 1];             // window minimum of the k-mer at position base-1+e
+	__shared__ uint8_t s_valid[kBlock + 1];
+	const int w = k - m + 1;
+	const int L = (int)kBlock + w;  // m-mer entries e = 0 .. L-1  <->  positions base-1 .. base+kBlock-1+w-1
 	const uint64_t base = (uint64_t)blockIdx.x * kBlock;
-	const uint64_t q = base + threadIdx.x;
-	auto eval = [&](uint64_t p, uint32_t& mini) -> bool {
-		mini = 0;
-		if (p + (uint64_t)k > total_len)
+	const int tid = (int)threadIdx.x;
+	auto mmer_hash = [&](int e) -> int32_t {
+		const int64_t p = (int64_t)base - 1 + e;
+		if (p < 0 || (uint64_t)p + (uint64_t)m > total_len)
+			return 0x7fffffff;
+		const uint64_t wd = (uint64_t)p >> 5;
+		const int sh = 2 * (int)(p & 31);
+		const uint32_t f = (uint32_t)(funnel_left(src[wd], src[wd + 1], sh) >> (64 - 2 * m));
+		const uint32_t r = (uint32_t)(rc_digits64((uint64_t)f) >> (64 - 2 * m));
+		return revhash32(((__popc(f) & 1) ? f : r) >> 1);  // ParityCanonical, kmer.h:475-487; revhash kmer.h:102-108
+	};
+	auto kmer_valid = [&](int64_t p) -> bool {
+		if (p < 0 || (uint64_t)p + (uint64_t)k > total_len)
 			return false;
 		// unitig starts inside (p, p+k-1] make the k-mer straddle two unitigs
-		const uint64_t win = bitmap_window(ustart, p + 1);
+		const uint64_t win = bitmap_window(ustart, (uint64_t)p + 1);
 		const uint64_t msk = (k - 1 >= 64) ? ~0ull : ((1ull << (k - 1)) - 1ull);
-		if (win & msk)
-			return false;
-		const Kmer<KW> x = packed_kmer<KW>(src, p, k);
-		mini = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m);
-		return true;
+		return (win & msk) == 0;
 	};
-	uint32_t mini;
-	const bool valid = eval(q, mini);
-	sm_mini[threadIdx.x + 1] = mini;
-	sm_valid[threadIdx.x + 1] = valid ? 1 : 0;
-	if (threadIdx.x == 0) {
-		uint32_t pm = 0;
-		const bool pv = base > 0 ? eval(base - 1, pm) : false;
-		sm_mini[0] = pm;
-		sm_valid[0] = pv ? 1 : 0;
+	for (int e = tid; e < L; e += (int)kBlock)
+		s_pow[0][e] = mmer_hash(e);
+	for (int e = tid; e <= (int)kBlock; e += (int)kBlock) {
+		s_min[e] = 0x7fffffff;
+		s_valid[e] = kmer_valid((int64_t)base - 1 + e) ? 1 : 0;
 	}
 	__syncthreads();
-	const bool pvalid = sm_valid[threadIdx.x] != 0;
-	const uint32_t pmini = sm_mini[threadIdx.x];
+	int cur = 0, off = 0;
+	for (int p2 = 0; (1 << p2) <= w; p2++) {
+		const int step = 1 << p2;
+		if (w & step) {
+			for (int e = tid; e <= (int)kBlock; e += (int)kBlock)
+				s_min[e] = min(s_min[e], s_pow[cur][e + off]);
+			off += step;
+		}
+		for (int e = tid; e + step < L; e += (int)kBlock)
+			s_pow[cur ^ 1][e] = min(s_pow[cur][e], s_pow[cur][e + step]);
+		__syncthreads();
+		cur ^= 1;
+	}
+	const uint64_t q = base + threadIdx.x;
+	const bool valid = s_valid[tid + 1] != 0, pvalid = s_valid[tid] != 0;
 	const bool is_start = q <= total_len && ((ustart[q >> 6] >> (q & 63)) & 1ull);
-	const bool cont = pvalid && valid && pmini == mini && !is_start;
+	const bool cont = pvalid && valid && s_min[tid] == s_min[tid + 1] && !is_start;
 	const unsigned long long hb = __ballot(valid && !cont);
 	const unsigned long long eb = __ballot(pvalid && !cont);
 	if ((threadIdx.x & 63) == 0) {
@@ -463,22 +488,23 @@ __global__ __launch_bounds__(kSurviveBlock) void k_mphf_survive(BuildGroups bg, 
 // the most expensive part of the build.  A group's level-i bit array (2n bits at level 0 for gamma = 2) fits the 160 KB
 // LDS for groups of up to ~295 K keys, so one 1024-thread workgroup per group keeps the current level's bit and
 // collision arrays in LDS (ds atomics), compacts the survivors into the group's own slice of two global lists, and
-// writes the finished level (bits & ~collisions) with plain coalesced stores.  Keys are read once per level they reach.
+// writes the finished level (bits & ~collisions) with plain coalesced stores.  Levels larger than the LDS arrays are
+// built in up to kLdsMaxSlices slices (one walk over the level's keys per slice).
 constexpr uint32_t kLdsLevelWords = 18432;                 // 32-bit words per LDS array: 72 KB each, two arrays
-constexpr uint64_t kLdsLevelBits = (uint64_t)kLdsLevelWords * 32;  // level-0 size limit for the LDS path (589,824 bits)
+constexpr uint64_t kLdsLevelBits = (uint64_t)kLdsLevelWords * 32;  // bits per LDS slice (589,824)
+constexpr uint32_t kLdsMaxSlices = 4;  // larger groups (> ~1.18 M keys) use the global level kernels
 constexpr unsigned kGroupBlock = 1024;
 
 template <int KW>
 __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, const uint64_t* __restrict__ keys, uint32_t* __restrict__ listA,
                                                                 uint32_t* __restrict__ listB, uint32_t* __restrict__ gbits32,
-                                                                uint32_t* __restrict__ fb_count, int* __restrict__ levels_max)
+                                                                uint32_t* __restrict__ fb_count, int* __restrict__ levels_max,
+                                                                const uint32_t* __restrict__ order)
 {
 	__shared__ uint32_t s_bits[kLdsLevelWords];
 	__shared__ uint32_t s_coll[kLdsLevelWords];
 	__shared__ uint32_t s_cnt;
-	const uint32_t g = blockIdx.x;
-	if (!bg.small[g])
-		return;
+	const uint32_t g = order[blockIdx.x];  // largest groups first: the multi-slice groups must not be the tail of the grid
 	const GroupDesc* gd = &bg.groups[g];
 	const uint64_t kb = bg.g_prefix[g];
 	const uint32_t n = (uint32_t)gd->nkeys;
@@ -490,58 +516,68 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 	for (; level < kLevels && count > 0; level++) {
 		const uint64_t size = gd->size[level];
 		const uint32_t words = (uint32_t)(size >> 5);
-		for (uint32_t w = threadIdx.x; w < words; w += kGroupBlock) {
-			s_bits[w] = 0;
-			s_coll[w] = 0;
-		}
 		if (threadIdx.x == 0)
 			s_cnt = 0;
-		__syncthreads();
-		// mark: test-and-set, a second hit marks the collision map (processLevel_, bbhash.h:677-709)
-		for (uint32_t i = threadIdx.x; i < count; i += kGroupBlock) {
-			const uint32_t j = level == 0 ? i : cur[i];
-			LevelHasher hs(KW == 1 ? keys[kb + j] : keys[2 * (kb + j)]);
-			uint64_t h = 0;
-			for (int l = 0; l <= level; l++)
-				h = hs.next(l);
-			const uint32_t b = (uint32_t)reduce_level(h, size);
-			const uint32_t m = 1u << (b & 31);
-			if (atomicOr(&s_bits[b >> 5], m) & m)
-				atomicOr(&s_coll[b >> 5], m);
-		}
-		__syncthreads();
-		// survivors (wave-aggregated append into the group's slice of the next list)
-		const uint32_t rounds = (count + kGroupBlock - 1) / kGroupBlock;
-		for (uint32_t r = 0; r < rounds; r++) {
-			const uint32_t i = r * kGroupBlock + threadIdx.x;
-			bool surv = false;
-			uint32_t j = 0;
-			if (i < count) {
-				j = level == 0 ? i : cur[i];
+		// a level larger than the LDS arrays is built in slices of kLdsLevelWords words: every pass walks the level's keys
+		// and handles those whose bit falls into the slice (key reads are coalesced and cheap next to global atomics)
+		for (uint32_t w0 = 0; w0 < words; w0 += kLdsLevelWords) {
+			const uint32_t wn = min(kLdsLevelWords, words - w0);
+			for (uint32_t w = threadIdx.x; w < wn; w += kGroupBlock) {
+				s_bits[w] = 0;
+				s_coll[w] = 0;
+			}
+			__syncthreads();
+			// mark: test-and-set, a second hit marks the collision map (processLevel_, bbhash.h:677-709)
+			for (uint32_t i = threadIdx.x; i < count; i += kGroupBlock) {
+				const uint32_t j = level == 0 ? i : cur[i];
 				LevelHasher hs(KW == 1 ? keys[kb + j] : keys[2 * (kb + j)]);
 				uint64_t h = 0;
 				for (int l = 0; l <= level; l++)
 					h = hs.next(l);
 				const uint32_t b = (uint32_t)reduce_level(h, size);
-				surv = (s_coll[b >> 5] >> (b & 31)) & 1u;
+				const uint32_t lw = (b >> 5) - w0;
+				if (lw < wn) {
+					const uint32_t m = 1u << (b & 31);
+					if (atomicOr(&s_bits[lw], m) & m)
+						atomicOr(&s_coll[lw], m);
+				}
 			}
-			const unsigned long long bal = __ballot(surv);
-			if (bal) {
-				const uint32_t lane = threadIdx.x & 63;
-				uint32_t base = 0;
-				const int leader = __ffsll(bal) - 1;
-				if ((int)lane == leader)
-					base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
-				base = __shfl(base, leader);
-				if (surv)
-					nxt[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = j;
+			__syncthreads();
+			// survivors of this slice (wave-aggregated append into the group's slice of the next list)
+			const uint32_t rounds = (count + kGroupBlock - 1) / kGroupBlock;
+			for (uint32_t r = 0; r < rounds; r++) {
+				const uint32_t i = r * kGroupBlock + threadIdx.x;
+				bool surv = false;
+				uint32_t j = 0;
+				if (i < count) {
+					j = level == 0 ? i : cur[i];
+					LevelHasher hs(KW == 1 ? keys[kb + j] : keys[2 * (kb + j)]);
+					uint64_t h = 0;
+					for (int l = 0; l <= level; l++)
+						h = hs.next(l);
+					const uint32_t b = (uint32_t)reduce_level(h, size);
+					const uint32_t lw = (b >> 5) - w0;
+					surv = lw < wn && ((s_coll[lw] >> (b & 31)) & 1u);
+				}
+				const unsigned long long bal = __ballot(surv);
+				if (bal) {
+					const uint32_t lane = threadIdx.x & 63;
+					uint32_t base = 0;
+					const int leader = __ffsll(bal) - 1;
+					if ((int)lane == leader)
+						base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
+					base = __shfl(base, leader);
+					if (surv)
+						nxt[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = j;
+				}
 			}
+			__syncthreads();
+			// the finished slice: bits that exactly one key claimed (clearCollisions, bbhash.h:358-368)
+			uint32_t* out = gbits32 + 2 * gd->wbase + (loff >> 5) + w0;
+			for (uint32_t w = threadIdx.x; w < wn; w += kGroupBlock)
+				out[w] = s_bits[w] & ~s_coll[w];
+			__syncthreads();
 		}
-		__syncthreads();
-		// the finished level: bits that exactly one key claimed (clearCollisions, bbhash.h:358-368)
-		uint32_t* out = gbits32 + 2 * gd->wbase + (loff >> 5);
-		for (uint32_t w = threadIdx.x; w < words; w += kGroupBlock)
-			out[w] = s_bits[w] & ~s_coll[w];
 		const uint32_t c = s_cnt;
 		__syncthreads();
 		count = c;
@@ -559,6 +595,18 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 		for (uint32_t i = threadIdx.x; i < count; i += kGroupBlock)
 			listA[kb + i] = cur[i];
 	}
+}
+
+// first work list of the global level kernels: the key indices of the groups that do NOT fit the LDS path
+__global__ void k_seed_large_list(const uint64_t* __restrict__ g_prefix, const uint8_t* __restrict__ small, const uint64_t* __restrict__ seed_off,
+                                  uint32_t ngroups, uint32_t* __restrict__ list)
+{
+	const uint32_t g = blockIdx.x;
+	if (g >= ngroups || small[g])
+		return;
+	const uint64_t kb = g_prefix[g], n = g_prefix[g + 1] - kb, o = seed_off[g];
+	for (uint64_t i = threadIdx.x; i < n; i += blockDim.x)
+		list[o + i] = (uint32_t)(kb + i);
 }
 
 // fallback keys of the LDS-built groups -> global key indices appended to the fallback list
@@ -1146,7 +1194,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	const bool lds_off = lds_env && atoi(lds_env) != 0;
 	for (uint32_t g = 0; g < ngroups; g++) {
 		const GroupDesc& gd = ix.h_groups[g];
-		if (gd.nkeys && !lds_off && gd.size[0] <= kLdsLevelBits) {
+		if (gd.nkeys && !lds_off && gd.size[0] <= kLdsLevelBits * kLdsMaxSlices) {
 			h_small[g] = 1;
 			n_small++;
 		} else {
@@ -1165,8 +1213,20 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		BLMX_HIP(d_lB.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_fbcnt.alloc((size_t)ngroups * 4, true, s));
 		BLMX_HIP(d_lvmax.alloc(4, true, s));
-		hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3(ngroups), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(), d_lA.as<uint32_t>(),
-		                   d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>());
+		std::vector<uint32_t> h_order;
+		h_order.reserve(n_small);
+		for (uint32_t g = 0; g < ngroups; g++)
+			if (h_small[g])
+				h_order.push_back(g);
+		std::sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b2) {
+			return ix.h_groups[a].nkeys != ix.h_groups[b2].nkeys ? ix.h_groups[a].nkeys > ix.h_groups[b2].nkeys : a < b2;
+		});
+		DevBuf d_gorder;
+		BLMX_HIP(d_gorder.alloc(h_order.size() * 4, false, s));
+		BLMX_HIP(hipMemcpyAsync(d_gorder.p, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3((unsigned)h_order.size()), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(),
+		                   d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>(),
+		                   d_gorder.as<uint32_t>());
 		BLMX_HIP(hipGetLastError());
 		std::vector<uint32_t> h_fbcnt(ngroups);
 		BLMX_HIP(hipMemcpyAsync(h_fbcnt.data(), d_fbcnt.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
@@ -1186,10 +1246,29 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		}
 		BLMX_HIP(hipStreamSynchronize(s));
 	}
-	uint64_t count = keys_large ? N : 0;
+	// global path: seeded with the keys of the large groups only (all keys when the LDS path is unused)
+	uint64_t count = keys_large;
 	const uint32_t* cur = nullptr;
 	uint32_t* nxt = nullptr;
 	uint64_t F = 0;
+	DevBuf d_seed, d_seedoff;
+	if (keys_large && n_small) {
+		std::vector<uint64_t> h_seedoff(ngroups, 0);
+		uint64_t o = 0;
+		for (uint32_t g = 0; g < ngroups; g++) {
+			h_seedoff[g] = o;
+			if (!h_small[g])
+				o += ix.h_groups[g].nkeys;
+		}
+		BLMX_HIP(d_seedoff.alloc((size_t)ngroups * 8, false, s));
+		BLMX_HIP(hipMemcpyAsync(d_seedoff.p, h_seedoff.data(), (size_t)ngroups * 8, hipMemcpyHostToDevice, s));
+		BLMX_HIP(d_seed.alloc((keys_large + 1) * 4, false, s));
+		hipLaunchKernelGGL(k_seed_large_list, dim3(ngroups), dim3(256), 0, s, d_gpre.as<uint64_t>(), d_small.as<uint8_t>(), d_seedoff.as<uint64_t>(),
+		                   ngroups, d_seed.as<uint32_t>());
+		BLMX_HIP(hipGetLastError());
+		BLMX_HIP(hipStreamSynchronize(s));  // h_seedoff goes out of scope
+		cur = d_seed.as<uint32_t>();
+	}
 	for (int level = 0; level < kLevels && count > 0; level++) {
 		levels_used = std::max(levels_used, level + 1);
 		hipLaunchKernelGGL((k_mphf_mark<KW>), dim3(grid_for(count)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,

@@ -236,8 +236,8 @@ def test_binned_batch_query_equals_direct(B, O, k, m, n, b, kb):
 
 
 def test_both_mphf_build_paths(B, O, monkeypatch):
-    """BBHash levels are built either by one workgroup per group in LDS (groups of up to ~295 K keys) or by the global level
-    kernels (larger groups); both must give the oracle's arrays, alone and mixed inside one index."""
+    """BBHash levels are built either by one workgroup per group in LDS (groups of up to ~1.18 M keys, in 1-4 slices) or by
+    the global level kernels (larger groups); both must give the oracle's arrays, alone and mixed inside one index."""
     c = G.Case("dup_k31_m7_n5_b6")  # exercises 16 levels + fallback
     for no_lds in ("0", "1"):
         monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", no_lds)
@@ -248,7 +248,7 @@ def test_both_mphf_build_paths(B, O, monkeypatch):
     monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", "0")
     # mixed: a 3-letter source skews the minimizers, so some of the 4 groups exceed the LDS budget and some do not
     rng = np.random.default_rng(21)
-    seqs = [_rand_seq(rng, 31 + int(rng.integers(20, 400)), "ACG") for _ in range(7000)]
+    seqs = [_rand_seq(rng, 31 + int(rng.integers(20, 400)), "ACG") for _ in range(20000)]
     k, m, n, b = 31, 9, 2, 6
     ix = _build(B, k, m, n, b, seqs)
     st = ix.stats()
