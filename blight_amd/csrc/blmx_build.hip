@@ -18,6 +18,8 @@
 //
 // All build-time atomics are ORs into zeroed arrays or order-independent appends that are sorted afterwards, so the
 // finished index is bit-for-bit reproducible.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -903,6 +905,18 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	Scratch sc;
 	sc.s = s;
 	(void)n;
+	// BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream).  Note that on this
+	// driver a fresh hipMalloc costs ~30-50 ms per GB (VRAM is cleared on allocation), which can exceed the kernel time.
+	const bool trace = getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) != 0;
+	auto t_last = t_begin;
+	auto mark = [&](const char* what) {
+		if (!trace)
+			return;
+		(void)hipStreamSynchronize(s);
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[blmx build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
 
 	DevBuf d_err;
 	BLMX_HIP(d_err.alloc(sizeof(int), true, s));
@@ -929,6 +943,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		check_build_err(d_err.as<int>(), s);
 	}
 
+	mark("K1 encode+starts");
 	// ---- K2: super-k-mer head / end bitmaps
 	uint64_t nsk = 0;
 	DevBuf d_Hpre, d_Epre;
@@ -952,6 +967,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	}
 	d_ustart.release();
 
+	mark("K2 flags+scans");
 	// ---- K3: compact super-k-mers
 	DevBuf d_skpos, d_sklast, d_skmini;
 	BLMX_HIP(d_skpos.alloc((nsk + 1) * 8, false, s));
@@ -969,6 +985,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_Hpre.release();
 	d_Epre.release();
 
+	mark("K3 collect");
 	// ---- sharding: every rank sees the whole input, derives the same key-balanced group boundaries from the
 	// global per-group key histogram, and keeps only the super-k-mers of its own groups.  IDs stay global (id_base).
 	uint64_t id_base = 0, global_N = 0;
@@ -1033,6 +1050,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		nsk = kept;
 	}
 
+	mark("shard filter");
 	// ---- K4: stable sort by minimizer, offsets, bucket + group tables
 	DevBuf d_smini, d_order, d_lennt, d_lenk, d_ntstart, d_keystart;
 	BLMX_HIP(d_smini.alloc((nsk + 1) * 4, false, s));
@@ -1112,6 +1130,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_gnk.release();
 	d_gmax.release();
 
+	mark("K4 sort+tables");
 	// ---- host: group descriptors (blight.cpp:292-303) and BBHash level tables (bbhash.h:591-614)
 	ix.h_groups.assign(ngroups, GroupDesc{});
 	std::vector<uint64_t> h_loff((size_t)ngroups * kLevels, 0), h_line_base((size_t)ngroups + 1, 0);
@@ -1162,6 +1181,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	BLMX_HIP(hipMemcpyAsync(d_line_base.p, h_line_base.data(), h_line_base.size() * 8, hipMemcpyHostToDevice, s));
 	BLMX_HIP(hipMemcpyAsync(d_bgroups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
 
+	mark("host descriptors");
 	// ---- K5: packed bucket sequence.  Padding: the 2^b scan may read NW words past the last k-mer (blight.cpp:738)
 	const uint64_t pad_words = ((1ull << std::min(b, 20)) + 64 * (uint64_t)KW + 64) / 32 + 4;
 	ix.seq_words = total_nt / 32 + pad_words;
@@ -1170,6 +1190,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		hipLaunchKernelGGL(k_scatter_pack, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
 		                   d_skpos.as<uint64_t>(), d_ntstart.as<uint64_t>(), nsk, ix.seq.as<unsigned long long>());
 
+	mark("K5 scatter_pack");
 	// ---- K6: keys in (bucket, position) order
 	DevBuf d_keys;
 	BLMX_HIP(d_keys.alloc((N + 1) * 8 * KW, false, s));
@@ -1182,6 +1203,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_skpos.release();
 	d_order.release();
 
+	mark("K6 expand_keys");
 	// ---- K7: BBHash levels.  Groups whose level-0 array fits the LDS budget are built by one workgroup each
 	// (k_mphf_group_lds); the others go through the global level kernels, which skip the keys of the LDS-built groups.
 	DevBuf d_bits, d_coll, d_listA, d_listB, d_cnt, d_small, d_fbcnt, d_fboff, d_lvmax, d_fball;
@@ -1300,6 +1322,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		F += F_lds;
 	}
 
+	mark("K7 mphf levels");
 	// ---- K8: collisions cleared + ranks -> 16-B lines [u32 rank | 96 bits]
 	DevBuf d_linepc, d_linepre, d_gpopc;
 	BLMX_HIP(d_linepc.alloc((total_lines + 1) * 8, false, s));
@@ -1322,6 +1345,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_coll.release();
 	d_linepc.release();
 
+	mark("K8 lines+ranks");
 	// ---- K9a: fallback table
 	DevBuf d_fbsorted, d_fk, d_frank, d_fgrp, d_perm, d_tgrp, d_gfbstart, d_gfbcount;
 	BLMX_HIP(ix.fb_keys.alloc((F + 1) * 8 * KW, true, s));
@@ -1372,6 +1396,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	BLMX_HIP(ix.groups.alloc((size_t)ngroups * sizeof(GroupDesc), false, s));
 	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
 
+	mark("K9a fallback");
 	// ---- K9b: positions
 	ix.positions_words = total_pos / 64 + 3;
 	BLMX_HIP(ix.positions.alloc(ix.positions_words * 8, true, s));
@@ -1389,6 +1414,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	}
 	BLMX_HIP(hipStreamSynchronize(s));
 
+	mark("K9b positions");
 	// ---- public counters (blight.h:52-59, recap blight.cpp:361-378)
 	ix.total_lines = total_lines;
 	ix.total_logical_words = total_words;
