@@ -185,6 +185,45 @@ def cpu_baseline(ix, st, args_k, m, n, b, q_host, gpu_ids_host, budget_s):
     }
 
 
+def cpu_reference_calibration(sample_ascii, sample_offs, k, m, n, b, nq=2_000_000):
+    """The REAL reference (oracle/_ref: Piezoid/Blight + the three one-token fixes, compiled from /root/reference in the dev
+    container, -t 1) timed on this host next to the oracle port, both on a bounded sample of the workload: the first unitigs
+    of the same synthetic input and the same 50/50 query mix.  Calibrates the `port` numbers against the reference itself."""
+    import numpy as np
+    from oracle import oracle as O
+    if not O.ref_available() or k > 32:
+        return None
+    o = sample_offs
+    seqs = [sample_ascii[o[i]:o[i + 1]].tobytes().decode() for i in range(len(o) - 1)]
+    t = time.time()
+    ref = O.Reference(k, m, n, b, seqs)
+    t_ref_build = time.time() - t
+    t = time.time()
+    orc = O.Oracle(k, m, n, b, seqs)
+    t_orc_build = time.time() - t
+    nk = ref.stats["number_kmer"]
+    rng = np.random.default_rng(5)
+    pos = np.concatenate([orc.canonical_kmers(s) for s in seqs[: max(1, nq // 2 // 80)]])[: nq // 2]
+    neg = rng.integers(0, 1 << 62, size=nq - pos.size, dtype=np.uint64)
+    neg = np.array([min(int(x), O.p_rc(int(x), k)) for x in neg[:20000]] * ((nq - pos.size) // 20000 + 1), dtype=np.uint64)[: nq - pos.size]
+    q = np.concatenate([pos, neg])
+    q = np.ascontiguousarray(q[rng.permutation(q.size)])
+    t = time.time()
+    ids_ref = ref.query_kmers(q)
+    t_ref = time.time() - t
+    t = time.time()
+    ids_orc = orc.query_kmers(q, threads=1)
+    t_orc = time.time() - t
+    out = {"value": q.size / t_ref, "unit": "queries/s", "cores": 1, "kind": "reference",
+           "sample": "patched reference (-t 1) on the first %d unitigs (%d k-mers) of the same synthetic input, %d queries 50/50; "
+                     "index built by the reference itself in %.1f s (%.2f M k-mers/s)" % (len(seqs), nk, q.size, t_ref_build, nk / t_ref_build / 1e6),
+           "port_single_thread_same_sample": q.size / t_orc, "port_build_kmers_per_s": nk / t_orc_build,
+           "ids_equal_to_port": bool(np.array_equal(ids_ref, ids_orc))}
+    ref.close()
+    orc.close()
+    return out
+
+
 def main():
     args = parse_args()
     import torch  # first: one HIP runtime for torch and the library
@@ -223,6 +262,12 @@ def main():
     ascii_, offs, total = synth_unitigs(torch, dev, n_kmers, k, args.seed)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
+    ref_sample = None
+    if world == 1 and args.cpu_seconds > 0 and kw == 1:
+        # host copy of the first unitigs (~1.5e7 k-mers) for the reference calibration leg
+        nu = min(offs.numel() - 1, 190_000)
+        so = offs[: nu + 1].cpu().numpy()
+        ref_sample = (ascii_[: int(so[-1])].cpu().numpy(), so)
     ix = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
     if effective_mode == "sharded":
         ix.set_shard(rank, world)  # this rank keeps the MPHF groups it owns; IDs stay global
@@ -333,6 +378,10 @@ def main():
                                                    ids.cpu().numpy(), args.cpu_seconds)
             except Exception as e:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+            try:
+                out["cpu_reference"] = cpu_reference_calibration(ref_sample[0], ref_sample[1], k, m, n, b) if ref_sample else None
+            except Exception as e:
+                out["cpu_reference"] = {"value": None, "kind": "reference", "sample": "failed: %r" % (e,)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
