@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
-ABI_VERSION = 4  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
+ABI_VERSION = 5  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 _u64p = C.POINTER(C.c_uint64)
@@ -70,6 +70,9 @@ def load_library():
     lib.blmx_query_membership.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8)]
     lib.blmx_query_sequences.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _i64p]
     lib.blmx_query_file.argtypes = [C.c_void_p, C.c_char_p, _u64p, _u64p]
+    lib.blmx_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.blmx_load.argtypes = [C.c_void_p, C.c_char_p]
+    lib.blmx_peek_params.argtypes = [C.c_char_p, C.POINTER(blmx_params)]
     lib.blmx_sequence_kmer_count.argtypes = [C.c_void_p, _u64p, C.c_uint64]
     lib.blmx_sequence_kmer_count.restype = C.c_uint64
     lib.blmx_query_kmers_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -184,6 +187,25 @@ class kmer_Set_Light:
 
     def construct_index_from_device(self, d_concat_ptr, d_offsets_ptr, nseq, total_len):
         self._check(self._lib.blmx_build_from_device_sequences(self._h, d_concat_ptr, d_offsets_ptr, nseq, total_len))
+
+    # -- index image on disk (mainline Blight's dump_disk / load constructor, absent from this fork)
+    def dump_disk(self, path):
+        self._check(self._lib.blmx_save(self._h, os.fsencode(path)))
+
+    def load_disk(self, path):
+        """Fill this (unbuilt) object from an image written with the same k, m, log2_mphfs_number, bits_to_save."""
+        self._check(self._lib.blmx_load(self._h, os.fsencode(path)))
+
+    @classmethod
+    def from_file(cls, path, device=0):
+        lib = load_library()
+        p = blmx_params()
+        rc = lib.blmx_peek_params(os.fsencode(path), C.byref(p))
+        if rc:
+            _raise(rc, "not a Blight MI355X index file: %s" % path)
+        self = cls(p.k, p.m, p.log2_mphf, p.log2_superbuckets, 1, p.bits_saved, device=device, kmer_bytes=p.kmer_bytes)
+        self.load_disk(path)
+        return self
 
     # -- counters (blight.h:52-59)
     def stats(self):

@@ -309,6 +309,27 @@ int blmx_query_sequences(blmx_index* h, const char* concat, const uint64_t* offs
 	});
 }
 
+int blmx_save(blmx_index* h, const char* path)
+{
+	if (!h || !path)
+		return BLMX_EINVAL;
+	return guarded(h, [&] { save_index(h->ix, path); });
+}
+
+int blmx_load(blmx_index* h, const char* path)
+{
+	if (!h || !path)
+		return BLMX_EINVAL;
+	return guarded(h, [&] { load_index(h->ix, path); });
+}
+
+int blmx_peek_params(const char* path, blmx_params* out)
+{
+	if (!path || !out)
+		return BLMX_EINVAL;
+	return peek_index_params(path, *out);
+}
+
 int blmx_query_file(blmx_index* h, const char* path, uint64_t* good, uint64_t* erroneous)
 {
 	if (!h || !path || !good || !erroneous)

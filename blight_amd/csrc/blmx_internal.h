@@ -173,6 +173,10 @@ void launch_unpermute(const int64_t* d_vals, const uint32_t* d_order, uint64_t n
 // streaming front end (blmx_stream.hip)
 int read_fasta_records(const char* path, std::string& concat, std::vector<uint64_t>& offs);
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);
+// index image on disk (blmx_stream.hip)
+void save_index(Index& ix, const char* path);
+void load_index(Index& ix, const char* path);
+int peek_index_params(const char* path, blmx_params& out);
 void launch_primitive(int op, int KW, const void* d_in, uint64_t n, int arg, int arg2, void* d_out, hipStream_t s);
 
 }  // namespace blmx

@@ -7,6 +7,7 @@
 // comes back over PCIe.
 #include <zlib.h>
 
+#include <cstdio>
 #include <cstring>
 
 #include "blmx_internal.h"
@@ -182,6 +183,196 @@ void grow(DevBuf& b, size_t bytes, hipStream_t s)
 }
 
 }  // namespace
+
+// ---- index image on disk (the fork has no dump/load; mainline Blight's dump_disk / load constructor is the model) --
+// Layout: FileHeader, shard bounds (u32 x nbounds), fallback group tags (u32 x nfb), then the seven HBM arrays exactly as they
+// sit in device memory (padding included), each preceded by its byte count, then the end tag.  Arrays move through a pinned
+// 64 MiB bounce buffer; nothing is recomputed on load except the host mirror of the group table.
+namespace {
+
+constexpr char kImageMagic[8] = {'B', 'L', 'M', 'X', 'I', 'D', 'X', '1'};
+constexpr char kImageEnd[8] = {'B', 'L', 'M', 'X', 'E', 'N', 'D', '1'};
+constexpr uint32_t kImageVersion = 1;
+
+struct FileHeader {
+	char magic[8];
+	uint32_t version, abi, stats_bytes, group_desc_bytes;
+	uint32_t k, m, log2_mphf, log2_superbuckets, bits_saved, kmer_bytes;
+	uint32_t kw, gshift, nbuckets, ngroups, shard_rank, shard_world, nbounds, pad;
+	uint64_t nfb, positions_words, seq_words, total_lines, total_logical_words;
+	blmx_stats_t st;
+};
+
+struct File {
+	FILE* f = nullptr;
+	~File()
+	{
+		if (f)
+			fclose(f);
+	}
+};
+
+void put(FILE* f, const void* p, size_t n)
+{
+	if (n && fwrite(p, 1, n, f) != n)
+		throw StatusError{BLMX_EIO, "short write to the index file"};
+}
+void get(FILE* f, void* p, size_t n)
+{
+	if (n && fread(p, 1, n, f) != n)
+		throw StatusError{BLMX_EIO, "index file truncated"};
+}
+
+constexpr size_t kBounce = 64u << 20;
+
+void put_device(FILE* f, const DevBuf& b, Pinned& pin, hipStream_t s)
+{
+	const uint64_t bytes = b.bytes;
+	put(f, &bytes, 8);
+	for (size_t o = 0; o < bytes; o += kBounce) {
+		const size_t n = std::min(kBounce, (size_t)bytes - o);
+		BLMX_HIP(hipMemcpyAsync(pin.p, (const char*)b.p + o, n, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+		put(f, pin.p, n);
+	}
+}
+
+void get_device(FILE* f, DevBuf& b, uint64_t min_bytes, Pinned& pin, hipStream_t s)
+{
+	uint64_t bytes = 0;
+	get(f, &bytes, 8);
+	if (bytes < min_bytes || bytes > (1ull << 40))
+		throw StatusError{BLMX_EIO, "index file is inconsistent (array size)"};
+	BLMX_HIP(b.alloc(bytes, false, s));
+	for (size_t o = 0; o < bytes; o += kBounce) {
+		const size_t n = std::min(kBounce, (size_t)bytes - o);
+		get(f, pin.p, n);
+		BLMX_HIP(hipMemcpyAsync((char*)b.p + o, pin.p, n, hipMemcpyHostToDevice, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+	}
+}
+
+}  // namespace
+
+void save_index(Index& ix, const char* path)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	File fh;
+	fh.f = fopen(path, "wb");
+	if (!fh.f)
+		throw StatusError{BLMX_EIO, "Problem with files opening"};
+	FileHeader h{};
+	memcpy(h.magic, kImageMagic, 8);
+	h.version = kImageVersion;
+	h.abi = BLMX_ABI_VERSION;
+	h.stats_bytes = sizeof(blmx_stats_t);
+	h.group_desc_bytes = sizeof(GroupDesc);
+	h.k = ix.prm.k;
+	h.m = ix.prm.m;
+	h.log2_mphf = ix.prm.log2_mphf;
+	h.log2_superbuckets = ix.prm.log2_superbuckets;
+	h.bits_saved = ix.prm.bits_saved;
+	h.kmer_bytes = ix.prm.kmer_bytes;
+	h.kw = (uint32_t)ix.KW;
+	h.gshift = (uint32_t)ix.gshift;
+	h.nbuckets = ix.nbuckets;
+	h.ngroups = ix.ngroups;
+	h.shard_rank = ix.shard_rank;
+	h.shard_world = ix.shard_world;
+	h.nbounds = (uint32_t)ix.shard_bounds.size();
+	h.nfb = ix.h_fb_group.size();
+	h.positions_words = ix.positions_words;
+	h.seq_words = ix.seq_words;
+	h.total_lines = ix.total_lines;
+	h.total_logical_words = ix.total_logical_words;
+	h.st = ix.st;
+	put(fh.f, &h, sizeof h);
+	put(fh.f, ix.shard_bounds.data(), ix.shard_bounds.size() * 4);
+	put(fh.f, ix.h_fb_group.data(), ix.h_fb_group.size() * 4);
+	Pinned pin;
+	pin.ensure(kBounce);
+	for (const DevBuf* b : {&ix.buckets, &ix.groups, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks})
+		put_device(fh.f, *b, pin, ix.stream);
+	put(fh.f, kImageEnd, 8);
+	if (fflush(fh.f) != 0)
+		throw StatusError{BLMX_EIO, "short write to the index file"};
+}
+
+int peek_index_params(const char* path, blmx_params& out)
+{
+	File fh;
+	fh.f = fopen(path, "rb");
+	if (!fh.f)
+		return BLMX_EIO;
+	FileHeader h{};
+	if (fread(&h, 1, sizeof h, fh.f) != sizeof h || memcmp(h.magic, kImageMagic, 8) != 0 || h.version != kImageVersion)
+		return BLMX_EIO;
+	out = blmx_params{};
+	out.k = h.k;
+	out.m = h.m;
+	out.log2_mphf = h.log2_mphf;
+	out.log2_superbuckets = h.log2_superbuckets;
+	out.threads = 1;
+	out.bits_saved = h.bits_saved;
+	out.kmer_bytes = h.kmer_bytes;
+	return BLMX_OK;
+}
+
+void load_index(Index& ix, const char* path)
+{
+	if (ix.built)
+		throw StatusError{BLMX_ESTATE, "index already built"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	File fh;
+	fh.f = fopen(path, "rb");
+	if (!fh.f)
+		throw StatusError{BLMX_EIO, "Problem with files opening"};
+	FileHeader h{};
+	get(fh.f, &h, sizeof h);
+	if (memcmp(h.magic, kImageMagic, 8) != 0)
+		throw StatusError{BLMX_EIO, "not a Blight MI355X index file"};
+	if (h.version != kImageVersion || h.stats_bytes != sizeof(blmx_stats_t) || h.group_desc_bytes != sizeof(GroupDesc))
+		throw StatusError{BLMX_EIO, "index file written by an incompatible library version"};
+	if (h.k != ix.prm.k || h.m != ix.prm.m || h.log2_mphf != ix.prm.log2_mphf || h.bits_saved != ix.prm.bits_saved ||
+	    h.kmer_bytes != ix.prm.kmer_bytes)
+		throw StatusError{BLMX_EINVAL, "index file parameters (k, m, log2_mphf, bits_to_save, k-mer width) differ from this object's"};
+	if (h.kw != (uint32_t)ix.KW || h.gshift != (uint32_t)ix.gshift || h.nbuckets != ix.nbuckets || h.ngroups != ix.ngroups ||
+	    h.nbounds > (1u << 20) || h.nfb > (1ull << 36))
+		throw StatusError{BLMX_EIO, "index file is inconsistent (header)"};
+	hipStream_t s = ix.stream;
+	ix.shard_bounds.resize(h.nbounds);
+	get(fh.f, ix.shard_bounds.data(), (size_t)h.nbounds * 4);
+	ix.h_fb_group.resize(h.nfb);
+	get(fh.f, ix.h_fb_group.data(), (size_t)h.nfb * 4);
+	Pinned pin;
+	pin.ensure(kBounce);
+	get_device(fh.f, ix.buckets, (uint64_t)h.nbuckets * sizeof(BucketDesc), pin, s);
+	get_device(fh.f, ix.groups, (uint64_t)h.ngroups * sizeof(GroupDesc), pin, s);
+	get_device(fh.f, ix.seq, h.seq_words * 8, pin, s);
+	get_device(fh.f, ix.positions, h.positions_words * 8, pin, s);
+	get_device(fh.f, ix.lines, (h.total_lines + 1) * kLineBytes, pin, s);
+	get_device(fh.f, ix.fb_keys, (h.nfb + 1) * 8 * h.kw, pin, s);
+	get_device(fh.f, ix.fb_ranks, (h.nfb + 1) * 8, pin, s);
+	char end[8];
+	get(fh.f, end, 8);
+	if (memcmp(end, kImageEnd, 8) != 0)
+		throw StatusError{BLMX_EIO, "index file is inconsistent (end tag)"};
+	ix.h_groups.resize(h.ngroups);
+	BLMX_HIP(hipMemcpyAsync(ix.h_groups.data(), ix.groups.p, (size_t)h.ngroups * sizeof(GroupDesc), hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	ix.shard_rank = h.shard_rank;
+	ix.shard_world = h.shard_world;
+	ix.positions_words = h.positions_words;
+	ix.seq_words = h.seq_words;
+	ix.total_lines = h.total_lines;
+	ix.total_logical_words = h.total_logical_words;
+	const uint64_t nq = ix.st.number_query;
+	ix.st = h.st;
+	ix.st.number_query = nq;
+	ix.built = true;
+}
 
 // file_query: returns good / erroneous k-mer counts (the reference prints them: "Good kmer", "Erroneous kmers").
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous)

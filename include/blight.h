@@ -104,6 +104,15 @@ public:
 		}
 	}
 
+	// Index image on disk.  Absent from this fork of the reference; named after mainline Blight's pair.
+	// load() needs an object constructed with the parameters the image was written with (std::invalid_argument otherwise).
+	void dump_disk(const std::string& output_file) { check(blmx_save(_h, output_file.c_str())); }
+	void load(const std::string& index_file)
+	{
+		check(blmx_load(_h, index_file.c_str()));
+		refresh();
+	}
+
 	// blight.cpp:545-550
 	int64_t query_kmer_hash(kmer_t canon)
 	{

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
  * so a stale caller binary is detected instead of corrupting memory. */
-#define BLMX_ABI_VERSION 4
+#define BLMX_ABI_VERSION 5
 
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
@@ -115,6 +115,15 @@ int blmx_query_sequences(blmx_index* ix, const char* concat, const uint64_t* off
  * GPU in pinned double-buffered batches (parse | H2D | kernels | 16-byte D2H overlap), skips sequences shorter than k
  * (blight.cpp:782) and returns the recap counters "Good kmer" / "Erroneous kmers".  Only the two counters cross PCIe back. */
 int blmx_query_file(blmx_index* ix, const char* path, uint64_t* good_out, uint64_t* erroneous_out);
+/* Index image on disk.  This fork of the reference cannot persist an index (README: "no dump/load"); mainline
+ * Blight's dump_disk(file) / kmer_Set_Light(file) pair is the model.  blmx_save writes the finished HBM arrays verbatim
+ * (buckets, group table, 2-bit sequences, positions, MPHF lines, fallback table) behind a header carrying the parameters
+ * and public counters; blmx_load fills an index created with the SAME (k, m, log2_mphf, bits_saved, kmer_bytes) -- any
+ * difference is BLMX_EINVAL -- and leaves it in the built state; a truncated or foreign file is BLMX_EIO.
+ * blmx_peek_params reads just the parameters, so that a caller can blmx_create the right object first. */
+int blmx_save(blmx_index* ix, const char* path);
+int blmx_load(blmx_index* ix, const char* path);
+int blmx_peek_params(const char* path, blmx_params* out);
 /* number of IDs blmx_query_sequences writes for these offsets */
 uint64_t blmx_sequence_kmer_count(const blmx_index* ix, const uint64_t* offsets, uint64_t nseq);
 

@@ -46,6 +46,18 @@ def test_ctor_validation_messages():
             blight_amd.kmer_Set_Light(k, m, n, s, t, b, kmer_bytes=kb)
 
 
+def test_peek_params_rejects_foreign_files(tmp_path):
+    import blight_amd
+    lib = blight_amd.load_library()
+    p = blight_amd.blmx_params()
+    assert lib.blmx_peek_params(os.fsencode(str(tmp_path / "missing.blmx")), C.byref(p)) == blight_amd.BLMX_EIO
+    bogus = tmp_path / "bogus.blmx"
+    bogus.write_bytes(b">seq\nACGT\n" * 100)
+    assert lib.blmx_peek_params(os.fsencode(str(bogus)), C.byref(p)) == blight_amd.BLMX_EIO
+    with pytest.raises(OSError):
+        blight_amd.kmer_Set_Light.from_file(str(bogus))
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU the product must fail loudly (BLMX_EHIP), never compute on the host."""
     if os.path.exists("/dev/kfd"):

@@ -257,3 +257,40 @@ def test_both_mphf_build_paths(B, O, monkeypatch):
     assert 0 < st["mphf_groups_lds_built"] < int((nk > 0).sum()), (st["mphf_groups_lds_built"], nk.tolist())
     _check_against_oracle_arrays(ix, orc)
     assert np.array_equal(ix.query_sequences_hash(seqs[:500]), np.concatenate([orc.query_sequence(s) for s in seqs[:500]]))
+
+
+@pytest.mark.parametrize("k,m,n,b,kb", [(31, 9, 7, 6, 8), (63, 9, 7, 8, 16)])
+def test_index_image_round_trip(B, O, tmp_path, k, m, n, b, kb):
+    """dump_disk -> load into a fresh object (and from_file): every exported array, every counter and every answer is
+    identical; wrong parameters, truncated and foreign files are refused with the documented errors."""
+    rng = np.random.default_rng(k)
+    seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 60))) for _ in range(1500)] + [_rand_seq(rng, k + 40, "AC") for _ in range(20)]
+    a = _build(B, k, m, n, b, seqs, kmer_bytes=kb)
+    path = str(tmp_path / "index.blmx")
+    a.dump_disk(path)
+    c = B.kmer_Set_Light.from_file(path)
+    d = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+    d.load_disk(path)
+    for other in (c, d):
+        for key in B.EXPORT:
+            assert np.array_equal(a.export(key), other.export(key)), key
+        sa, so = a.stats(), other.stats()
+        sa.pop("number_query"), so.pop("number_query")
+        assert sa == so
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    q = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs[:400]]).reshape(-1)
+    want = orc.query_kmers(q if kb == 8 else q.reshape(-1, 2))
+    assert np.array_equal(c.query_kmer_hash(q), want) and np.array_equal(d.query_kmer_hash(q), want)
+    assert np.array_equal(c.query_sequence_hash(seqs[0]), orc.query_sequence(seqs[0]))
+    # refusals
+    with pytest.raises(ValueError):
+        B.kmer_Set_Light(k, m, n - 1, min(n - 1, 3), 1, b, kmer_bytes=kb).load_disk(path)
+    with pytest.raises(B.BlightError):
+        d.load_disk(path)  # already built
+    raw = open(path, "rb").read()
+    cut = str(tmp_path / "cut.blmx")
+    open(cut, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(OSError):
+        B.kmer_Set_Light.from_file(cut)
+    with pytest.raises(OSError):
+        B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb).load_disk(str(tmp_path / "nope.blmx"))

@@ -16,9 +16,9 @@ using namespace std;
 int main(int argc, char** argv)
 {
 	int ch;
-	string input, query;
+	string input, query, dump, load;
 	uint k(31), m1(9), m2(17), m3(6), c(1), bit(6);
-	while ((ch = getopt(argc, argv, "g:q:k:m:n:s:t:b:")) != -1) {
+	while ((ch = getopt(argc, argv, "g:q:k:m:n:s:t:b:d:l:")) != -1) {
 		switch (ch) {
 		case 'q': query = optarg; break;
 		case 'g': input = optarg; break;
@@ -28,6 +28,8 @@ int main(int argc, char** argv)
 		case 's': m3 = stoi(optarg); break;
 		case 't': c = stoi(optarg); break;
 		case 'b': bit = stoi(optarg); break;
+		case 'd': dump = optarg; break;  // extension: write the index image after construction
+		case 'l': load = optarg; break;  // extension: load an index image instead of constructing
 		}
 	}
 	if (query == "" and input != "")
@@ -45,6 +47,8 @@ int main(int argc, char** argv)
 		     << "\t-n to create 2^n mphf (2^" << m2 << "=" << (1u << m2) << "). More mean slower construction but better index, must be <=2*m-1" << endl
 		     << "\t-s to use 2^s files (2^" << m3 << "=" << (1u << m3) << "). Accepted for compatibility (no temp files are used), must be <=n" << endl
 		     << "\t-t core used (" << c << "). Accepted for compatibility (the GPU path has no host threads)" << endl
+		     << "\t-d file: also write the index image (extension)" << endl
+		     << "\t-l file: load an index image written with the same -k -m -n -b instead of building from -g (extension)" << endl
 		     << "\t-b bit saved to encode positions (" << bit << "). Will reduce the memory usage of b bit per kmer but query have to check 2^b kmers" << endl;
 		return 0;
 	}
@@ -53,7 +57,12 @@ int main(int argc, char** argv)
 		            " -t " + to_string(c) + " -b " + to_string(bit)
 		     << endl;
 		kmer_Set_Light ksl(k, m1, m2, m3, c, bit);
-		ksl.construct_index(input);
+		if (load != "")
+			ksl.load(load);
+		else
+			ksl.construct_index(input);
+		if (dump != "")
+			ksl.dump_disk(dump);
 		ksl.file_query(query);
 		cout << "I am glad you are here with me. Here at the end of all things." << endl;
 	} catch (const std::exception& e) {
