@@ -27,19 +27,12 @@ namespace blmx {
 // A step = mask + xor/or compare against x and rc(x) + one v_min3; no exec-mask juggling, no branches.
 // ID / membership mode: returns 0 on any match, -1 otherwise (the ID does not depend on WHICH position matched,
 // blight.cpp:736).  WANT_POS: returns the index j of the FIRST match in [0, 2^LOGP) (blight.cpp:706) or -1.
-template <int KW, int LOGP, bool WANT_POS>
-__device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uint64_t g0, int k, Kmer<KW> x, Kmer<KW> xr)
+template <int KW, int LOGP, bool WANT_POS, int NW>
+__device__ __forceinline__ int scan_window_exact(const uint64_t (&W)[NW], int s0, int k, Kmer<KW> x, Kmer<KW> xr)
 {
 	constexpr int P = 1 << LOGP;
 	constexpr int NSEG = (P + 31) / 32;  // 32-step segments, one pre-aligned stream word each
-	constexpr int NW = KW + NSEG + 1;
 	constexpr int NWORD = 2 * KW;
-	const uint64_t w0 = g0 >> 5;
-	const int s0 = (int)(g0 & 31);
-	uint64_t W[NW];
-#pragma unroll
-	for (int i = 0; i < NW; i++)
-		W[i] = seq[w0 + i];
 	// top-aligned window and query words, most significant first
 	uint32_t c[NWORD], X[NWORD], XR[NWORD], M[NWORD];
 	const int sh = 64 * KW - 2 * k;  // insignificant low bits of the top-aligned window
@@ -122,6 +115,110 @@ __device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uin
 		return first == 0x7fffffff ? -1 : first;
 	else
 		return acc == 0 ? 0 : -1;
+}
+
+// The k-mer at nucleotide offset T of the register window W (T < 32 * (NW - KW)): the two or three words are picked with
+// compares against the (lane-varying) word index, then shifted like packed_kmer.
+template <int KW, int NW> __device__ __forceinline__ Kmer<KW> window_kmer(const uint64_t (&W)[NW], int T, int k)
+{
+	const int wi = T >> 5, sb = 2 * (T & 31);
+	uint64_t a = 0, b = 0, c = 0;
+#pragma unroll
+	for (int i = 0; i + KW < NW; i++) {
+		if (wi == i) {
+			a = W[i];
+			b = W[i + 1];
+			if constexpr (KW == 2)
+				c = W[i + 2];
+		}
+	}
+	Kmer<KW> r;
+	if constexpr (KW == 1) {
+		r.lo = funnel_left(a, b, sb) >> (64 - 2 * k);
+	} else {
+		const uint64_t v0 = funnel_left(a, b, sb), v1 = funnel_left(b, c, sb);
+		const int sh = 128 - 2 * k;
+		if (sh >= 64) {
+			r.lo = v0 >> (sh - 64);
+			r.hi = 0;
+		} else {
+			r.lo = (v1 >> sh) | (v0 << (64 - sh));
+			r.hi = v0 >> sh;
+		}
+	}
+	return r;
+}
+
+// The scan as the query kernel runs it: a FILTER on the 16 leading nucleotides, then one exact comparison.
+// A stored k-mer can equal x or rc(x) only if its top 32 bits equal theirs, so every step is: one v_alignbit with a
+// compile-time shift (the lane's stream is pre-aligned once per 32-step segment), two v_cmp_eq, one v_cndmask -- 4 VALU
+// instead of the 12 of the exact step, and no serial dependency between steps.  Steps run downwards inside a segment so
+// that "candidate = this step" needs no min.  The first candidate (smallest step) is then compared exactly in registers;
+// it is the first full match unless the filter was hit by a different k-mer with the same 16-nucleotide prefix
+// (~2^-32 per step on random data, common in repeats): only then the exact scan above runs.  k < 16 (top word not fully
+// significant) always takes the exact scan.
+template <int KW, int LOGP, bool WANT_POS>
+__device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uint64_t g0, int k, Kmer<KW> x, Kmer<KW> xr)
+{
+	constexpr int P = 1 << LOGP;
+	constexpr int NSEG = (P + 31) / 32;
+	constexpr int NW = KW + NSEG + 1;
+	constexpr int kNone = 0x7fffffff;
+	const uint64_t w0 = g0 >> 5;
+	const int s0 = (int)(g0 & 31);
+	uint64_t W[NW];
+#pragma unroll
+	for (int i = 0; i < NW; i++)
+		W[i] = seq[w0 + i];
+	if (k >= 16) {
+	uint32_t X0, XR0;  // top 32 bits of the top-aligned queries
+	if constexpr (KW == 1) {
+		const int sh = 64 - 2 * k;
+		X0 = (uint32_t)((x.lo << sh) >> 32);
+		XR0 = (uint32_t)((xr.lo << sh) >> 32);
+	} else {
+		const int sh = 128 - 2 * k;
+		uint64_t xh, xrh;
+		if (sh >= 64) {
+			xh = x.lo << (sh - 64);
+			xrh = xr.lo << (sh - 64);
+		} else {
+			xh = (x.hi << sh) | (sh ? (x.lo >> (64 - sh)) : 0ull);
+			xrh = (xr.hi << sh) | (sh ? (xr.lo >> (64 - sh)) : 0ull);
+		}
+		X0 = (uint32_t)(xh >> 32);
+		XR0 = (uint32_t)(xrh >> 32);
+	}
+	int first = kNone;
+	uint64_t sw = funnel_left(W[0], W[1], 2 * s0);
+#pragma unroll
+	for (int r = 0; r < NSEG; r++) {
+		const uint64_t swn = funnel_left(W[r + 1], W[r + 2], 2 * s0);
+		const uint32_t A0 = (uint32_t)(sw >> 32), A1 = (uint32_t)sw, A2 = (uint32_t)(swn >> 32);
+		constexpr int kSteps = P < 32 ? P : 32;
+		int f = kNone;
+#pragma unroll
+		for (int t = kSteps - 1; t >= 0; t--) {
+			const uint32_t hi = t < 16 ? A0 : A1, lo = t < 16 ? A1 : A2;
+			const int sft = 2 * (t & 15);
+			const uint32_t c0 = sft == 0 ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - sft);
+			f = ((c0 == X0) | (c0 == XR0)) ? 32 * r + t : f;
+		}
+		first = min(first, f);
+		sw = swn;
+		// all lanes of the wave that are scanning have a candidate: stop (self-queries end after the first segments)
+		if constexpr (NSEG > 1) {
+			if (__all(first != kNone))
+				break;
+		}
+	}
+	if (first == kNone)
+		return -1;
+	const Kmer<KW> cand = window_kmer<KW, NW>(W, s0 + first, k);
+	if (cand == x || cand == xr)
+		return first;
+	}
+	return scan_window_exact<KW, LOGP, WANT_POS, NW>(W, s0, k, x, xr);
 }
 
 template <int KW, int LOGP, bool WANT_POS>

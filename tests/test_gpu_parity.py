@@ -294,3 +294,52 @@ def test_index_image_round_trip(B, O, tmp_path, k, m, n, b, kb):
         B.kmer_Set_Light.from_file(cut)
     with pytest.raises(OSError):
         B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb).load_disk(str(tmp_path / "nope.blmx"))
+
+
+@pytest.mark.parametrize("k,kb,b", [(31, 8, 6), (63, 16, 8), (21, 8, 3)])
+def test_scan_filter_false_candidates(B, O, k, kb, b):
+    """The query kernel scans the 2^b window with a filter on the 16 leading nucleotides and verifies the first candidate
+    exactly; a DIFFERENT k-mer with the same 16-nt prefix earlier in the window must send it to the exact scan.  The data
+    plants such pairs (a unit repeated after p nucleotides with a mutation behind the shared prefix); the test first
+    proves from the exported index that false candidates really precede matches, then compares with the oracle."""
+    rng = np.random.default_rng(100 + k)
+    m, n = 9, 7
+    seqs = []
+    for _ in range(600):
+        if (1 << b) > 27:
+            p = int(rng.integers(17, 28))          # distance between the two copies
+            u = _rand_seq(rng, p)
+            v = list(u)
+            mut = int(rng.integers(16, p)) if p > 16 else 16
+            v[mut % p] = "ACGT"[("ACGT".index(v[mut % p]) + 1 + int(rng.integers(0, 3))) % 4]
+            core = u + "".join(v)
+        else:                                      # small windows: a short period, k-mers p apart share k-2 nucleotides
+            p = int(rng.integers(2, 1 << b))
+            core = (_rand_seq(rng, p) * k)[: k - 2 + p]
+        seqs.append(_rand_seq(rng, int(rng.integers(0, 40))) + core + _rand_seq(rng, k + int(rng.integers(0, 30))))
+    ix = _build(B, k, m, n, b, seqs, kmer_bytes=kb)
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    q = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
+    ids = ix.query_kmer_hash(q.reshape(-1))
+    assert np.array_equal(ids, orc.query_kmers(q.reshape(-1) if kb == 8 else q))
+    assert (ids >= 0).all()
+    # positions (first match in the window) through the same scan
+    ints = O.array_to_kmers(q, kb)
+    minis = np.array([O.p_minimizer(x, k, m, kb) for x in ints], dtype=np.uint32)
+    pos = ix.query_get_pos_unitig(q.reshape(-1), minis)
+    assert np.array_equal(pos.astype(np.int64), orc.query_kmers_mini(q.reshape(-1) if kb == 8 else q, minis, want_pos=True))
+    # proof that the filter met false candidates: decode the bucket sequences and look at the windows
+    words = ix.export("seq")
+    nts = ((words[:, None] >> np.arange(62, -2, -2, dtype=np.uint64)[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)
+    bstart = ix.export("bucket_start")
+    P = 1 << b
+    false_first = 0
+    for i in range(0, len(pos), 7 if P > 16 else 1):
+        g = int(bstart[minis[i]]) + int(pos[i])
+        w = g - (int(pos[i]) & (P - 1))
+        tgt = nts[g:g + 16]
+        for j in range(w, g):
+            if np.array_equal(nts[j:j + 16], tgt):
+                false_first += 1
+                break
+    assert false_first > 0
