@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=4)
+    ap.add_argument("--present", type=float, default=0.5, help="fraction of the queries that are indexed k-mers (headline: 0.5)")
     return ap.parse_args()
 
 
@@ -93,24 +94,25 @@ def synth_unitigs(torch, dev, n_kmers, k, seed):
     return ascii_, offs, total
 
 
-def synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, seed, kmer_words):
-    """50 % indexed k-mers (uniform over positions), 50 % uniform random k-mers, shuffled; canonical, in HBM."""
+def synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, seed, kmer_words, present=0.5):
+    """`present` (default 50 %) indexed k-mers (uniform over positions), the rest uniform random k-mers, shuffled;
+    canonical, in HBM."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    npos = nq // 2
-    p = torch.randint(0, total, (npos,), device=dev, dtype=torch.int64, generator=g)
+    npos = int(nq * present)
+    p = torch.randint(0, total, (max(npos, 1),), device=dev, dtype=torch.int64, generator=g)
     u = torch.searchsorted(offs, p, right=True) - 1
     p = torch.minimum(p, offs[u + 1] - k)
     q = torch.empty((nq, kmer_words), device=dev, dtype=torch.int64)
-    pos_k = torch.empty((npos, kmer_words), device=dev, dtype=torch.int64)
+    pos_k = torch.empty((max(npos, 1), kmer_words), device=dev, dtype=torch.int64)
     err = torch.zeros(1, device=dev, dtype=torch.int32)
-    ix.kmers_at_device(ascii_.data_ptr(), p.data_ptr(), npos, pos_k.data_ptr(), err.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    neg = torch.randint(-(1 << 63), (1 << 63) - 1, (nq - npos, kmer_words), device=dev, dtype=torch.int64, generator=g)
-    ix.canonicalize_device(neg.data_ptr(), nq - npos, torch.cuda.current_stream().cuda_stream)
+    ix.kmers_at_device(ascii_.data_ptr(), p.data_ptr(), max(npos, 1), pos_k.data_ptr(), err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    neg = torch.randint(-(1 << 63), (1 << 63) - 1, (max(nq - npos, 1), kmer_words), device=dev, dtype=torch.int64, generator=g)
+    ix.canonicalize_device(neg.data_ptr(), max(nq - npos, 1), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert int(err.item()) == 0
-    q[:npos] = pos_k
-    q[npos:] = neg
+    q[:npos] = pos_k[:npos]
+    q[npos:] = neg[: nq - npos]
     perm = torch.randperm(nq, device=dev, generator=g)
     # shuffle word column by word column on contiguous 1-D tensors (a 2-D row gather of a (1e8, 2) int64 tensor returned
     # wrong rows on this torch/ROCm build; the 1-D gather is the well-trodden path)
@@ -281,7 +283,7 @@ def main():
             st["number_kmer"] / t_build / 1e6))
 
     # ---- queries (per rank, resident in HBM)
-    q, is_pos = synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank, kw)
+    q, is_pos = synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank, kw, args.present)
     ids = torch.empty(nq, device=dev, dtype=torch.int64)
     torch.cuda.synchronize()
 
@@ -362,7 +364,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if kw == 1 else "u128", "data": "synthetic",
             "config": {"workload": "%s: %d indexed %d-mers (seeded synthetic unitigs, k%d m%d n%d b%d), %d queries/step/GPU, "
-                                   "50%% indexed / 50%% random" % (args.workload, st["number_kmer"], k, k, m, n, b, nq),
+                                   "%g%% indexed / %g%% random" % (args.workload, st["number_kmer"], k, k, m, n, b, nq,
+                                                                    100 * args.present, 100 * (1 - args.present)),
                        "parallelism": "1 GPU" if world == 1 else ("%s x%d" % (effective_mode, world)),
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
                        "build_kmers_per_sec": st["number_kmer"] / t_build},

@@ -119,7 +119,7 @@ struct Index {
 	// staging for host-buffer queries
 	DevBuf q_in, q_aux, q_out;
 	// scratch of the locality-binned batch query (grow-only; guarded by bin_mu)
-	DevBuf b_bins, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp;
+	DevBuf b_bins, b_minis, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp;
 	std::mutex bin_mu;
 	hipEvent_t bin_done = nullptr;       // recorded after each binned pipeline: a call on another stream waits for it
 	hipStream_t bin_last_stream = nullptr;
@@ -153,7 +153,7 @@ void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs
 
 // query (blmx_query.hip).  mode: 0 = IDs (query_kmer_hash / query_get_hash), 1 = positions (query_get_pos_unitig),
 // 2 = membership byte.  d_minis == nullptr -> minimizers are computed on the device.
-enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2 };
+enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2, kQueryXcdMajor = 0x100 /* flag: XCD-major block order */ };
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
                   hipStream_t s, const uint32_t* d_out_index = nullptr);
 // Large batches: partition the queries by the top bits of their minimizer first (one counting pass), run the query

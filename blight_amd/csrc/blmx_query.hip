@@ -226,7 +226,14 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
                                                const uint32_t* __restrict__ minis, uint64_t nq, void* __restrict__ out,
                                                int mode, const uint32_t* __restrict__ oidx)
 {
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	// kQueryXcdMajor (batch partitioned by minimizer): workgroup b runs on XCD b % 8, each XCD has its own L2.  Give XCD x
+	// the x-th contiguous eighth of the batch, so that one bin's slice of the index is cached by ONE L2 instead of being
+	// fetched into all eight (the grid is a multiple of 8).
+	uint32_t blk = blockIdx.x;
+	if (mode & kQueryXcdMajor)
+		blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+	mode &= 0xff;
+	const uint64_t i = (uint64_t)blk * blockDim.x + threadIdx.x;
 	if (i >= nq)
 		return;
 	const Kmer<KW> x = load_kmer<KW>(kmers, i);
@@ -572,10 +579,14 @@ static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t
 {
 	const DeviceIndexView v = ix.view();
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
-	const unsigned grid = grid_for(nq, 256);
+	unsigned grid = grid_for(nq, 256);
+	if ((mode & kQueryXcdMajor) && v.b <= 8)
+		grid = (grid + 7u) & ~7u;
+	else
+		mode &= 0xff;
 #define BLMX_Q(LP)                                                                                  \
 	case LP:                                                                                        \
-		if (mode == (int)kQueryPos)                                                                 \
+		if ((mode & 0xff) == (int)kQueryPos)                                                        \
 			hipLaunchKernelGGL((k_query<KW, LP, true>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode, d_oidx);  \
 		else                                                                                        \
 			hipLaunchKernelGGL((k_query<KW, LP, false>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode, d_oidx); \
@@ -616,14 +627,14 @@ void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis,
 // work on the same ~1/1024 slice of the index, which L2 / Infinity Cache then serve: measured 13.4 -> 7.2 ms per 1e8
 // queries on the human-scale index.  One LSD counting pass (per-block LDS histograms, bin-major scan, scatter); the
 // IDs are gathered back through the inverse permutation, whose 1024 streams are each (nearly) sequential.
-constexpr int kBinThreads = 1024;  // 16 waves per CU: the scatter holds 92 KB of LDS, so one block per CU
+constexpr int kBinThreads = 1024;  // 16 waves per CU: the scatter holds 108 KB of LDS, so one block per CU
 constexpr int kBinBitsMax = 10;
 // queries per block in the partition passes: the scatter stages a whole tile (k-mers + bin ids) in LDS
 template <int KW> struct BinTile { static constexpr int value = 8192 / KW; };
 
 template <int KW>
 __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, int bin_shift, uint32_t nbins, const uint64_t* __restrict__ kmers,
-                                                          uint64_t nq, uint16_t* __restrict__ binbuf, uint32_t* __restrict__ hist, uint32_t nblk)
+                                                          uint64_t nq, uint32_t* __restrict__ minibuf, uint32_t* __restrict__ hist, uint32_t nblk)
 {
 	constexpr int kTile = BinTile<KW>::value;
 	__shared__ uint32_t s_hist[1 << kBinBitsMax];
@@ -635,9 +646,9 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, int bin_
 		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
 		if (i < nq) {
 			const Kmer<KW> x = load_kmer<KW>(kmers, i);
-			const uint32_t bin = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m) >> bin_shift;
-			binbuf[i] = (uint16_t)bin;
-			atomicAdd(&s_hist[bin], 1u);
+			const uint32_t mini = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m);
+			minibuf[i] = mini;  // travels with the k-mer to the query kernel: the 23 m-mer hashes are paid once
+			atomicAdd(&s_hist[mini >> bin_shift], 1u);
 		}
 	}
 	__syncthreads();
@@ -649,14 +660,15 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, int bin_
 // each (tile, bin) run is written as consecutive 8-B elements (64-128 B per run) instead of isolated 8-B stores
 // (measured: isolated stores wrote 2.8x the payload to HBM).  inv[i] = final position of query i (coalesced by i).
 template <int KW>
-__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __restrict__ kmers, uint64_t nq, const uint16_t* __restrict__ binbuf,
-                                                             const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t nblk,
-                                                             uint32_t nbins, uint64_t* __restrict__ sorted, uint32_t* __restrict__ inv)
+__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __restrict__ kmers, uint64_t nq, const uint32_t* __restrict__ minibuf,
+                                                             int bin_shift, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
+                                                             uint32_t nblk, uint32_t nbins, uint64_t* __restrict__ sorted,
+                                                             uint32_t* __restrict__ sorted_minis, uint32_t* __restrict__ inv)
 {
 	constexpr int kTile = BinTile<KW>::value;
 	constexpr int kNB = 1 << kBinBitsMax;
 	__shared__ uint64_t s_keys[kTile * KW];
-	__shared__ uint16_t s_bin[kTile];
+	__shared__ uint32_t s_mini[kTile];
 	__shared__ uint32_t s_lstart[kNB];  // first slot of each bin inside the tile
 	__shared__ uint32_t s_cur[kNB];
 	__shared__ uint32_t s_gstart[kNB];  // first global slot of this tile's run of each bin
@@ -688,7 +700,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 	for (int it = 0; it < kTile / kBinThreads; it++) {
 		const uint64_t i = base + (uint64_t)it * kBinThreads + t;
 		if (i < nq) {
-			const uint32_t b = binbuf[i];
+			const uint32_t mini = minibuf[i];
+			const uint32_t b = mini >> bin_shift;
 			const uint32_t r = atomicAdd(&s_cur[b], 1u);
 			if constexpr (KW == 1) {
 				s_keys[r] = kmers[i];
@@ -696,15 +709,18 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 				s_keys[2 * r] = kmers[2 * i];
 				s_keys[2 * r + 1] = kmers[2 * i + 1];
 			}
-			s_bin[r] = (uint16_t)b;
+			s_mini[r] = mini;
 			inv[i] = s_gstart[b] + (r - s_lstart[b]);
 		}
 	}
 	__syncthreads();
 	const uint32_t count = (uint32_t)min((uint64_t)kTile, nq - base);
 	for (uint32_t sidx = t; sidx < count; sidx += kBinThreads) {
-		const uint32_t b = s_bin[sidx];
+		const uint32_t mini = s_mini[sidx];
+		const uint32_t b = mini >> bin_shift;
 		const uint64_t dst = (uint64_t)s_gstart[b] + (sidx - s_lstart[b]);
+		if (sorted_minis)
+			sorted_minis[dst] = mini;
 		if constexpr (KW == 1) {
 			sorted[dst] = s_keys[sidx];
 		} else {
@@ -765,7 +781,16 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
 	const uint32_t nblk = (uint32_t)((nq + tile - 1) / tile);
 	const size_t nh = (size_t)nbins * nblk;
-	ensure_buf(ix.b_bins, nq * 2, s);
+	ensure_buf(ix.b_bins, nq * 4, s);
+	// hand the minimizers over to the query kernel?  (env BLIGHT_MINI_HANDOFF=0/1 overrides)
+	static const int env_handoff = [] {
+		const char* e = getenv("BLIGHT_MINI_HANDOFF");
+		return e ? atoi(e) : -1;
+	}();
+	const bool handoff = env_handoff >= 0 ? env_handoff != 0 : ix.KW == 2;
+	if (handoff)
+		ensure_buf(ix.b_minis, nq * 4, s);
+	uint32_t* d_sorted_minis = handoff ? ix.b_minis.as<uint32_t>() : nullptr;
 	ensure_buf(ix.b_sorted, nq * 8 * (size_t)ix.KW, s);
 	ensure_buf(ix.b_inv, nq * 4, s);
 	ensure_buf(ix.b_ids, nq * 8, s);
@@ -774,27 +799,27 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	if (ix.KW == 1)
 		hipLaunchKernelGGL((k_bin_hist<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bin_shift, nbins, km, nq,
-		                   ix.b_bins.as<uint16_t>(), ix.b_hist.as<uint32_t>(), nblk);
+		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
 	else
 		hipLaunchKernelGGL((k_bin_hist<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bin_shift, nbins, km, nq,
-		                   ix.b_bins.as<uint16_t>(), ix.b_hist.as<uint32_t>(), nblk);
+		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
 	BLMX_HIP(hipGetLastError());
 	size_t bytes = 0;
 	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
 	ensure_buf(ix.b_tmp, bytes, s);
 	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
 	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint16_t>(), ix.b_hist.as<uint32_t>(),
-		                   ix.b_offs.as<uint32_t>(), nblk,
-		                   nbins, ix.b_sorted.as<uint64_t>(), ix.b_inv.as<uint32_t>());
+		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), bin_shift,
+		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, ix.b_sorted.as<uint64_t>(), d_sorted_minis,
+		                   ix.b_inv.as<uint32_t>());
 	else
-		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint16_t>(), ix.b_hist.as<uint32_t>(),
-		                   ix.b_offs.as<uint32_t>(), nblk,
-		                   nbins, ix.b_sorted.as<uint64_t>(), ix.b_inv.as<uint32_t>());
+		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), bin_shift,
+		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, ix.b_sorted.as<uint64_t>(), d_sorted_minis,
+		                   ix.b_inv.as<uint32_t>());
 	BLMX_HIP(hipGetLastError());
 	// (storing each ID straight into the caller's slot from k_query was measured 2.8 ms SLOWER per 1e8 queries than this
 	// separate gather: 1e8 scattered 8-B stores cost more than reading the IDs back through the inverse permutation)
-	launch_query(ix, ix.b_sorted.p, nullptr, nq, ix.b_ids.p, kQueryIds, s);
+	launch_query(ix, ix.b_sorted.p, d_sorted_minis, nq, ix.b_ids.p, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
 	if (ix.KW == 1)
 		hipLaunchKernelGGL((k_gather_ids<BinTile<1>::value>), dim3(nblk), dim3(kBinThreads), 0, s, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq,
 		                   d_out);
