@@ -51,6 +51,16 @@ __device__ __forceinline__ int32_t revhash32(uint32_t x)
 	return (int32_t)x;
 }
 
+// Inverse permutation of revhash32: x ^= x >> 16 is an involution, the multipliers are inverted modulo 2^32
+// (0x297a2d39 * 0x0cf0b109 = 0x2c1b3c6d * 0x64ea2d65 = 1 mod 2^32).
+__device__ __forceinline__ uint32_t unrevhash32(uint32_t x)
+{
+	x = ((x >> 16) ^ x) * 0x0cf0b109u;
+	x = ((x >> 16) ^ x) * 0x64ea2d65u;
+	x = ((x >> 16) ^ x);
+	return x;
+}
+
 // Reverse all 32 2-bit digits of a u64 and complement each (XOR 0b10): v_bfrev + pair swap instead of the byte-swap
 // ladder of rcb(), kmer.h:218-232 -- same function.
 __device__ __forceinline__ uint64_t rc_digits64(uint64_t x)
@@ -97,22 +107,18 @@ __device__ __forceinline__ uint32_t kmer_shr32(Kmer<2> x, int s)
 // (revhash is a bijection), so the scan order is irrelevant.
 template <int KW> __device__ __forceinline__ uint32_t kmer_minimizer(Kmer<KW> x, Kmer<KW> xr, int k, int m)
 {
+	// Only the smallest hash is tracked (one v_min_i32 per m-mer); revhash is a bijection on 32 bits, so the m-mer it
+	// belongs to is recovered once at the end with the inverse permutation instead of being carried through the loop.
 	const uint32_t mask = (m >= 16) ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+	const uint32_t cmask = mask >> 1;
 	const int w = k - m;
-	uint32_t f = kmer_shr32(x, 0) & mask, r = kmer_shr32(xr, 2 * w) & mask;
-	uint32_t best = ((__popc(f) & 1) ? f : r) >> 1;
-	int32_t best_h = revhash32(best);
-	for (int i = 1; i <= w; i++) {
-		f = kmer_shr32(x, 2 * i) & mask;
-		r = kmer_shr32(xr, 2 * (w - i)) & mask;
-		const uint32_t c = ((__popc(f) & 1) ? f : r) >> 1;
-		const int32_t h = revhash32(c);
-		if (h < best_h) {
-			best_h = h;
-			best = c;
-		}
+	int32_t best_h = 0x7fffffff;
+	for (int i = 0; i <= w; i++) {
+		const uint32_t f = kmer_shr32(x, 2 * i), r = kmer_shr32(xr, 2 * (w - i));
+		const uint32_t c = (((__popc(f & mask) & 1) ? f : r) >> 1) & cmask;
+		best_h = min(best_h, revhash32(c));
 	}
-	return best;
+	return unrevhash32((uint32_t)best_h);
 }
 
 // ---- 2-bit packed sequences: nt p lives in bits 63-2(p%32) .. 62-2(p%32) of word p/32 (first nt most significant) ----
