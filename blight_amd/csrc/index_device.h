@@ -1,5 +1,7 @@
 // index_device.h -- device-side accessors of the finished index shared by the build (fill_positions) and query kernels.
 #pragma once
+#include <cstddef>
+
 #include "blmx_internal.h"
 
 namespace blmx {
@@ -23,18 +25,19 @@ template <> __device__ __forceinline__ Kmer<2> load_kmer<2>(const uint64_t* __re
 // One BBHash probe = ONE 16-B load: a line holds [u32 rank | 96 level bits], so the rank costs no second memory access.
 // Logical bit b of the group's level array lives in line (b>>5)/3, data word (b>>5)%3, bit b&31.
 // Returns true and sets `rank` when the bit is set (level_finder_tmp + bitVector::rank, bbhash.h:617-663, 467-480).
+__device__ __forceinline__ bool mphf_probe_line(const uint4 L, uint32_t slot, uint32_t bi, uint64_t& rank)
+{
+	// select without control flow so that the load stays one dwordx4
+	const uint32_t word = (slot == 0 ? L.y : 0u) | (slot == 1 ? L.z : 0u) | (slot == 2 ? L.w : 0u);
+	const uint32_t before = (slot > 0 ? __popc(L.y) : 0) + (slot > 1 ? __popc(L.z) : 0);
+	rank = (uint64_t)(L.x + before + __popc(word & ((1u << bi) - 1u)));
+	return (word >> bi) & 1u;
+}
 __device__ __forceinline__ bool mphf_probe(const uint4* __restrict__ lines, uint64_t bit, uint64_t& rank)
 {
 	const uint32_t w32 = (uint32_t)(bit >> 5);  // a group's level array is < 2^37 bits (checked at build time)
 	const uint32_t line = w32 / kLineData32;
-	const uint32_t slot = w32 - line * kLineData32;
-	const uint4 L = lines[line];
-	// select without control flow so that the load stays one dwordx4
-	const uint32_t word = (slot == 0 ? L.y : 0u) | (slot == 1 ? L.z : 0u) | (slot == 2 ? L.w : 0u);
-	const uint32_t bi = (uint32_t)bit & 31u;
-	const uint32_t before = (slot > 0 ? __popc(L.y) : 0) + (slot > 1 ? __popc(L.z) : 0);
-	rank = (uint64_t)(L.x + before + __popc(word & ((1u << bi) - 1u)));
-	return (word >> bi) & 1u;
+	return mphf_probe_line(lines[line], w32 - line * kLineData32, (uint32_t)bit & 31u, rank);
 }
 
 // The first 64-B sector of a GroupDesc, fetched with four back-to-back 16-B loads and ONE wait: everything a query
@@ -106,11 +109,23 @@ __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v,
 	if (mphf_probe(lines, off + reduce_level(hs.next(2), gh.size2), rank))
 		return rank;
 	off += gh.size2;
-	for (int lv = 3; lv < kLevels; lv++) {
-		const uint64_t size = gd->size[lv];
-		if (mphf_probe(lines, off + reduce_level(hs.next(lv), size), rank))
+	// Deeper levels two at a time: both sizes come with one 16-B load (size[lv], lv odd, is 16-B aligned inside GroupDesc)
+	// and both lines are requested before either is inspected -- two dependent round trips per pair instead of four.
+	static_assert((offsetof(GroupDesc, size) + 8 * 3) % 16 == 0 && kLevels % 2 == 0, "size[3] must be 16-B aligned");
+	for (int lv = 3; lv < kLevels; lv += 2) {
+		const uint4 sz = *reinterpret_cast<const uint4*>(&gd->size[lv]);  // size[lv], size[lv + 1] (unused for lv = 15)
+		const uint64_t size_a = (uint64_t)sz.x | ((uint64_t)sz.y << 32), size_b = (uint64_t)sz.z | ((uint64_t)sz.w << 32);
+		const uint64_t bit_a = off + reduce_level(hs.next(lv), size_a);
+		const bool two = lv + 1 < kLevels;
+		const uint64_t bit_b = two ? off + size_a + reduce_level(hs.next(lv + 1), size_b) : bit_a;
+		const uint32_t wa = (uint32_t)(bit_a >> 5), wb = (uint32_t)(bit_b >> 5);
+		const uint32_t la = wa / kLineData32, lb = wb / kLineData32;
+		const uint4 A = lines[la], B = lines[lb];
+		if (mphf_probe_line(A, wa - la * kLineData32, (uint32_t)bit_a & 31u, rank))
 			return rank;
-		off += size;
+		if (two && mphf_probe_line(B, wb - lb * kLineData32, (uint32_t)bit_b & 31u, rank))
+			return rank;
+		off += size_a + size_b;
 	}
 	return kNotFound;
 }
