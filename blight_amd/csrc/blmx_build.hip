@@ -1395,6 +1395,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			ix.h_groups[g].prefix += id_base;
 	BLMX_HIP(ix.groups.alloc((size_t)ngroups * sizeof(GroupDesc), false, s));
 	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
+	make_query_heads(ix);
 
 	mark("K9a fallback");
 	// ---- K9b: positions
@@ -1441,12 +1442,33 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	st.bits_saved = ix.prm.bits_saved;
 	st.kmer_bytes = (uint32_t)(8 * KW);
 	st.max_levels_used = (uint32_t)levels_used;
-	st.device_bytes = ix.buckets.bytes + ix.groups.bytes + ix.seq.bytes + ix.positions.bytes + ix.lines.bytes + ix.fb_keys.bytes +
+	st.device_bytes = ix.buckets.bytes + ix.groups.bytes + ix.qheads.bytes + ix.seq.bytes + ix.positions.bytes + ix.lines.bytes + ix.fb_keys.bytes +
 	                  ix.fb_ranks.bytes;
 	st.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
 }  // namespace
+
+void make_query_heads(Index& ix)
+{
+	ix.has_qheads = false;
+	std::vector<QueryHead> h(ix.ngroups);
+	for (uint32_t g = 0; g < ix.ngroups; g++) {
+		const GroupDesc& gd = ix.h_groups[g];
+		if ((gd.line_base >> 32) || (gd.size[0] >> 32) || (gd.size[1] >> 32) || (gd.size[2] >> 32) || (gd.posstart >> 56) || gd.nbits > 255)
+			return;  // a group too large for the narrow fields: the kernels keep reading the GroupDesc head
+		h[g].prefix = gd.prefix;
+		h[g].posstart_nbits = gd.posstart | ((uint64_t)gd.nbits << 56);
+		h[g].line_base = (uint32_t)gd.line_base;
+		h[g].size0 = (uint32_t)gd.size[0];
+		h[g].size1 = (uint32_t)gd.size[1];
+		h[g].size2 = (uint32_t)gd.size[2];
+	}
+	BLMX_HIP(ix.qheads.alloc((size_t)ix.ngroups * sizeof(QueryHead), false, ix.stream));
+	BLMX_HIP(hipMemcpyAsync(ix.qheads.p, h.data(), h.size() * sizeof(QueryHead), hipMemcpyHostToDevice, ix.stream));
+	BLMX_HIP(hipStreamSynchronize(ix.stream));
+	ix.has_qheads = true;
+}
 
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
 {

@@ -37,11 +37,23 @@ struct alignas(64) GroupDesc {
 };
 static_assert(sizeof(GroupDesc) == 192 + 0, "GroupDesc must be 192 bytes");
 
+// What a query needs from its group up to MPHF level 2, in 32 B (two 16-B loads instead of four): built from the group
+// table once the index is finished (make_query_heads).  Only used when every group fits the narrow fields; otherwise
+// DeviceIndexView::qheads is null and the kernels read the GroupDesc head.
+struct alignas(32) QueryHead {
+	uint64_t prefix;
+	uint64_t posstart_nbits;  // posstart (56 bits) | nbits << 56
+	uint32_t line_base;
+	uint32_t size0, size1, size2;
+};
+static_assert(sizeof(QueryHead) == 32, "QueryHead must be 32 bytes");
+
 struct DeviceIndexView {
 	int k, m, n, b, gshift;
 	uint32_t nbuckets, ngroups;
 	const BucketDesc* buckets;
 	const GroupDesc* groups;
+	const QueryHead* qheads;    // compact per-group head for the query kernel, or nullptr
 	const uint64_t* seq;        // 2-bit packed, MSB-first
 	const uint64_t* positions;  // LSB-first bit fields
 	const uint64_t* lines;      // MPHF lines: [rank | 7 data words]
@@ -109,7 +121,8 @@ struct Index {
 	std::mutex mu;  // serialises host-buffer queries (shared staging buffers)
 
 	// finished index (HBM)
-	DevBuf buckets, groups, seq, positions, lines, fb_keys, fb_ranks;
+	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks;
+	bool has_qheads = false;
 	// host mirror of the group table (export / stats)
 	std::vector<GroupDesc> h_groups;
 	std::vector<uint32_t> h_fb_group;
@@ -138,6 +151,7 @@ struct Index {
 		v.ngroups = ngroups;
 		v.buckets = buckets.as<BucketDesc>();
 		v.groups = groups.as<GroupDesc>();
+		v.qheads = has_qheads ? qheads.as<QueryHead>() : nullptr;
 		v.seq = seq.as<uint64_t>();
 		v.positions = positions.as<uint64_t>();
 		v.lines = lines.as<uint64_t>();
@@ -149,6 +163,7 @@ struct Index {
 };
 
 // build (blmx_build.hip)
+void make_query_heads(Index& ix);  // from ix.h_groups, after the group table is final (build and load)
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
 
 // query (blmx_query.hip).  mode: 0 = IDs (query_kmer_hash / query_get_hash), 1 = positions (query_get_pos_unitig),

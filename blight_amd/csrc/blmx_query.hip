@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 		uint64_t bstart;
 		uint32_t bnt;
 		const GroupDesc* gd = &v.groups[mini >> v.gshift];
-		const GroupHead gh = load_bucket_and_head(&v.buckets[mini], gd, bstart, bnt);
+		const GroupHead gh = v.qheads ? load_bucket_and_qhead(&v.buckets[mini], &v.qheads[mini >> v.gshift], bstart, bnt)
+		                              : load_bucket_and_head(&v.buckets[mini], gd, bstart, bnt);
 		if (bnt == 0)  // blight.cpp:719-720
 			break;
 		const uint64_t h = mphf_lookup<KW>(v, gd, gh, x);

@@ -362,6 +362,7 @@ void load_index(Index& ix, const char* path)
 	ix.h_groups.resize(h.ngroups);
 	BLMX_HIP(hipMemcpyAsync(ix.h_groups.data(), ix.groups.p, (size_t)h.ngroups * sizeof(GroupDesc), hipMemcpyDeviceToHost, s));
 	BLMX_HIP(hipStreamSynchronize(s));
+	make_query_heads(ix);
 	ix.shard_rank = h.shard_rank;
 	ix.shard_world = h.shard_world;
 	ix.positions_words = h.positions_words;

@@ -90,6 +90,35 @@ __device__ __forceinline__ GroupHead load_bucket_and_head(const BucketDesc* __re
 	return unpack_group_head(a, b, c, d);
 }
 
+// The same round trip with the compact QueryHead (32 B): three 16-B loads instead of five.  fb_* are not part of it
+// (the lookup reads them from the GroupDesc when all levels missed).
+__device__ __forceinline__ GroupHead load_bucket_and_qhead(const BucketDesc* __restrict__ bp, const QueryHead* __restrict__ qp, uint64_t& bstart,
+                                                           uint32_t& bnt)
+{
+	uint4 bd, a, b;
+	asm volatile(
+	    "global_load_dwordx4 %0, %3, off\n\t"
+	    "global_load_dwordx4 %1, %4, off\n\t"
+	    "global_load_dwordx4 %2, %4, off offset:16\n\t"
+	    "s_waitcnt vmcnt(0)"
+	    : "=&v"(bd), "=&v"(a), "=&v"(b)
+	    : "v"(bp), "v"(qp)
+	    : "memory");
+	bstart = (uint64_t)bd.x | ((uint64_t)bd.y << 32);
+	bnt = bd.z;
+	GroupHead h;
+	h.prefix = (uint64_t)a.x | ((uint64_t)a.y << 32);
+	h.posstart = (uint64_t)a.z | ((uint64_t)(a.w & 0x00ffffffu) << 32);
+	h.nbits = a.w >> 24;
+	h.line_base = b.x;
+	h.size0 = b.y;
+	h.size1 = b.z;
+	h.size2 = b.w;
+	h.fb_start = 0;
+	h.fb_count = 0;
+	return h;
+}
+
 // mphf::lookup restricted to the level bit arrays (bbhash.h:561-566): probe levels until a set bit is found and rank it.
 // Levels 0..2 use the sizes that came with the group head; deeper levels read their size on demand.
 template <int KW>
@@ -135,11 +164,15 @@ template <int KW>
 __device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x)
 {
 	const uint64_t r = mphf_lookup_levels<KW>(v, gd, gh, x);
-	if (r != kNotFound || gh.fb_count == 0)
+	if (r != kNotFound)
 		return r;
+	const uint32_t fb_count = gd->fb_count;  // from the descriptor: the compact query head does not carry the fallback fields
+	if (fb_count == 0)
+		return r;
+	const uint64_t fb_start = gd->fb_start;
 	// _final_hash.find(elem), bbhash.h:567-575.  The table is sorted by (group, key, input order) and keeps every
 	// occurrence of a duplicated key; the map's "last assignment wins" (bbhash.h:724) = the LAST entry of an equal run.
-	uint64_t lo = gh.fb_start, hi = lo + gh.fb_count;
+	uint64_t lo = fb_start, hi = lo + fb_count;
 	const uint64_t begin = lo;
 	while (lo < hi) {  // upper bound
 		const uint64_t mid = (lo + hi) >> 1;
@@ -158,11 +191,13 @@ __device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const 
 __device__ __forceinline__ uint32_t read_position(const uint64_t* __restrict__ positions, uint64_t posstart, uint32_t nbits,
                                                   uint64_t h, int b)
 {
+	// nbits <= 32 and a dword-aligned 8-B window starts at most 31 bits before the field: ONE global_load_dwordx2
+	// (multi-dword loads need dword alignment only) instead of two aligned 8-B words
+	typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 	const uint64_t o = posstart + h * (uint64_t)nbits;
-	const uint64_t w = o >> 6;
-	const uint32_t s = (uint32_t)o & 63u;
-	const uint64_t lo = positions[w], hi = positions[w + 1];
-	const uint64_t v = s ? ((lo >> s) | (hi << (64 - s))) : lo;
+	const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint32_t*>(positions) + (o >> 5));
+	const uint32_t s = (uint32_t)o & 31u;
+	const uint64_t v = ((uint64_t)w.x | ((uint64_t)w.y << 32)) >> s;
 	const uint32_t field = (uint32_t)(v & ((nbits >= 32) ? 0xffffffffull : ((1ull << nbits) - 1ull)));
 	return field << b;
 }
