@@ -359,22 +359,47 @@ __global__ void k_scatter_pack(const uint64_t* __restrict__ src, const uint32_t*
 }
 
 // ---- K6 ----------------------------------------------------------------------------------------------------------------
-template <int KW>
-__global__ void k_expand_keys(const uint64_t* __restrict__ src, const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
-                              const uint64_t* __restrict__ key_start, uint64_t nsk, int k, uint64_t* __restrict__ keys)
+// Load-balanced expansion shared by K6 and K9b: a block owns kSkPerBlock consecutive sorted super-k-mers, stages their
+// key_start[] in LDS and hands out the KEYS round-robin to its lanes (key idx -> super-k-mer by a binary search in LDS),
+// so that lanes are equally loaded whatever the super-k-mer lengths and the key array is accessed fully coalesced
+// (one lane per super-k-mer wrote 84-B-strided runs and idled behind the longest super-k-mer of its wave).
+constexpr int kSkPerBlock = 256;
+__device__ __forceinline__ uint32_t sk_of_key(const uint64_t* s_ks, uint32_t nj, uint64_t idx)
 {
-	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= nsk)
-		return;
-	const uint64_t p = sk_pos[order[j]];
-	const uint64_t ks = key_start[j], ke = key_start[j + 1];
-	for (uint64_t t = 0; t < ke - ks; t++) {
-		const Kmer<KW> c = kmer_canon<KW>(packed_kmer<KW>(src, p + t, k), k);
+	uint32_t lo = 0, hi = nj;  // last j in [0, nj) with s_ks[j] <= idx
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (s_ks[mid] <= idx)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_expand_keys(const uint64_t* __restrict__ src, const uint32_t* __restrict__ order,
+                                                        const uint64_t* __restrict__ sk_pos, const uint64_t* __restrict__ key_start, uint64_t nsk,
+                                                        int k, uint64_t* __restrict__ keys)
+{
+	__shared__ uint64_t s_ks[kSkPerBlock + 1];
+	__shared__ uint64_t s_p[kSkPerBlock];
+	const uint64_t j0 = (uint64_t)blockIdx.x * kSkPerBlock;
+	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, nsk - j0);
+	for (uint32_t t = threadIdx.x; t <= nj; t += kBlock)
+		s_ks[t] = key_start[j0 + t];
+	for (uint32_t t = threadIdx.x; t < nj; t += kBlock)
+		s_p[t] = sk_pos[order[j0 + t]];
+	__syncthreads();
+	const uint64_t k1 = s_ks[nj];
+	for (uint64_t idx = s_ks[0] + threadIdx.x; idx < k1; idx += kBlock) {
+		const uint32_t j = sk_of_key(s_ks, nj, idx);
+		const Kmer<KW> c = kmer_canon<KW>(packed_kmer<KW>(src, s_p[j] + (idx - s_ks[j]), k), k);
 		if constexpr (KW == 1) {
-			keys[ks + t] = c.lo;
+			keys[idx] = c.lo;
 		} else {
-			keys[2 * (ks + t)] = c.lo;
-			keys[2 * (ks + t) + 1] = c.hi;
+			keys[2 * idx] = c.lo;
+			keys[2 * idx + 1] = c.hi;
 		}
 	}
 }
@@ -770,42 +795,36 @@ __global__ void k_fb_table(const uint32_t* __restrict__ perm, uint64_t F, const 
 }
 
 // ---- positions -----------------------------------------------------------------------------------------------------------
-// int_to_bool (blight.cpp:464-469): nbits-wide little-endian field at bit start + h*nbits (array is zero-initialised)
-__device__ __forceinline__ void write_position(unsigned long long* __restrict__ positions, uint64_t posstart, uint32_t nbits, uint64_t h,
-                                               uint64_t value)
-{
-	if (value == 0)
-		return;
-	const uint64_t o = posstart + h * (uint64_t)nbits;
-	const uint64_t w = o >> 6;
-	const uint32_t s = (uint32_t)o & 63u;
-	atomicOr(&positions[w], value << s);
-	if (s + nbits > 64)
-		atomicOr(&positions[w + 1], value >> (64 - s));
-}
-
-// fill_positions (blight.cpp:486-519): one lane per sorted super-k-mer walks its keys.  Keys that live in the fallback
-// table are written by k_fb_positions (a duplicated key keeps the position of its LAST occurrence: assignment order).
+// fill_positions (blight.cpp:486-519): one lane per key (load-balanced over the block's super-k-mers) looks its rank up and
+// stores the position field in a 32-bit array indexed by rank.  Keys that live in the fallback table are written by
+// k_fb_positions (a duplicated key keeps the position of its LAST occurrence: assignment order).
 template <int KW>
-__global__ void k_fill_positions(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
-                                 const uint64_t* __restrict__ key_start, uint64_t nsk, const uint64_t* __restrict__ keys,
-                                 unsigned long long* __restrict__ positions)
+__global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
+                                                           const uint64_t* __restrict__ key_start, uint64_t nsk, const uint64_t* __restrict__ keys,
+                                                           uint64_t id_base, uint32_t* __restrict__ field_of_rank)
 {
-	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= nsk)
-		return;
-	const uint32_t mi = smini[j];
-	const GroupDesc* gd = &v.groups[mi >> v.gshift];
-	const uint64_t pos0 = nt_start[j] - v.buckets[mi].start;
-	const uint64_t ks = key_start[j], ke = key_start[j + 1];
-	const GroupHead gh = load_group_head(gd);
-	const uint64_t posstart = gh.posstart;
-	const uint32_t nbits = gh.nbits;
-	for (uint64_t t = 0; t < ke - ks; t++) {
-		const Kmer<KW> x = load_kmer<KW>(keys, ks + t);
+	__shared__ uint64_t s_ks[kSkPerBlock + 1];
+	__shared__ uint64_t s_pos0[kSkPerBlock];
+	__shared__ uint32_t s_mini[kSkPerBlock];
+	const uint64_t j0 = (uint64_t)blockIdx.x * kSkPerBlock;
+	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, nsk - j0);
+	for (uint32_t t = threadIdx.x; t <= nj; t += kBlock)
+		s_ks[t] = key_start[j0 + t];
+	for (uint32_t t = threadIdx.x; t < nj; t += kBlock) {
+		const uint32_t mi = smini[j0 + t];
+		s_mini[t] = mi;
+		s_pos0[t] = nt_start[j0 + t] - v.buckets[mi].start;
+	}
+	__syncthreads();
+	const uint64_t k1 = s_ks[nj];
+	for (uint64_t idx = s_ks[0] + threadIdx.x; idx < k1; idx += kBlock) {
+		const uint32_t j = sk_of_key(s_ks, nj, idx);
+		const GroupDesc* gd = &v.groups[s_mini[j] >> v.gshift];
+		const GroupHead gh = load_group_head(gd);
+		const Kmer<KW> x = load_kmer<KW>(keys, idx);
 		const uint64_t h = mphf_lookup_levels<KW>(v, gd, gh, x);
-		if (h != kNotFound)
-			write_position(positions, posstart, nbits, h, (pos0 + t) >> v.b);
+		if (h != kNotFound)  // ranks are distinct: a plain 4-B store, no atomics (k_pack_positions makes the bit fields)
+			field_of_rank[gh.prefix - id_base + h] = (uint32_t)((s_pos0[j] + (idx - s_ks[j])) >> v.b);
 	}
 }
 
@@ -813,7 +832,7 @@ template <int KW>
 __global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ fb_sorted, uint64_t F,
                                const uint64_t* __restrict__ tk, const uint64_t* __restrict__ trank, const uint32_t* __restrict__ tgrp,
                                const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
-                               const uint64_t* __restrict__ key_start, uint64_t nsk, unsigned long long* __restrict__ positions)
+                               const uint64_t* __restrict__ key_start, uint64_t nsk, uint64_t id_base, uint32_t* __restrict__ field_of_rank)
 {
 	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= F)
@@ -834,7 +853,55 @@ __global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ p
 	const uint32_t mi = smini[lo];
 	const GroupDesc* gd = &v.groups[mi >> v.gshift];
 	const uint64_t pos = nt_start[lo] - v.buckets[mi].start + (idx - key_start[lo]);
-	write_position(positions, gd->posstart, gd->nbits, trank[e], pos >> v.b);
+	field_of_rank[gd->prefix - id_base + trank[e]] = (uint32_t)(pos >> v.b);
+}
+
+// int_to_bool for a whole group (blight.cpp:464-469): one workgroup packs the group's 32-bit fields (indexed by rank)
+// into its nbits-wide little-endian slice of `positions`.  Per chunk of 128 output words the fields that touch the chunk
+// are staged in LDS with coalesced loads, then one lane assembles one 64-bit word (all offsets relative to the chunk:
+// 32-bit arithmetic).  Only the first and last word of a slice can be shared with the neighbouring groups: those are
+// ORed atomically (the array is zero-initialised), every other word is a plain store.
+constexpr int kPackWords = 128;
+__global__ __launch_bounds__(kPackWords) void k_pack_positions(const GroupDesc* __restrict__ groups, uint64_t id_base,
+                                                               const uint32_t* __restrict__ field_of_rank, unsigned long long* __restrict__ positions)
+{
+	__shared__ uint32_t s_f[kPackWords * 64 + 8];
+	const GroupDesc* gd = &groups[blockIdx.x];
+	const uint64_t n = gd->nkeys;
+	const uint32_t nbits = gd->nbits;
+	if (n == 0 || nbits == 0)
+		return;
+	const uint64_t ps = gd->posstart, pe = ps + n * nbits;
+	const uint32_t* __restrict__ f = field_of_rank + (gd->prefix - id_base);
+	const uint64_t w_first = ps >> 6, w_last = (pe - 1) >> 6;
+	const uint32_t fmask = nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u);
+	for (uint64_t wc = w_first; wc <= w_last; wc += kPackWords) {
+		const uint64_t wend = min(wc + (uint64_t)kPackWords - 1, w_last);
+		const uint64_t cb0 = max(wc << 6, ps), cb1 = min((wend << 6) + 64, pe);  // bits of the slice inside this chunk
+		const uint64_t hA = (cb0 - ps) / nbits, hB = (cb1 - 1 - ps) / nbits;     // fields touching the chunk (uniform)
+		const uint32_t nf = (uint32_t)(hB - hA + 1);
+		__syncthreads();  // the previous chunk has been consumed
+		for (uint32_t i = threadIdx.x; i < nf; i += kPackWords)
+			s_f[i] = f[hA + i] & fmask;
+		__syncthreads();
+		const uint64_t w = wc + threadIdx.x;
+		if (w <= wend) {
+			const int32_t r0 = (int32_t)((int64_t)(w << 6) - (int64_t)(ps + hA * nbits));  // word start relative to field hA
+			const int32_t r1 = (int32_t)((int64_t)min((w << 6) + 64, pe) - (int64_t)(ps + hA * nbits));
+			const uint32_t lo = r0 < 0 ? 0u : (uint32_t)r0;
+			const uint32_t i0 = lo / nbits, i1 = ((uint32_t)r1 - 1u) / nbits;
+			uint64_t acc = 0;
+			for (uint32_t i = i0; i <= i1; i++) {
+				const uint64_t val = s_f[i];
+				const int32_t o = (int32_t)(i * nbits) - r0;
+				acc |= o >= 0 ? (val << o) : (val >> (-o));
+			}
+			if ((w == w_first && (ps & 63)) || (w == w_last && (pe & 63)))
+				atomicOr(&positions[w], (unsigned long long)acc);
+			else
+				positions[w] = acc;
+		}
+	}
 }
 
 // ---- host orchestration ------------------------------------------------------------------------------------------------
@@ -898,6 +965,16 @@ template <int KW>
 void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
 {
 	const auto t_begin = std::chrono::steady_clock::now();
+	// temporaries of this build recycle each other's device blocks (declared first: destroyed after every temporary)
+	struct PoolScope {
+		BuildPool pool;
+		PoolScope()
+		{
+			const char* e = getenv("BLIGHT_BUILD_POOL");
+			BuildPool::current() = (e && atoi(e) == 0) ? nullptr : &pool;
+		}
+		~PoolScope() { BuildPool::current() = nullptr; }
+	} pool_scope;
 	hipStream_t s = ix.stream;
 	const int k = (int)ix.prm.k, m = (int)ix.prm.m, n = (int)ix.prm.log2_mphf, b = (int)ix.prm.bits_saved;
 	const uint32_t nbuckets = ix.nbuckets, ngroups = ix.ngroups;
@@ -905,8 +982,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	Scratch sc;
 	sc.s = s;
 	(void)n;
-	// BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream).  Note that on this
-	// driver a fresh hipMalloc costs ~30-50 ms per GB (VRAM is cleared on allocation), which can exceed the kernel time.
+	// BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream).
 	const bool trace = getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) != 0;
 	auto t_last = t_begin;
 	auto mark = [&](const char* what) {
@@ -1195,7 +1271,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	DevBuf d_keys;
 	BLMX_HIP(d_keys.alloc((N + 1) * 8 * KW, false, s));
 	if (nsk)
-		hipLaunchKernelGGL((k_expand_keys<KW>), dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
+		hipLaunchKernelGGL((k_expand_keys<KW>), dim3(grid_for(nsk, kSkPerBlock)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
 		                   d_skpos.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, k, d_keys.as<uint64_t>());
 	BLMX_HIP(hipGetLastError());
 	BLMX_HIP(hipStreamSynchronize(s));
@@ -1404,16 +1480,21 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	ix.st.total_nt = total_nt;
 	{
 		const DeviceIndexView v = ix.view();
+		DevBuf d_field;  // position field of every local rank (ranks nobody owns -- overwritten duplicates -- stay 0 like in the reference)
+		BLMX_HIP(d_field.alloc((N + 1) * 4, true, s));
 		if (nsk)
-			hipLaunchKernelGGL((k_fill_positions<KW>), dim3(grid_for(nsk)), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
-			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), ix.positions.as<unsigned long long>());
+			hipLaunchKernelGGL((k_fill_positions<KW>), dim3(grid_for(nsk, kSkPerBlock)), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
+			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>());
 		if (F)
 			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint32_t>(), F,
 			                   ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(),
-			                   d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, ix.positions.as<unsigned long long>());
+			                   d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, id_base, d_field.as<uint32_t>());
+		if (N)
+			hipLaunchKernelGGL(k_pack_positions, dim3(ngroups), dim3(kPackWords), 0, s, ix.groups.as<GroupDesc>(), id_base, d_field.as<uint32_t>(),
+			                   ix.positions.as<unsigned long long>());
 		BLMX_HIP(hipGetLastError());
+		BLMX_HIP(hipStreamSynchronize(s));
 	}
-	BLMX_HIP(hipStreamSynchronize(s));
 
 	mark("K9b positions");
 	// ---- public counters (blight.h:52-59, recap blight.cpp:361-378)

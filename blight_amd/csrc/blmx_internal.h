@@ -63,31 +63,95 @@ struct DeviceIndexView {
 };
 
 // ---- tiny RAII device buffer ---------------------------------------------------------------------------------------
+// Cache of device blocks for the temporaries of ONE build.  On this driver hipMalloc of recycled VRAM costs 30-50 ms per GB
+// (pages are cleared when they are handed out again), and a human-scale build allocates ~70 GB of temporaries in ~60
+// buffers whose lifetimes barely overlap: blocks released by a temporary are kept here and handed to the next request
+// they fit (all work of a build is on one stream, so reuse is ordered), and everything goes back to the driver when
+// the build ends.  Index arrays (DevBuf::persistent) never come from the pool.
+struct BuildPool {
+	struct Block {
+		void* p;
+		size_t bytes;
+	};
+	std::vector<Block> free_blocks;
+	~BuildPool() { drain(); }
+	void drain()
+	{
+		for (const Block& b : free_blocks)
+			(void)hipFree(b.p);
+		free_blocks.clear();
+	}
+	hipError_t get(size_t n, void** p, size_t* bytes)
+	{
+		size_t best = free_blocks.size();
+		for (size_t i = 0; i < free_blocks.size(); i++)
+			if (free_blocks[i].bytes >= n && free_blocks[i].bytes <= 2 * n + (64u << 20) &&
+			    (best == free_blocks.size() || free_blocks[i].bytes < free_blocks[best].bytes))
+				best = i;
+		if (best != free_blocks.size()) {
+			*p = free_blocks[best].p;
+			*bytes = free_blocks[best].bytes;
+			free_blocks.erase(free_blocks.begin() + (long)best);
+			return hipSuccess;
+		}
+		hipError_t e = hipMalloc(p, n);
+		if (e != hipSuccess) {  // out of memory with blocks parked here: give them back and retry
+			(void)hipGetLastError();
+			drain();
+			e = hipMalloc(p, n);
+		}
+		*bytes = n;
+		return e;
+	}
+	void put(void* p, size_t bytes) { free_blocks.push_back(Block{p, bytes}); }
+	static BuildPool*& current()
+	{
+		static thread_local BuildPool* pool = nullptr;
+		return pool;
+	}
+};
+
 struct DevBuf {
 	void* p = nullptr;
 	size_t bytes = 0;
+	bool persistent = false;     // index array: exact hipMalloc, never pooled
+	BuildPool* owner = nullptr;  // pool the current block came from (build temporaries)
 	DevBuf() = default;
 	DevBuf(const DevBuf&) = delete;
 	DevBuf& operator=(const DevBuf&) = delete;
 	~DevBuf() { release(); }
 	void release()
 	{
-		if (p)
-			(void)hipFree(p);
+		if (p) {
+			if (owner)
+				owner->put(p, bytes);
+			else
+				(void)hipFree(p);
+		}
 		p = nullptr;
 		bytes = 0;
+		owner = nullptr;
 	}
 	hipError_t alloc(size_t n, bool zero, hipStream_t s)
 	{
 		release();
 		if (n == 0)
 			n = 16;
-		hipError_t e = hipMalloc(&p, n);
+		BuildPool* pool = persistent ? nullptr : BuildPool::current();
+		hipError_t e;
+		if (pool) {
+			e = pool->get(n, &p, &bytes);
+			owner = e == hipSuccess ? pool : nullptr;
+		} else {
+			e = hipMalloc(&p, n);
+			bytes = n;
+		}
 		if (e != hipSuccess) {
 			p = nullptr;
+			bytes = 0;
+			owner = nullptr;
 			return e;
 		}
-		bytes = n;
 		if (zero)
 			e = hipMemsetAsync(p, 0, n, s);
 		return e;
@@ -138,6 +202,12 @@ struct Index {
 	hipStream_t bin_last_stream = nullptr;
 	bool bin_used = false;
 	int bin_policy = 0;  // 0 = automatic, 1 = always bin, -1 = never (BLIGHT_QUERY_BINNING env / blmx_set_query_binning)
+
+	Index()
+	{
+		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks})
+			b->persistent = true;
+	}
 
 	DeviceIndexView view() const
 	{
