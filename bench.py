@@ -30,9 +30,9 @@ ALGO_BYTES = {31: 145, 63: 209}  # algorithmic bytes per query, SURVEY.md sectio
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per step (all kernels of the query pipeline: k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids) from
 # rocprofv3 PMC passes of this same command (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; FETCH_SIZE calibrated = 1.000 on random
-# 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern): profiles/r01_pmc_pipeline_c4_v13.txt.
+# 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern): profiles/r01_pmc_pipeline_c4_v14.txt.
 # Only quoted for the workload it was measured on.
-TRAFFIC_BYTES = {"C4": (14.751e6 + 3.867e6) * 1024}
+TRAFFIC_BYTES = {"C4": (18.440e6 + 3.494e6) * 1024}
 
 WORKLOADS = {
     # name: (k, m, log2_mphf, b, indexed k-mers, queries per step per GPU)

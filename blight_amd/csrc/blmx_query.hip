@@ -630,6 +630,9 @@ void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis,
 // IDs are gathered back through the inverse permutation, whose 1024 streams are each (nearly) sequential.
 constexpr int kBinThreads = 1024;  // 16 waves per CU: the scatter holds 108 KB of LDS, so one block per CU
 constexpr int kBinBitsMax = 10;
+// 512 bins: (tile, bin) runs of 16 k-mers = 128 B keep the scatter's stores and the gather's reads line-sized; with the
+// XCD-major query order the finer 1024-bin partition no longer pays for its 64-B runs (C4: 7.33 ms vs 7.60 ms per step).
+constexpr int kBinBitsDefault = 9;
 // queries per block in the partition passes: the scatter stages a whole tile (k-mers + bin ids) in LDS
 template <int KW> struct BinTile { static constexpr int value = 8192 / KW; };
 
@@ -776,7 +779,12 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 		BLMX_HIP(hipEventCreateWithFlags(&ix.bin_done, hipEventDisableTiming));
 	if (ix.bin_used && ix.bin_last_stream != s)
 		BLMX_HIP(hipStreamWaitEvent(s, ix.bin_done, 0));
-	const int tbits = mbits < kBinBitsMax ? mbits : kBinBitsMax;
+	static const int env_bits = [] {
+		const char* e = getenv("BLIGHT_BIN_BITS");  // experiment knob
+		const int v = e ? atoi(e) : kBinBitsDefault;
+		return v < 1 ? 1 : (v > kBinBitsMax ? kBinBitsMax : v);
+	}();
+	const int tbits = mbits < env_bits ? mbits : env_bits;
 	const uint32_t nbins = 1u << tbits;
 	const int bin_shift = mbits - tbits;
 	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
