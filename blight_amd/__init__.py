@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
-ABI_VERSION = 5  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
+ABI_VERSION = 6  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 _u64p = C.POINTER(C.c_uint64)
@@ -71,6 +71,9 @@ def load_library():
     lib.blmx_query_sequences.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _i64p]
     lib.blmx_query_file.argtypes = [C.c_void_p, C.c_char_p, _u64p, _u64p]
     lib.blmx_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.blmx_partition_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.blmx_query_partitioned_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.blmx_gather_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_load.argtypes = [C.c_void_p, C.c_char_p]
     lib.blmx_peek_params.argtypes = [C.c_char_p, C.POINTER(blmx_params)]
     lib.blmx_sequence_kmer_count.argtypes = [C.c_void_p, _u64p, C.c_uint64]
@@ -297,6 +300,15 @@ class kmer_Set_Light:
     # -- device-resident batch API (bench / pipelines): raw device pointers + hipStream_t
     def query_kmers_device(self, d_kmers_ptr, nq, d_ids_ptr, stream=None):
         self._check(self._lib.blmx_query_kmers_device(self._h, d_kmers_ptr, nq, d_ids_ptr, stream))
+
+    def partition_device(self, d_kmers_ptr, nq, d_ordered_ptr, d_inv_ptr, d_rank_counts_ptr=None, stream=None):
+        self._check(self._lib.blmx_partition_device(self._h, d_kmers_ptr, nq, d_ordered_ptr, d_inv_ptr, d_rank_counts_ptr, stream))
+
+    def query_partitioned_device(self, d_ordered_ptr, nq, d_ids_ptr, stream=None):
+        self._check(self._lib.blmx_query_partitioned_device(self._h, d_ordered_ptr, nq, d_ids_ptr, stream))
+
+    def gather_ids_device(self, d_ids_ordered_ptr, d_inv_ptr, nq, d_ids_out_ptr, stream=None):
+        self._check(self._lib.blmx_gather_ids_device(self._h, d_ids_ordered_ptr, d_inv_ptr, nq, d_ids_out_ptr, stream))
 
     def kmer_groups_device(self, d_kmers_ptr, nq, d_groups_ptr, stream=None):
         self._check(self._lib.blmx_kmer_groups_device(self._h, d_kmers_ptr, nq, d_groups_ptr, stream))

@@ -437,6 +437,42 @@ int blmx_unpermute_device(blmx_index* h, const int64_t* d_vals, const uint32_t* 
 	});
 }
 
+int blmx_partition_device(blmx_index* h, const void* d_kmers, uint64_t nq, void* d_sorted_kmers, uint32_t* d_inv, uint64_t* d_rank_counts,
+                          void* stream)
+{
+	if (!h || (nq && (!d_kmers || !d_sorted_kmers || !d_inv)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		if (!h->ix.built)
+			throw StatusError{BLMX_ESTATE, "index not built"};
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		launch_partition(h->ix, d_kmers, nq, d_sorted_kmers, d_inv, d_rank_counts, reinterpret_cast<hipStream_t>(stream));
+	});
+}
+
+int blmx_query_partitioned_device(blmx_index* h, const void* d_sorted_kmers, uint64_t nq, int64_t* d_ids, void* stream)
+{
+	if (!h || (nq && (!d_sorted_kmers || !d_ids)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		if (!h->ix.built)
+			throw StatusError{BLMX_ESTATE, "index not built"};
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		launch_query_partitioned(h->ix, d_sorted_kmers, nq, d_ids, reinterpret_cast<hipStream_t>(stream));
+		h->ix.st.number_query += nq;
+	});
+}
+
+int blmx_gather_ids_device(blmx_index* h, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_ids_out, void* stream)
+{
+	if (!h || (nq && (!d_ids_sorted || !d_inv || !d_ids_out)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		launch_gather_ids(h->ix, d_ids_sorted, d_inv, nq, d_ids_out, reinterpret_cast<hipStream_t>(stream));
+	});
+}
+
 int blmx_set_query_binning(blmx_index* h, int policy)
 {
 	if (!h)

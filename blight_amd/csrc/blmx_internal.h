@@ -244,6 +244,9 @@ void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis,
 // Large batches: partition the queries by the top bits of their minimizer first (one counting pass), run the query
 // kernel on the partitioned batch, gather the IDs back into the caller's order.
 void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s);
+void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorted, uint32_t* d_inv, uint64_t* d_rank_counts, hipStream_t s);
+void launch_query_partitioned(Index& ix, const void* d_sorted_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s);
+void launch_gather_ids(Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s);
 void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s);
 // rolling canonical k-mers of ASCII sequences -> canonical k-mer array (KW words each); returns via d_err (BLMX_EDNA)
 void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, const uint64_t* d_kmer_offs,

@@ -636,8 +636,24 @@ constexpr int kBinBitsDefault = 9;
 // queries per block in the partition passes: the scatter stages a whole tile (k-mers + bin ids) in LDS
 template <int KW> struct BinTile { static constexpr int value = 8192 / KW; };
 
+// minimizer -> partition bin.  Bins are minimizer prefixes; on a sharded index every bin that contains a shard boundary
+// is split there (at most 15 extra bins), so that bins stay monotone in the minimizer AND every bin belongs to exactly
+// one owner rank: a batch partitioned with this map can be cut into per-owner segments without another pass.
+struct BinMap {
+	int shift;
+	uint32_t nbound;
+	uint32_t bound[15];  // bound[r] = first minimizer owned by rank r + 1 (non-decreasing)
+	__host__ __device__ uint32_t bin_of(uint32_t mini) const
+	{
+		uint32_t b = mini >> shift;
+		for (uint32_t r = 0; r < nbound; r++)
+			b += mini >= bound[r] ? 1u : 0u;
+		return b;
+	}
+};
+
 template <int KW>
-__global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, int bin_shift, uint32_t nbins, const uint64_t* __restrict__ kmers,
+__global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, BinMap bm, uint32_t nbins, const uint64_t* __restrict__ kmers,
                                                           uint64_t nq, uint32_t* __restrict__ minibuf, uint32_t* __restrict__ hist, uint32_t nblk)
 {
 	constexpr int kTile = BinTile<KW>::value;
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, int bin_
 			const Kmer<KW> x = load_kmer<KW>(kmers, i);
 			const uint32_t mini = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m);
 			minibuf[i] = mini;  // travels with the k-mer to the query kernel: the 23 m-mer hashes are paid once
-			atomicAdd(&s_hist[mini >> bin_shift], 1u);
+			atomicAdd(&s_hist[bm.bin_of(mini)], 1u);
 		}
 	}
 	__syncthreads();
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, int bin_
 // (measured: isolated stores wrote 2.8x the payload to HBM).  inv[i] = final position of query i (coalesced by i).
 template <int KW>
 __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __restrict__ kmers, uint64_t nq, const uint32_t* __restrict__ minibuf,
-                                                             int bin_shift, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
+                                                             BinMap bm, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
                                                              uint32_t nblk, uint32_t nbins, uint64_t* __restrict__ sorted,
                                                              uint32_t* __restrict__ sorted_minis, uint32_t* __restrict__ inv)
 {
@@ -705,7 +721,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 		const uint64_t i = base + (uint64_t)it * kBinThreads + t;
 		if (i < nq) {
 			const uint32_t mini = minibuf[i];
-			const uint32_t b = mini >> bin_shift;
+			const uint32_t b = bm.bin_of(mini);
 			const uint32_t r = atomicAdd(&s_cur[b], 1u);
 			if constexpr (KW == 1) {
 				s_keys[r] = kmers[i];
@@ -721,7 +737,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 	const uint32_t count = (uint32_t)min((uint64_t)kTile, nq - base);
 	for (uint32_t sidx = t; sidx < count; sidx += kBinThreads) {
 		const uint32_t mini = s_mini[sidx];
-		const uint32_t b = mini >> bin_shift;
+		const uint32_t b = bm.bin_of(mini);
 		const uint64_t dst = (uint64_t)s_gstart[b] + (sidx - s_lstart[b]);
 		if (sorted_minis)
 			sorted_minis[dst] = mini;
@@ -754,6 +770,106 @@ static void ensure_buf(DevBuf& b, size_t bytes, hipStream_t s)
 		BLMX_HIP(b.alloc(bytes + bytes / 8 + 256, false, s));
 }
 
+// per-owner k-mer counts of a partitioned batch: owner r holds bins [first_bin[r], first_bin[r + 1])
+__global__ void k_rank_counts(const uint32_t* __restrict__ offs, uint32_t nblk, uint32_t nbins, uint64_t nq, uint32_t world,
+                              const uint32_t* __restrict__ first_bin, uint64_t* __restrict__ counts)
+{
+	const uint32_t r = threadIdx.x;
+	if (r >= world)
+		return;
+	const uint32_t b0 = first_bin[r], b1 = first_bin[r + 1];
+	const uint64_t a = b0 >= nbins ? nq : offs[(uint64_t)b0 * nblk], z = b1 >= nbins ? nq : offs[(uint64_t)b1 * nblk];
+	counts[r] = z - a;
+}
+
+namespace {
+
+struct PartitionPlan {
+	BinMap bm;
+	uint32_t nbins, nblk;
+	bool handoff;
+};
+
+// scratch of the partition passes is shared by all calls on this index: order this pipeline after the previous one when
+// it was enqueued on a different stream (caller holds ix.bin_mu)
+void partition_begin(Index& ix, hipStream_t s)
+{
+	if (!ix.bin_done)
+		BLMX_HIP(hipEventCreateWithFlags(&ix.bin_done, hipEventDisableTiming));
+	if (ix.bin_used && ix.bin_last_stream != s)
+		BLMX_HIP(hipStreamWaitEvent(s, ix.bin_done, 0));
+}
+void partition_end(Index& ix, hipStream_t s)
+{
+	BLMX_HIP(hipEventRecord(ix.bin_done, s));
+	ix.bin_last_stream = s;
+	ix.bin_used = true;
+}
+
+// k_bin_hist -> scan -> k_bin_scatter.  d_sorted / d_inv are the outputs; d_sorted_minis may be null.
+PartitionPlan partition_batch(Index& ix, const void* d_kmers, uint64_t nq, bool owner_bins, void* d_sorted, uint32_t* d_sorted_minis,
+                              uint32_t* d_inv, hipStream_t s)
+{
+	const int mbits = 2 * (int)ix.prm.m - 1;
+	static const int env_bits = [] {
+		const char* e = getenv("BLIGHT_BIN_BITS");  // experiment knob
+		const int v = e ? atoi(e) : kBinBitsDefault;
+		return v < 1 ? 1 : (v > kBinBitsMax ? kBinBitsMax : v);
+	}();
+	const int tbits = mbits < env_bits ? mbits : env_bits;
+	PartitionPlan pl;
+	pl.bm.shift = mbits - tbits;
+	pl.bm.nbound = 0;
+	if (owner_bins && ix.shard_world > 1) {  // split the bins at the shard boundaries (first minimizer of each owner)
+		if (ix.shard_world > 16)
+			throw StatusError{BLMX_ELIMIT, "at most 16 shards in the partitioned exchange"};
+		for (uint32_t r = 1; r < ix.shard_world; r++)
+			pl.bm.bound[pl.bm.nbound++] = ix.shard_bounds[r] << ix.gshift;
+	}
+	pl.nbins = (1u << tbits) + pl.bm.nbound;
+	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
+	pl.nblk = (uint32_t)((nq + tile - 1) / tile);
+	pl.handoff = d_sorted_minis != nullptr;
+	const uint32_t nblk = pl.nblk, nbins = pl.nbins;
+	const size_t nh = (size_t)nbins * nblk;
+	ensure_buf(ix.b_bins, nq * 4, s);
+	ensure_buf(ix.b_hist, nh * 4, s);
+	ensure_buf(ix.b_offs, nh * 4, s);
+	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_bin_hist<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, pl.bm, nbins, km, nq,
+		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
+	else
+		hipLaunchKernelGGL((k_bin_hist<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, pl.bm, nbins, km, nq,
+		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
+	BLMX_HIP(hipGetLastError());
+	size_t bytes = 0;
+	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
+	ensure_buf(ix.b_tmp, bytes, s);
+	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), pl.bm,
+		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
+	else
+		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), pl.bm,
+		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
+	BLMX_HIP(hipGetLastError());
+	return pl;
+}
+
+void gather_ids(const Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s)
+{
+	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
+	const uint32_t nblk = (uint32_t)((nq + tile - 1) / tile);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_gather_ids<BinTile<1>::value>), dim3(nblk), dim3(kBinThreads), 0, s, d_ids_sorted, d_inv, nq, d_out);
+	else
+		hipLaunchKernelGGL((k_gather_ids<BinTile<2>::value>), dim3(nblk), dim3(kBinThreads), 0, s, d_ids_sorted, d_inv, nq, d_out);
+	BLMX_HIP(hipGetLastError());
+}
+
+}  // namespace
+
 void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s)
 {
 	if (nq == 0)
@@ -773,24 +889,7 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 		return;
 	}
 	std::lock_guard<std::mutex> lock(ix.bin_mu);
-	// the scratch buffers are shared by all calls on this index: order this pipeline after the previous one when it was
-	// enqueued on a different stream
-	if (!ix.bin_done)
-		BLMX_HIP(hipEventCreateWithFlags(&ix.bin_done, hipEventDisableTiming));
-	if (ix.bin_used && ix.bin_last_stream != s)
-		BLMX_HIP(hipStreamWaitEvent(s, ix.bin_done, 0));
-	static const int env_bits = [] {
-		const char* e = getenv("BLIGHT_BIN_BITS");  // experiment knob
-		const int v = e ? atoi(e) : kBinBitsDefault;
-		return v < 1 ? 1 : (v > kBinBitsMax ? kBinBitsMax : v);
-	}();
-	const int tbits = mbits < env_bits ? mbits : env_bits;
-	const uint32_t nbins = 1u << tbits;
-	const int bin_shift = mbits - tbits;
-	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
-	const uint32_t nblk = (uint32_t)((nq + tile - 1) / tile);
-	const size_t nh = (size_t)nbins * nblk;
-	ensure_buf(ix.b_bins, nq * 4, s);
+	partition_begin(ix, s);
 	// hand the minimizers over to the query kernel?  (env BLIGHT_MINI_HANDOFF=0/1 overrides)
 	static const int env_handoff = [] {
 		const char* e = getenv("BLIGHT_MINI_HANDOFF");
@@ -803,42 +902,59 @@ void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t*
 	ensure_buf(ix.b_sorted, nq * 8 * (size_t)ix.KW, s);
 	ensure_buf(ix.b_inv, nq * 4, s);
 	ensure_buf(ix.b_ids, nq * 8, s);
-	ensure_buf(ix.b_hist, nh * 4, s);
-	ensure_buf(ix.b_offs, nh * 4, s);
-	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
-	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_hist<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bin_shift, nbins, km, nq,
-		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
-	else
-		hipLaunchKernelGGL((k_bin_hist<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bin_shift, nbins, km, nq,
-		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
-	BLMX_HIP(hipGetLastError());
-	size_t bytes = 0;
-	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
-	ensure_buf(ix.b_tmp, bytes, s);
-	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
-	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), bin_shift,
-		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, ix.b_sorted.as<uint64_t>(), d_sorted_minis,
-		                   ix.b_inv.as<uint32_t>());
-	else
-		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), bin_shift,
-		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, ix.b_sorted.as<uint64_t>(), d_sorted_minis,
-		                   ix.b_inv.as<uint32_t>());
-	BLMX_HIP(hipGetLastError());
+	partition_batch(ix, d_kmers, nq, false, ix.b_sorted.p, d_sorted_minis, ix.b_inv.as<uint32_t>(), s);
 	// (storing each ID straight into the caller's slot from k_query was measured 2.8 ms SLOWER per 1e8 queries than this
 	// separate gather: 1e8 scattered 8-B stores cost more than reading the IDs back through the inverse permutation)
 	launch_query(ix, ix.b_sorted.p, d_sorted_minis, nq, ix.b_ids.p, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
-	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_gather_ids<BinTile<1>::value>), dim3(nblk), dim3(kBinThreads), 0, s, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq,
-		                   d_out);
-	else
-		hipLaunchKernelGGL((k_gather_ids<BinTile<2>::value>), dim3(nblk), dim3(kBinThreads), 0, s, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq,
-		                   d_out);
-	BLMX_HIP(hipGetLastError());
-	BLMX_HIP(hipEventRecord(ix.bin_done, s));
-	ix.bin_last_stream = s;
-	ix.bin_used = true;
+	gather_ids(ix, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out, s);
+	partition_end(ix, s);
+}
+
+// ---- the three stages as separate entry points: the sharded exchange (blight_amd/dist.py) partitions on the rank that
+// holds the queries, ships every owner its contiguous segment, queries the received (already bin-ordered) segments
+// without another partition pass, ships the IDs back and gathers them through the inverse permutation.
+void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorted, uint32_t* d_inv, uint64_t* d_rank_counts, hipStream_t s)
+{
+	if (nq >= 0xffffffffull)
+		throw StatusError{BLMX_ELIMIT, "a partitioned batch holds fewer than 2^32 - 1 k-mers"};
+	const uint32_t world = ix.shard_world;
+	if (nq == 0) {
+		if (d_rank_counts)
+			BLMX_HIP(hipMemsetAsync(d_rank_counts, 0, 8 * (size_t)world, s));
+		return;
+	}
+	std::lock_guard<std::mutex> lock(ix.bin_mu);
+	partition_begin(ix, s);
+	const PartitionPlan pl = partition_batch(ix, d_kmers, nq, true, d_sorted, nullptr, d_inv, s);
+	if (d_rank_counts) {
+		uint32_t first_bin[18];
+		first_bin[0] = 0;
+		for (uint32_t r = 1; r < world; r++)
+			first_bin[r] = pl.bm.bin_of(pl.bm.bound[r - 1]);
+		first_bin[world] = pl.nbins;
+		ensure_buf(ix.b_tmp, 4096, s);
+		// the bins of owner r start at bin_of(its first minimizer); staged through the (now idle) scan scratch
+		BLMX_HIP(hipMemcpyAsync(ix.b_tmp.p, first_bin, 4 * (size_t)(world + 1), hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_rank_counts, dim3(1), dim3(64), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, pl.nbins, nq, world,
+		                   ix.b_tmp.as<uint32_t>(), d_rank_counts);
+		BLMX_HIP(hipGetLastError());
+		BLMX_HIP(hipStreamSynchronize(s));  // first_bin lives on this stack frame
+	}
+	partition_end(ix, s);
+}
+
+void launch_query_partitioned(Index& ix, const void* d_sorted_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s)
+{
+	if (nq == 0)
+		return;
+	launch_query(ix, d_sorted_kmers, nullptr, nq, d_ids, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
+}
+
+void launch_gather_ids(Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s)
+{
+	if (nq == 0)
+		return;
+	gather_ids(ix, d_ids_sorted, d_inv, nq, d_out, s);
 }
 
 void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s)

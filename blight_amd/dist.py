@@ -1,9 +1,10 @@
 """Sharded multi-GPU queries: one process per GPU, MPHF groups (contiguous minimizer-bucket ranges,
 reference blight.cpp:692) partitioned over the ranks by key count, and ONE exchange step per query batch:
 
-    local k-mers --route (minimizer -> group -> owner rank)--> all-to-all-v of k-mers  (RCCL over xGMI, `nccl` backend)
-                 owner runs the query kernel on its shard
-                 all-to-all-v of the 8-byte IDs back --> un-permute into the caller's order
+    local k-mers --partition by minimizer prefix, bins split at the shard boundaries (= grouped by owner rank AND ordered
+                   for locality, one pass)--> all-to-all-v of k-mers  (RCCL over xGMI, `nccl` backend)
+                 owner runs the query kernel on the received, already ordered segments (no second partition pass)
+                 all-to-all-v of the 8-byte IDs back --> gather through the inverse permutation into the caller's order
 
 The reference has no communication at all (single process, OpenMP); this is the MI355X-native equivalent of its shared
 memory.  all-to-all-v uses every point-to-point xGMI link at once (each pairwise flow has its own link), payload is
@@ -37,28 +38,28 @@ class DeviceOps:
         return torch.empty(n, device=self.dev, dtype=torch.int64)
 
     def route(self, kmers, bounds_dev, world):
-        """-> (k-mers grouped by destination rank, order, counts per destination [host list])"""
+        """-> (k-mers ordered by partition bin = grouped by owner rank, inverse permutation, counts per owner [device])
+
+        ONE partition pass serves both purposes: it groups the batch by owner (every bin belongs to one owner) and leaves
+        every owner's segment ordered by minimizer prefix, which is the order its query kernel wants -- the owner does not
+        partition again."""
         nq = kmers.shape[0]
-        dest = torch.empty(nq, device=self.dev, dtype=torch.uint8)
-        counts = torch.empty(world, device=self.dev, dtype=torch.int64)
-        self.ix.route_count_device(kmers.data_ptr(), nq, bounds_dev.data_ptr(), world, dest.data_ptr(), counts.data_ptr(), self._stream())
-        offsets = torch.cumsum(counts, 0) - counts
         sorted_k = self.empty_kmers(nq)
-        order = torch.empty(nq, device=self.dev, dtype=torch.int32)
-        cursor = torch.empty(world, device=self.dev, dtype=torch.int64)
-        self.ix.route_scatter_device(kmers.data_ptr(), dest.data_ptr(), nq, offsets.data_ptr(), world, sorted_k.data_ptr(),
-                                     order.data_ptr(), cursor.data_ptr(), self._stream())
-        return sorted_k, order, counts
+        inv = torch.empty(nq, device=self.dev, dtype=torch.int32)
+        counts = torch.zeros(world, device=self.dev, dtype=torch.int64)
+        self.ix.partition_device(kmers.data_ptr(), nq, sorted_k.data_ptr(), inv.data_ptr(), counts.data_ptr(), self._stream())
+        return sorted_k, inv, counts
 
     def query(self, kmers):
+        """answers a batch made of ordered segments (one per peer); IDs in batch order"""
         n = kmers.shape[0]
         ids = self.empty_ids(n)
-        self.ix.query_kmers_device(kmers.data_ptr(), n, ids.data_ptr(), self._stream())
+        self.ix.query_partitioned_device(kmers.data_ptr(), n, ids.data_ptr(), self._stream())
         return ids
 
-    def unpermute(self, vals, order):
+    def unpermute(self, vals, inv):
         out = self.empty_ids(vals.shape[0])
-        self.ix.unpermute_device(vals.data_ptr(), order.data_ptr(), vals.shape[0], out.data_ptr(), self._stream())
+        self.ix.gather_ids_device(vals.data_ptr(), inv.data_ptr(), vals.shape[0], out.data_ptr(), self._stream())
         return out
 
 

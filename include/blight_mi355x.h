@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
  * so a stale caller binary is detected instead of corrupting memory. */
-#define BLMX_ABI_VERSION 5
+#define BLMX_ABI_VERSION 6
 
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
@@ -159,6 +159,21 @@ int blmx_route_scatter_device(blmx_index* ix, const void* d_canon_kmers, const u
                               uint32_t world, void* d_sorted_kmers_out, uint32_t* d_order_out, uint64_t* d_cursor_scratch, void* stream);
 int blmx_unpermute_device(blmx_index* ix, const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, void* stream);
 
+/* The query pipeline as three separate stages, for the sharded exchange (one all-to-all-v out, one back):
+ *   blmx_partition_device         on the rank that holds the queries: orders the batch by minimizer prefix; on a sharded
+ *                                 index (blmx_set_shard) every partition bin belongs to exactly one owner, so the result
+ *                                 is a concatenation of per-owner segments: rank_counts_out[r] (device, world entries,
+ *                                 may be NULL) = length of owner r's segment.  inv_out[i] = position of query i in the
+ *                                 ordered batch.  nq < 2^32 - 1.
+ *   blmx_query_partitioned_device on the owner: answers a batch that is already ordered (a concatenation of ordered
+ *                                 segments received from the peers) without another partition pass; ids in batch order.
+ *   blmx_gather_ids_device        back on the first rank: ids_out[i] = ids_ordered[inv[i]].
+ * With world = 1 the three calls in sequence are exactly blmx_query_kmers_device. */
+int blmx_partition_device(blmx_index* ix, const void* d_kmers, uint64_t nq, void* d_ordered_kmers_out, uint32_t* d_inv_out,
+                          uint64_t* d_rank_counts_out, void* stream);
+int blmx_query_partitioned_device(blmx_index* ix, const void* d_ordered_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
+int blmx_gather_ids_device(blmx_index* ix, const int64_t* d_ids_ordered, const uint32_t* d_inv, uint64_t nq, int64_t* d_ids_out,
+                           void* stream);
 /* Batch-query strategy of blmx_query_kmers / blmx_query_kmers_device: 0 = automatic (large batches on large indexes are first
  * partitioned by the top bits of their minimizer so that concurrently running blocks share a slice of the index in
  * L2 / Infinity Cache; results are identical and in the caller's order), 1 = always partition, -1 = never.

@@ -66,3 +66,56 @@ def test_virtual_shards(world, k, m, n, b):
     torch.cuda.synchronize()
     own = alone >= 0
     assert torch.equal(alone[own], want[own]) and int(own.sum().item()) < int((want >= 0).sum().item())
+
+
+def test_routing_kernels_by_destination():
+    """blmx_route_count/scatter/unpermute (destination-major routing without the locality order; kept in the ABI for callers
+    that exchange unordered batches): owners computed on the device equal the bounds rule, the permutation round-trips."""
+    import torch
+    import blight_amd as B
+    from oracle import oracle as O
+    k, m, n, b, world = 31, 9, 7, 6, 4
+    rng = np.random.default_rng(5)
+    seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 80))) for _ in range(1500)]
+    ix = B.kmer_Set_Light(k, m, n, 3, 1, b)
+    ix.set_shard(1, world)
+    ix.construct_index_from_sequences(seqs)
+    bounds = ix.shard_bounds()
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    q = torch.from_numpy(rng.integers(0, 1 << 62, size=200000, dtype=np.uint64).view(np.int64)).to(dev)
+    nq = q.shape[0]
+    ix.canonicalize_device(q.data_ptr(), nq, s)
+    bt = torch.from_numpy(bounds.astype(np.int32)).to(dev)
+    dest = torch.empty(nq, device=dev, dtype=torch.uint8)
+    counts = torch.empty(world, device=dev, dtype=torch.int64)
+    ix.route_count_device(q.data_ptr(), nq, bt.data_ptr(), world, dest.data_ptr(), counts.data_ptr(), s)
+    offsets = torch.cumsum(counts, 0) - counts
+    sorted_k = torch.empty_like(q)
+    order = torch.empty(nq, device=dev, dtype=torch.int32)
+    cursor = torch.empty(world, device=dev, dtype=torch.int64)
+    ix.route_scatter_device(q.data_ptr(), dest.data_ptr(), nq, offsets.data_ptr(), world, sorted_k.data_ptr(), order.data_ptr(),
+                            cursor.data_ptr(), s)
+    groups = torch.empty(nq, device=dev, dtype=torch.int32)
+    ix.kmer_groups_device(q.data_ptr(), nq, groups.data_ptr(), s)
+    torch.cuda.synchronize()
+    want_dest = np.searchsorted(bounds[1:], groups.cpu().numpy(), side="right")
+    assert np.array_equal(dest.cpu().numpy(), want_dest)
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(want_dest, minlength=world))
+    back = torch.empty_like(q)
+    ix.unpermute_device(sorted_k.data_ptr(), order.data_ptr(), nq, back.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(back, q)
+    # the partitioned exchange groups by the same owners
+    ordered = torch.empty_like(q)
+    inv = torch.empty(nq, device=dev, dtype=torch.int32)
+    pc = torch.zeros(world, device=dev, dtype=torch.int64)
+    ix.partition_device(q.data_ptr(), nq, ordered.data_ptr(), inv.data_ptr(), pc.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(pc, counts)
+    og = torch.empty(nq, device=dev, dtype=torch.int32)
+    ix.kmer_groups_device(ordered.data_ptr(), nq, og.data_ptr(), s)
+    torch.cuda.synchronize()
+    od = np.searchsorted(bounds[1:], og.cpu().numpy(), side="right")
+    assert np.all(np.diff(od) >= 0)  # owner-major
+    assert torch.equal(ordered[inv.long()], q)
