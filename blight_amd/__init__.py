@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
-ABI_VERSION = 6  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
+ABI_VERSION = 7  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 _u64p = C.POINTER(C.c_uint64)
@@ -71,6 +71,13 @@ def load_library():
     lib.blmx_query_sequences.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _i64p]
     lib.blmx_query_file.argtypes = [C.c_void_p, C.c_char_p, _u64p, _u64p]
     lib.blmx_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.blmx_payload_create.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.blmx_payload_destroy.argtypes = [C.c_void_p]
+    lib.blmx_payload_destroy.restype = None
+    lib.blmx_payload_add_file.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _u64p, _u64p]
+    lib.blmx_payload_add_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    lib.blmx_payload_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.blmx_payload_export.restype = C.c_int64
     lib.blmx_partition_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.blmx_query_partitioned_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_gather_ids_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -377,3 +384,48 @@ def primitive(op, data, arg=0, arg2=0, kmer_bytes=8):
     if rc:
         _raise(rc, "blmx_primitive failed")
     return out
+
+
+class Payload:
+    """Per-k-mer payload in HBM keyed by the IDs of an index (reference Colored_/Abundance_De_Bruijn_graph_snippet.cpp):
+    kind "abundance" = uint8 counters (wrap at 256 like the reference), kind "colors" = ncolors bits per k-mer."""
+
+    def __init__(self, index, kind, ncolors=1):
+        self._ix = index
+        self._lib = index._lib
+        self.kind = {"abundance": 0, "colors": 1}[kind]
+        self.ncolors = 1 if self.kind == 0 else int(ncolors)
+        self._p = C.c_void_p()
+        index._check(self._lib.blmx_payload_create(index._h, self.kind, self.ncolors, C.byref(self._p)))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._lib.blmx_payload_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_file(self, path, color=0):
+        """every line of `path` that starts with A/C/G/T is a sequence; returns (k-mers found, k-mers absent)"""
+        f, a = C.c_uint64(), C.c_uint64()
+        self._ix._check(self._lib.blmx_payload_add_file(self._p, os.fsencode(path), color, C.byref(f), C.byref(a)))
+        return f.value, a.value
+
+    def add_ids_device(self, d_ids_ptr, n, color=0, stream=None):
+        self._ix._check(self._lib.blmx_payload_add_ids_device(self._p, d_ids_ptr, n, color, stream))
+
+    def export(self):
+        """abundance: uint8[number_kmer]; colors: bool[number_kmer, ncolors]"""
+        nbytes = self._lib.blmx_payload_export(self._p, None, 0)
+        if nbytes < 0:
+            self._ix._check(int(nbytes))
+        raw = np.empty(nbytes, dtype=np.uint8)
+        self._lib.blmx_payload_export(self._p, raw.ctypes.data, nbytes)
+        if self.kind == 0:
+            return raw
+        n = self._ix.number_kmer
+        return np.unpackbits(raw, bitorder="little")[: n * self.ncolors].reshape(n, self.ncolors).astype(bool)

@@ -17,6 +17,11 @@ struct blmx_index {
 	Index ix;
 };
 
+struct blmx_payload {
+	blmx_index* owner;
+	Payload pl;
+};
+
 namespace {
 
 thread_local std::string g_create_err;
@@ -338,6 +343,73 @@ int blmx_query_file(blmx_index* h, const char* path, uint64_t* good, uint64_t* e
 		std::lock_guard<std::mutex> lock(h->ix.mu);
 		query_file(h->ix, path, *good, *erroneous);
 	});
+}
+
+int blmx_payload_create(blmx_index* h, int kind, uint32_t ncolors, blmx_payload** out)
+{
+	if (out)
+		*out = nullptr;
+	if (!h || !out)
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		std::unique_ptr<blmx_payload> p(new blmx_payload());
+		p->owner = h;
+		p->pl.ix = &h->ix;
+		p->pl.kind = kind;
+		p->pl.ncolors = kind == 0 ? 1 : ncolors;
+		payload_init(p->pl);
+		*out = p.release();
+	});
+}
+
+void blmx_payload_destroy(blmx_payload* p)
+{
+	if (!p)
+		return;
+	(void)hipSetDevice(p->pl.ix->prm.device);
+	(void)hipDeviceSynchronize();
+	delete p;
+}
+
+int blmx_payload_add_file(blmx_payload* p, const char* path, uint32_t color, uint64_t* found_out, uint64_t* absent_out)
+{
+	if (!p || !path)
+		return BLMX_EINVAL;
+	return guarded(p->owner, [&] {
+		std::lock_guard<std::mutex> lock(p->owner->ix.mu);
+		uint64_t found = 0, absent = 0;
+		payload_add_file(p->pl, path, color, found, absent);
+		if (found_out)
+			*found_out = found;
+		if (absent_out)
+			*absent_out = absent;
+	});
+}
+
+int blmx_payload_add_ids_device(blmx_payload* p, const int64_t* d_ids, uint64_t n, uint32_t color, void* stream)
+{
+	if (!p || (n && !d_ids))
+		return BLMX_EINVAL;
+	return guarded(p->owner, [&] {
+		BLMX_HIP(hipSetDevice(p->pl.ix->prm.device));
+		payload_add_ids(p->pl, d_ids, n, color, reinterpret_cast<hipStream_t>(stream));
+	});
+}
+
+int64_t blmx_payload_export(blmx_payload* p, void* out, uint64_t cap_bytes)
+{
+	if (!p)
+		return BLMX_EINVAL;
+	int64_t result = -1;
+	const int rc = guarded(p->owner, [&] {
+		BLMX_HIP(hipSetDevice(p->pl.ix->prm.device));
+		BLMX_HIP(hipDeviceSynchronize());  // updates may have been enqueued on caller streams
+		result = (int64_t)p->pl.bytes;
+		const uint64_t n = std::min<uint64_t>(p->pl.bytes, cap_bytes);
+		if (out && n)
+			BLMX_HIP(hipMemcpy(out, p->pl.data.p, n, hipMemcpyDeviceToHost));
+	});
+	return rc == BLMX_OK ? result : rc;
 }
 
 int blmx_query_kmers_device(blmx_index* h, const void* d_kmers, uint64_t nq, int64_t* d_ids, void* stream)

@@ -261,6 +261,18 @@ void launch_unpermute(const int64_t* d_vals, const uint32_t* d_order, uint64_t n
 // streaming front end (blmx_stream.hip)
 int read_fasta_records(const char* path, std::string& concat, std::vector<uint64_t>& offs);
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);
+// payload applications on top of the IDs (reference Colored_/Abundance_De_Bruijn_graph_snippet.cpp), blmx_stream.hip
+struct Payload {
+	Index* ix = nullptr;
+	int kind = 0;           // 0 = abundance (uint8 per k-mer), 1 = colours (bit matrix, ncolors bits per k-mer)
+	uint32_t ncolors = 1;
+	uint64_t nids = 0;      // number_kmer of the index
+	uint64_t bytes = 0;     // payload size in bytes (device buffer is padded to 4)
+	DevBuf data;
+};
+void payload_init(Payload& pl);
+void payload_add_ids(Payload& pl, const int64_t* d_ids, uint64_t n, uint32_t color, hipStream_t s);
+void payload_add_file(Payload& pl, const char* path, uint32_t color, uint64_t& found, uint64_t& absent);
 // index image on disk (blmx_stream.hip)
 void save_index(Index& ix, const char* path);
 void load_index(Index& ix, const char* path);

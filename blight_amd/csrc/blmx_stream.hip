@@ -51,6 +51,17 @@ public:
 		}
 	}
 
+	// next line that starts with A/C/G/T (the payload snippets treat every such LINE as a sequence, whatever the record
+	// structure: Colored_De_Bruijn_graph_snippet.cpp:139); false at end of file
+	bool next_acgt_line(const char*& p, size_t& len)
+	{
+		while (next_line(p, len)) {
+			if (len && (p[0] == 'A' || p[0] == 'C' || p[0] == 'G' || p[0] == 'T'))
+				return true;
+		}
+		return false;
+	}
+
 private:
 	static constexpr size_t kChunk = 8u << 20;
 	gzFile f_;
@@ -375,8 +386,76 @@ void load_index(Index& ix, const char* path)
 	ix.built = true;
 }
 
-// file_query: returns good / erroneous k-mer counts (the reference prints them: "Good kmer", "Erroneous kmers").
-void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous)
+// ---- payload kernels --------------------------------------------------------------------------------------------------
+// abundance[id]++ on uint8 counters (Abundance_De_Bruijn_graph_snippet.cpp:147-150: wraps at 256 like the reference's
+// uint8_t): four counters share a 32-bit word, the increment is a CAS on the word that touches only its own byte.
+__global__ __launch_bounds__(256) void k_payload_abundance(const int64_t* __restrict__ ids, uint64_t n, uint32_t* __restrict__ words)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const int64_t id = ids[i];
+	if (id < 0)
+		return;
+	uint32_t* w = &words[(uint64_t)id >> 2];
+	const uint32_t sh = 8u * ((uint32_t)id & 3u);
+	uint32_t old = *w, assumed;
+	do {
+		assumed = old;
+		const uint32_t nb = ((assumed >> sh) + 1u) & 0xffu;
+		old = atomicCAS(w, assumed, (assumed & ~(0xffu << sh)) | (nb << sh));
+	} while (old != assumed);
+}
+
+// color_me_amaze[id * color_number + i_file] = true (Colored_De_Bruijn_graph_snippet.cpp:146-150); bit index order of the
+// reference's vector<bool>, 32 bits per word, least significant first.
+__global__ __launch_bounds__(256) void k_payload_color(const int64_t* __restrict__ ids, uint64_t n, uint32_t color, uint32_t ncolors,
+                                                       uint32_t* __restrict__ bits)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const int64_t id = ids[i];
+	if (id < 0)
+		return;
+	const uint64_t bit = (uint64_t)id * ncolors + color;
+	atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
+}
+
+void payload_init(Payload& pl)
+{
+	Index& ix = *pl.ix;
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	if (pl.kind != 0 && pl.kind != 1)
+		throw StatusError{BLMX_EINVAL, "payload kind must be 0 (abundance) or 1 (colours)"};
+	if (pl.kind == 1 && pl.ncolors == 0)
+		throw StatusError{BLMX_EINVAL, "a colour payload needs at least one colour"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	pl.nids = ix.st.number_kmer;
+	pl.bytes = pl.kind == 0 ? pl.nids : (pl.nids * pl.ncolors + 7) / 8;
+	BLMX_HIP(pl.data.alloc((pl.bytes + 3) / 4 * 4 + 4, true, ix.stream));
+	BLMX_HIP(hipStreamSynchronize(ix.stream));
+}
+
+void payload_add_ids(Payload& pl, const int64_t* d_ids, uint64_t n, uint32_t color, hipStream_t s)
+{
+	if (n == 0)
+		return;
+	if (pl.kind == 1 && color >= pl.ncolors)
+		throw StatusError{BLMX_EINVAL, "colour out of range"};
+	const unsigned grid = (unsigned)((n + 255) / 256);
+	if (pl.kind == 0)
+		hipLaunchKernelGGL(k_payload_abundance, dim3(grid), dim3(256), 0, s, d_ids, n, pl.data.as<uint32_t>());
+	else
+		hipLaunchKernelGGL(k_payload_color, dim3(grid), dim3(256), 0, s, d_ids, n, color, pl.ncolors, pl.data.as<uint32_t>());
+	BLMX_HIP(hipGetLastError());
+}
+
+// The streaming front end shared by file_query (2-line FASTA records, blight.cpp:760-775) and the payload applications
+// (every line that starts with A/C/G/T): parse | H2D | rolling k-mers -> query pipeline -> on-device counters
+// [-> payload update], two pinned batches in flight.
+static void stream_file(Index& ix, const char* path, bool acgt_lines, Payload* payload, uint32_t color, uint64_t& good, uint64_t& erroneous)
 {
 	if (!ix.built)
 		throw StatusError{BLMX_ESTATE, "index not built"};
@@ -419,7 +498,7 @@ void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous
 		b.total = 0;
 		b.h_seq.ensure(kBatchBytes + (1u << 20));
 		while (b.total < kBatchBytes) {
-			more = rd.next_sequence(p, len);
+			more = acgt_lines ? rd.next_acgt_line(p, len) : rd.next_sequence(p, len);
 			if (!more)
 				break;
 			if (len < k)  // blight.cpp:782: shorter than k -> skipped
@@ -455,6 +534,8 @@ void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous
 		hipLaunchKernelGGL(k_count_found, dim3((unsigned)((b.nk + 255) / 256)), dim3(256), 0, b.s, b.d_ids.as<int64_t>(), b.nk,
 		                   b.d_counts.as<unsigned long long>());
 		BLMX_HIP(hipGetLastError());
+		if (payload)
+			payload_add_ids(*payload, b.d_ids.as<int64_t>(), b.nk, color, b.s);
 		BLMX_HIP(hipMemcpyAsync(b.h_counts.p, b.d_counts.p, 16, hipMemcpyDeviceToHost, b.s));
 		BLMX_HIP(hipMemcpyAsync(b.h_counts.as<uint64_t>() + 2, b.d_err.p, 4, hipMemcpyDeviceToHost, b.s));
 		BLMX_HIP(hipEventRecord(b.done, b.s));
@@ -464,6 +545,16 @@ void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous
 	retire(batch[0]);
 	retire(batch[1]);
 	ix.st.number_query += queries;
+}
+
+// file_query: returns good / erroneous k-mer counts (the reference prints them: "Good kmer", "Erroneous kmers").
+void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous) { stream_file(ix, path, false, nullptr, 0, good, erroneous); }
+
+void payload_add_file(Payload& pl, const char* path, uint32_t color, uint64_t& found, uint64_t& absent)
+{
+	if (pl.kind == 1 && color >= pl.ncolors)
+		throw StatusError{BLMX_EINVAL, "colour out of range"};
+	stream_file(*pl.ix, path, true, &pl, color, found, absent);
 }
 
 }  // namespace blmx

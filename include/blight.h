@@ -199,6 +199,44 @@ public:
 
 	blmx_index* handle() const { return _h; }
 
+	// Payload applications (reference Colored_/Abundance_De_Bruijn_graph_snippet.cpp): a per-k-mer array in HBM keyed by the
+	// IDs of this index, updated on the device while a file streams through the query pipeline.
+	class payload {
+	public:
+		enum kind_t { abundance = 0, colors = 1 };
+		payload(kmer_Set_Light& ksl, kind_t kind, uint32_t ncolors = 1) : _ksl(ksl), _ncolors(kind == abundance ? 1 : ncolors)
+		{
+			_ksl.check(blmx_payload_create(_ksl._h, (int)kind, _ncolors, &_p));
+		}
+		payload(const payload&) = delete;
+		payload& operator=(const payload&) = delete;
+		~payload() { blmx_payload_destroy(_p); }
+		// every line of the file that starts with A/C/G/T is a sequence (snippet :139); returns k-mers found in the index
+		uint64_t add_file(const std::string& path, uint32_t color = 0)
+		{
+			uint64_t found = 0, absent = 0;
+			_ksl.check(blmx_payload_add_file(_p, path.c_str(), color, &found, &absent));
+			_ksl.number_query += found + absent;
+			return found;
+		}
+		// abundance: one byte per k-mer ID; colours: bit (id * ncolors + color), least significant bit first
+		std::vector<uint8_t> to_host()
+		{
+			const int64_t n = blmx_payload_export(_p, nullptr, 0);
+			if (n < 0)
+				_ksl.check((int)n);
+			std::vector<uint8_t> v((size_t)n);
+			blmx_payload_export(_p, v.data(), (uint64_t)n);
+			return v;
+		}
+		uint32_t ncolors() const { return _ncolors; }
+
+	private:
+		kmer_Set_Light& _ksl;
+		blmx_payload* _p = nullptr;
+		uint32_t _ncolors;
+	};
+
 private:
 	blmx_index* _h = nullptr;
 	blmx_stats_t _st{};

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
  * so a stale caller binary is detected instead of corrupting memory. */
-#define BLMX_ABI_VERSION 6
+#define BLMX_ABI_VERSION 7
 
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
@@ -124,6 +124,22 @@ int blmx_query_file(blmx_index* ix, const char* path, uint64_t* good_out, uint64
 int blmx_save(blmx_index* ix, const char* path);
 int blmx_load(blmx_index* ix, const char* path);
 int blmx_peek_params(const char* path, blmx_params* out);
+/* Payload applications (reference Colored_De_Bruijn_graph_snippet.cpp:113-157 and
+ * Abundance_De_Bruijn_graph_snippet.cpp:117-157): a per-k-mer payload in HBM keyed by the IDs of this index.
+ *   kind 0 = abundance: one uint8 counter per k-mer, ++ per occurrence, wrapping at 256 like the reference's uint8_t;
+ *   kind 1 = colours:   ncolors bits per k-mer; bit (id * ncolors + color) in the reference's vector<bool> order.
+ * blmx_payload_add_file streams `path` (plain or gzip) through the GPU like blmx_query_file, but -- like the snippets --
+ * takes every LINE that starts with A/C/G/T as a sequence; lines shorter than k contribute nothing; the update is done
+ * on the device (no ID crosses PCIe).  found_out / absent_out (may be NULL) = k-mers with ID >= 0 / < 0.
+ * blmx_payload_add_ids_device applies IDs that are already in HBM (asynchronous on `stream`).
+ * blmx_payload_export copies the payload to the host (abundance: number_kmer bytes; colours: ceil(number_kmer*ncolors/8)
+ * bytes, least significant bit first) and returns its size in bytes. */
+typedef struct blmx_payload blmx_payload;
+int blmx_payload_create(blmx_index* ix, int kind, uint32_t ncolors, blmx_payload** out);
+void blmx_payload_destroy(blmx_payload* p);
+int blmx_payload_add_file(blmx_payload* p, const char* path, uint32_t color, uint64_t* found_out, uint64_t* absent_out);
+int blmx_payload_add_ids_device(blmx_payload* p, const int64_t* d_ids, uint64_t n, uint32_t color, void* stream);
+int64_t blmx_payload_export(blmx_payload* p, void* out, uint64_t cap_bytes);
 /* number of IDs blmx_query_sequences writes for these offsets */
 uint64_t blmx_sequence_kmer_count(const blmx_index* ix, const uint64_t* offsets, uint64_t nseq);
 
