@@ -197,12 +197,7 @@ int blmx_build_from_fasta(blmx_index* h, const char* path)
 {
 	if (!h || !path)
 		return BLMX_EINVAL;
-	std::string concat;
-	std::vector<uint64_t> offs;
-	const int rc = read_fasta_records(path, concat, offs);
-	if (rc)
-		return fail(h, rc, "Problem with files opening");  // blight.cpp:188-189
-	return guarded(h, [&] { build_host(h, concat.data(), offs.data(), offs.size() - 1); });
+	return guarded(h, [&] { build_from_fasta_streamed(h->ix, path); });
 }
 
 int blmx_build_from_sequences(blmx_index* h, const char* concat, const uint64_t* offsets, uint64_t nseq)

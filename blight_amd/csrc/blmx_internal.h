@@ -259,8 +259,8 @@ void launch_route_scatter(const Index& ix, const void* d_kmers, const uint8_t* d
                           void* d_sorted, uint32_t* d_order, uint64_t* d_cursor, hipStream_t s);
 void launch_unpermute(const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, hipStream_t s);
 // streaming front end (blmx_stream.hip)
-int read_fasta_records(const char* path, std::string& concat, std::vector<uint64_t>& offs);
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);
+void build_from_fasta_streamed(Index& ix, const char* path);
 // payload applications on top of the IDs (reference Colored_/Abundance_De_Bruijn_graph_snippet.cpp), blmx_stream.hip
 struct Payload {
 	Index* ix = nullptr;

@@ -7,6 +7,7 @@
 // comes back over PCIe.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -116,21 +117,6 @@ private:
 	}
 };
 
-int read_fasta_records(const char* path, std::string& concat, std::vector<uint64_t>& offs)
-{
-	RecordReader rd(path);
-	if (!rd.ok())
-		return BLMX_EIO;
-	offs.assign(1, 0);
-	const char* p;
-	size_t len;
-	while (rd.next_sequence(p, len)) {
-		concat.append(p, len);
-		offs.push_back(concat.size());
-	}
-	return BLMX_OK;
-}
-
 // ---- on-device recap counters ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_count_found(const int64_t* __restrict__ ids, uint64_t n, unsigned long long* __restrict__ counts)
 {
@@ -194,6 +180,99 @@ void grow(DevBuf& b, size_t bytes, hipStream_t s)
 }
 
 }  // namespace
+
+// ---- streaming ingest for construction (reference blight.cpp:212-229 reads line by line) ---------------------
+// The host only parses: sequence lines are packed into two pinned 64 MiB buffers that leave for HBM with asynchronous
+// copies while the next chunk is being parsed, so the H2D transfer hides behind the (host-bound) parse and no pageable
+// whole-file copy of the input is ever made.  The device buffer starts at the file size (an upper bound for a plain file;
+// a guess for gzip) and doubles with a device-to-device copy when it runs out.
+void build_from_fasta_streamed(Index& ix, const char* path)
+{
+	if (ix.built)
+		throw StatusError{BLMX_ESTATE, "index already built"};
+	RecordReader rd(path);
+	if (!rd.ok())
+		throw StatusError{BLMX_EIO, "Problem with files opening"};  // blight.cpp:188-189
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	uint64_t file_bytes = 0;
+	bool gz = false;
+	if (FILE* f = fopen(path, "rb")) {
+		unsigned char magic[2] = {0, 0};
+		gz = fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+		if (fseek(f, 0, SEEK_END) == 0)
+			file_bytes = (uint64_t)ftell(f);
+		fclose(f);
+	}
+	constexpr size_t kChunk = 64u << 20;
+	hipStream_t s = nullptr;
+	BLMX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	struct StreamGuard {
+		hipStream_t s;
+		~StreamGuard() { (void)hipStreamDestroy(s); }
+	} guard{s};
+	Pinned pin[2];
+	hipEvent_t sent[2] = {nullptr, nullptr};
+	struct EventGuard {
+		hipEvent_t* e;
+		~EventGuard()
+		{
+			for (int i = 0; i < 2; i++)
+				if (e[i])
+					(void)hipEventDestroy(e[i]);
+		}
+	} eguard{sent};
+	for (int i = 0; i < 2; i++) {
+		pin[i].ensure(kChunk);
+		BLMX_HIP(hipEventCreateWithFlags(&sent[i], hipEventDisableTiming));
+	}
+	DevBuf d_ascii, d_offs;
+	BLMX_HIP(d_ascii.alloc(std::max<uint64_t>(gz ? file_bytes * 5 : file_bytes + 64, kChunk) + 64, false, s));
+	std::vector<uint64_t> offs(1, 0);
+	uint64_t total = 0;  // bytes already on their way to the device
+	size_t fill = 0;
+	int cur = 0;
+	bool busy[2] = {false, false};
+	auto flush = [&] {
+		if (fill == 0)
+			return;
+		if (total + fill + 64 > d_ascii.bytes) {  // grow: double, copy what is there (stream-ordered), drop the old block
+			DevBuf bigger;
+			BLMX_HIP(bigger.alloc(std::max<uint64_t>(2 * d_ascii.bytes, total + fill + 64), false, s));
+			BLMX_HIP(hipMemcpyAsync(bigger.p, d_ascii.p, total, hipMemcpyDeviceToDevice, s));
+			BLMX_HIP(hipStreamSynchronize(s));
+			std::swap(bigger.p, d_ascii.p);
+			std::swap(bigger.bytes, d_ascii.bytes);
+		}
+		BLMX_HIP(hipMemcpyAsync((char*)d_ascii.p + total, pin[cur].p, fill, hipMemcpyHostToDevice, s));
+		BLMX_HIP(hipEventRecord(sent[cur], s));
+		busy[cur] = true;
+		total += fill;
+		fill = 0;
+		cur ^= 1;
+		if (busy[cur]) {  // the other buffer is about to be overwritten
+			BLMX_HIP(hipEventSynchronize(sent[cur]));
+			busy[cur] = false;
+		}
+	};
+	const char* p;
+	size_t len;
+	while (rd.next_sequence(p, len)) {
+		if (fill + len > pin[cur].bytes) {
+			flush();
+			pin[cur].ensure(len);  // a single sequence longer than the chunk
+		}
+		memcpy(pin[cur].as<char>() + fill, p, len);
+		fill += len;
+		offs.push_back(total + fill);
+	}
+	flush();
+	const uint64_t nseq = offs.size() - 1;
+	BLMX_HIP(d_offs.alloc((nseq + 1) * 8, false, s));
+	BLMX_HIP(hipMemcpyAsync(d_offs.p, offs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	build_from_device(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), nseq, total);
+	ix.built = true;
+}
 
 // ---- index image on disk (the fork has no dump/load; mainline Blight's dump_disk / load constructor is the model) --
 // Layout: FileHeader, shard bounds (u32 x nbounds), fallback group tags (u32 x nfb), then the seven HBM arrays exactly as they
