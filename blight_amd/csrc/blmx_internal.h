@@ -240,7 +240,7 @@ void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs
 // 2 = membership byte.  d_minis == nullptr -> minimizers are computed on the device.
 enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2, kQueryXcdMajor = 0x100 /* flag: XCD-major block order */ };
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
-                  hipStream_t s, const uint32_t* d_out_index = nullptr);
+                  hipStream_t s);
 // Large batches: partition the queries by the top bits of their minimizer first (one counting pass), run the query
 // kernel on the partitioned batch, gather the IDs back into the caller's order.
 void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s);

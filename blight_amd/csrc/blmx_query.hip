@@ -224,7 +224,7 @@ __device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uin
 template <int KW, int LOGP, bool WANT_POS>
 __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t* __restrict__ kmers,
                                                const uint32_t* __restrict__ minis, uint64_t nq, void* __restrict__ out,
-                                               int mode, const uint32_t* __restrict__ oidx)
+                                               int mode)
 {
 	// kQueryXcdMajor (batch partitioned by minimizer): workgroup b runs on XCD b % 8, each XCD has its own L2.  Give XCD x
 	// the x-th contiguous eighth of the batch, so that one bin's slice of the index is cached by ONE L2 instead of being
@@ -271,9 +271,7 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 			posj = (int32_t)(pos + (uint64_t)j);  // blight.cpp:706
 		}
 	} while (0);
-	// oidx: the batch was partitioned for locality; the answer goes straight to the caller's slot (a fire-and-forget
-	// scattered 8-B store that overlaps with the kernel's memory latency instead of a separate gather pass)
-	const uint64_t o = oidx ? (uint64_t)oidx[i] : i;
+	const uint64_t o = i;
 	if (mode == kQueryIds)
 		reinterpret_cast<int64_t*>(out)[o] = id;
 	else if (mode == kQueryPos)
@@ -286,7 +284,7 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 template <int KW>
 __global__ __launch_bounds__(256) void k_query_anyb(DeviceIndexView v, const uint64_t* __restrict__ kmers,
                                                     const uint32_t* __restrict__ minis, uint64_t nq, void* __restrict__ out,
-                                                    int mode, const uint32_t* __restrict__ oidx)
+                                                    int mode)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq)
@@ -325,9 +323,7 @@ __global__ __launch_bounds__(256) void k_query_anyb(DeviceIndexView v, const uin
 			}
 		}
 	} while (0);
-	// oidx: the batch was partitioned for locality; the answer goes straight to the caller's slot (a fire-and-forget
-	// scattered 8-B store that overlaps with the kernel's memory latency instead of a separate gather pass)
-	const uint64_t o = oidx ? (uint64_t)oidx[i] : i;
+	const uint64_t o = i;
 	if (mode == kQueryIds)
 		reinterpret_cast<int64_t*>(out)[o] = id;
 	else if (mode == kQueryPos)
@@ -576,7 +572,7 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)(
 
 template <int KW>
 static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, int mode,
-                            hipStream_t s, const uint32_t* d_oidx)
+                            hipStream_t s)
 {
 	const DeviceIndexView v = ix.view();
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
@@ -588,9 +584,9 @@ static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t
 #define BLMX_Q(LP)                                                                                  \
 	case LP:                                                                                        \
 		if ((mode & 0xff) == (int)kQueryPos)                                                        \
-			hipLaunchKernelGGL((k_query<KW, LP, true>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode, d_oidx);  \
+			hipLaunchKernelGGL((k_query<KW, LP, true>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode);  \
 		else                                                                                        \
-			hipLaunchKernelGGL((k_query<KW, LP, false>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode, d_oidx); \
+			hipLaunchKernelGGL((k_query<KW, LP, false>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode); \
 		break;
 	switch (v.b) {
 		BLMX_Q(0)
@@ -603,21 +599,21 @@ static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t
 		BLMX_Q(7)
 		BLMX_Q(8)
 	default:
-		hipLaunchKernelGGL((k_query_anyb<KW>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode, d_oidx);
+		hipLaunchKernelGGL((k_query_anyb<KW>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode);
 		break;
 	}
 #undef BLMX_Q
 }
 
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
-                  hipStream_t s, const uint32_t* d_oidx)
+                  hipStream_t s)
 {
 	if (nq == 0)
 		return;
 	if (ix.KW == 1)
-		launch_query_kw<1>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s, d_oidx);
+		launch_query_kw<1>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s);
 	else
-		launch_query_kw<2>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s, d_oidx);
+		launch_query_kw<2>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s);
 	BLMX_HIP(hipGetLastError());
 }
 

@@ -59,8 +59,13 @@ class DeviceOps:
 
     def unpermute(self, vals, inv):
         out = self.empty_ids(vals.shape[0])
-        self.ix.gather_ids_device(vals.data_ptr(), inv.data_ptr(), vals.shape[0], out.data_ptr(), self._stream())
+        self.unpermute_into(out, vals, inv)
         return out
+
+    def unpermute_into(self, out, vals, inv):
+        """out[i] = vals[inv[i]] written straight into `out` (a contiguous slice of the caller's result)"""
+        assert out.is_contiguous() and out.shape[0] == vals.shape[0]
+        self.ix.gather_ids_device(vals.data_ptr(), inv.data_ptr(), vals.shape[0], out.data_ptr(), self._stream())
 
 
 class ShardedQuerier:
@@ -85,20 +90,61 @@ class ShardedQuerier:
         else:
             dist.all_to_all_single(out, inp, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
 
-    def query(self, kmers):
+    def query(self, kmers, chunks=None):
+        """IDs of `kmers` in the caller's order.
+
+        The batch is cut into `chunks` consecutive pieces (default: env BLIGHT_DIST_CHUNKS or 2; 1 when the collectives
+        are host-staged) that go through partition -> exchange -> query -> exchange -> gather as a software pipeline:
+        all pieces are partitioned first and their per-owner counts travel in ONE small all-to-all (one host sync), then
+        every piece's k-mer exchange is issued asynchronously, so that piece c + 1 is on the links while the owner answers
+        piece c, and the IDs of piece c travel back while piece c + 1 is being answered.  The collectives are issued in
+        the same order on every rank (k-mers 0..C-1 interleaved with IDs 0..C-1 as the loop below shows)."""
         world = self.world
-        sorted_k, order, counts = self.ops.route(kmers, self.bounds, world)
-        # counts exchange: how many k-mers every peer sends me
-        recv_counts = torch.empty_like(counts)
-        self._a2a(recv_counts, counts)
-        send_split = [int(x) for x in counts.tolist()]
-        recv_split = [int(x) for x in recv_counts.tolist()]
-        # k-mers out (all-to-all-v; order-preserving per pair, so no index travels)
-        recv_k = self.ops.empty_kmers(sum(recv_split))
-        self._a2a(recv_k, sorted_k, recv_split, send_split)
-        # the owner answers
-        ids_remote = self.ops.query(recv_k)
-        # IDs back
-        ids_sorted = self.ops.empty_ids(sum(send_split))
-        self._a2a(ids_sorted, ids_remote, send_split, recv_split)
-        return self.ops.unpermute(ids_sorted, order)
+        n = kmers.shape[0]
+        if chunks is None:
+            chunks = 1 if self.host_staging else int(os.environ.get("BLIGHT_DIST_CHUNKS", "2"))
+        chunks = max(1, int(chunks))  # the same on every rank, whatever the local batch size (pieces may be empty)
+        cuts = [(n * c) // chunks for c in range(chunks + 1)]
+        parts = [self.ops.route(kmers[cuts[c]:cuts[c + 1]], self.bounds, world) for c in range(chunks)]
+        # counts of all pieces in one exchange: row r of the send matrix = what I send to rank r, piece by piece
+        send_counts = torch.stack([p[2] for p in parts], dim=1).contiguous()  # (world, chunks)
+        recv_counts = torch.empty_like(send_counts)
+        self._a2a(recv_counts.view(-1), send_counts.view(-1))
+        send_split = send_counts.tolist()
+        recv_split = recv_counts.tolist()
+        out = self.ops.empty_ids(n)
+        if self.host_staging or chunks == 1:
+            for c in range(chunks):
+                ss = [int(send_split[r][c]) for r in range(world)]
+                rs = [int(recv_split[r][c]) for r in range(world)]
+                recv_k = self.ops.empty_kmers(sum(rs))
+                self._a2a(recv_k, parts[c][0], rs, ss)
+                ids_remote = self.ops.query(recv_k)
+                ids_sorted = self.ops.empty_ids(sum(ss))
+                self._a2a(ids_sorted, ids_remote, ss, rs)
+                self._unpermute_into(out[cuts[c]:cuts[c + 1]], ids_sorted, parts[c][1])
+            return out
+        ss = [[int(send_split[r][c]) for r in range(world)] for c in range(chunks)]
+        rs = [[int(recv_split[r][c]) for r in range(world)] for c in range(chunks)]
+        recv_k = [self.ops.empty_kmers(sum(rs[c])) for c in range(chunks)]
+        ids_sorted = [self.ops.empty_ids(sum(ss[c])) for c in range(chunks)]
+        ids_remote = [None] * chunks
+        w_k = [None] * chunks
+        w_i = [None] * chunks
+        w_k[0] = dist.all_to_all_single(recv_k[0], parts[0][0], rs[0], ss[0], group=self.group, async_op=True)
+        for c in range(chunks):
+            if c + 1 < chunks:  # the next piece's k-mers travel while this piece is answered
+                w_k[c + 1] = dist.all_to_all_single(recv_k[c + 1], parts[c + 1][0], rs[c + 1], ss[c + 1], group=self.group, async_op=True)
+            w_k[c].wait()
+            ids_remote[c] = self.ops.query(recv_k[c])
+            w_i[c] = dist.all_to_all_single(ids_sorted[c], ids_remote[c], ss[c], rs[c], group=self.group, async_op=True)
+        for c in range(chunks):
+            w_i[c].wait()
+            self._unpermute_into(out[cuts[c]:cuts[c + 1]], ids_sorted[c], parts[c][1])
+        return out
+
+    def _unpermute_into(self, out_slice, vals, order):
+        if hasattr(self.ops, "unpermute_into"):
+            self.ops.unpermute_into(out_slice, vals, order)
+        else:
+            out_slice.copy_(self.ops.unpermute(vals, order))

@@ -87,6 +87,10 @@ def _worker(rank, world, port, q):
         # uneven / empty batches
         got0 = sq.query(torch.from_numpy(kmers[: (5 if rank == 0 else 0)].view(np.int64).reshape(-1, 1).copy()))
         ok = ok and np.array_equal(got0.numpy(), want[: (5 if rank == 0 else 0)])
+        # the software pipeline with 1 (synchronous path) and 3 pieces gives the same answers
+        for chunks in (1, 3):
+            gc = sq.query(torch.from_numpy(kmers.view(np.int64).reshape(-1, 1).copy()), chunks=chunks)
+            ok = ok and bool(np.array_equal(gc.numpy(), want))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

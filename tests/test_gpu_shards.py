@@ -119,3 +119,66 @@ def test_routing_kernels_by_destination():
     od = np.searchsorted(bounds[1:], og.cpu().numpy(), side="right")
     assert np.all(np.diff(od) >= 0)  # owner-major
     assert torch.equal(ordered[inv.long()], q)
+
+
+_NCCL_WORLD1 = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["BLIGHT_ROOT"])
+import blight_amd as B
+from blight_amd.dist import DeviceOps, ShardedQuerier
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", os.environ["BLIGHT_PORT"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+rng = np.random.default_rng(3)
+k, m, n, b = 31, 9, 7, 6
+seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, 30 + int(rng.geometric(1 / 80)))) for _ in range(4000)]
+ix = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ix.set_shard(0, 1)
+ix.construct_index_from_sequences(seqs)
+q = torch.from_numpy(rng.integers(0, 1 << 62, size=(300000, 1), dtype=np.uint64).view(np.int64)).to(dev)
+s = torch.cuda.current_stream().cuda_stream
+ix.canonicalize_device(q.data_ptr(), q.shape[0], s)
+# half of the batch: k-mers of the index itself (first k-mer of every sequence)
+ascii_ = torch.frombuffer(bytearray("".join(seqs).encode()), dtype=torch.uint8).to(dev)
+starts = torch.from_numpy(np.cumsum([0] + [len(x) for x in seqs[:-1]]).astype(np.int64)).to(dev)
+pk = torch.empty((starts.numel(), 1), device=dev, dtype=torch.int64)
+err = torch.zeros(1, device=dev, dtype=torch.int32)
+ix.kmers_at_device(ascii_.data_ptr(), starts.data_ptr(), starts.numel(), pk.data_ptr(), err.data_ptr(), s)
+q = torch.cat([q, pk])[torch.randperm(q.shape[0] + pk.shape[0], device=dev)].contiguous()
+want = torch.empty(q.shape[0], device=dev, dtype=torch.int64)
+ix.query_kmers_device(q.data_ptr(), q.shape[0], want.data_ptr(), s)
+bounds = torch.from_numpy(ix.shard_bounds().astype(np.int32)).to(dev)
+sq = ShardedQuerier(DeviceOps(ix, dev), bounds)
+for chunks in (1, 2, 3):
+    got = sq.query(q, chunks=chunks)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), chunks
+assert int((want >= 0).sum().item()) >= len(seqs)
+dist.destroy_process_group()
+print("NCCL-WORLD1-OK")
+"""
+
+
+def test_sharded_querier_on_rccl_world1(tmp_path):
+    """The pipelined exchange (asynchronous all_to_all_single on the `nccl` = RCCL backend interleaved with the HIP kernels
+    on torch's current stream) with a world of ONE rank on the one GPU of the test box: the collectives degenerate to
+    device copies, but the stream choreography is the production one."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "world1.py"
+    script.write_text(_NCCL_WORLD1)
+    import os
+    env = dict(os.environ, BLIGHT_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), BLIGHT_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "NCCL-WORLD1-OK" in r.stdout, r.stderr[-2000:]
