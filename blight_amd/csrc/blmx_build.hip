@@ -806,7 +806,13 @@ __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, co
 	__shared__ uint64_t s_ks[kSkPerBlock + 1];
 	__shared__ uint64_t s_pos0[kSkPerBlock];
 	__shared__ uint32_t s_mini[kSkPerBlock];
-	const uint64_t j0 = (uint64_t)blockIdx.x * kSkPerBlock;
+	// XCD-major block order (workgroup b runs on XCD b % 8; the grid is a multiple of 8): XCD x takes the x-th contiguous
+	// eighth of the sorted super-k-mers, so that the ~600 KB rank range a group's scattered 4-B stores fall into is owned by
+	// ONE L2, which merges them into full lines, instead of being written in pieces from all eight (90 -> 65 ms at C4)
+	const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+	const uint64_t j0 = (uint64_t)blk * kSkPerBlock;
+	if (j0 >= nsk)
+		return;
 	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, nsk - j0);
 	for (uint32_t t = threadIdx.x; t <= nj; t += kBlock)
 		s_ks[t] = key_start[j0 + t];
@@ -1483,7 +1489,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		DevBuf d_field;  // position field of every local rank (ranks nobody owns -- overwritten duplicates -- stay 0 like in the reference)
 		BLMX_HIP(d_field.alloc((N + 1) * 4, true, s));
 		if (nsk)
-			hipLaunchKernelGGL((k_fill_positions<KW>), dim3(grid_for(nsk, kSkPerBlock)), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
+			hipLaunchKernelGGL((k_fill_positions<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
 			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>());
 		if (F)
 			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint32_t>(), F,
