@@ -676,14 +676,15 @@ int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
 
 int blmx_primitive(int op, int kmer_bytes, const void* in, uint64_t n, int arg, int arg2, void* out)
 {
-	if (!in || !out || (kmer_bytes != 8 && kmer_bytes != 16) || op < 0 || op > 6)
+	if (!in || !out || (kmer_bytes != 8 && kmer_bytes != 16) || op < 0 || op > 7 || (op == 7 && (arg2 < 0 || arg2 > kmer_bytes)))
 		return BLMX_EINVAL;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
 		return BLMX_EHIP;
 	return guarded(nullptr, [&] {
-		const size_t in_elem = (op <= 2) ? 4 : (op == 3 || op == 4) ? (size_t)kmer_bytes : (op == 5 ? 8 : 1);
-		const size_t out_elem = (op == 0 || op == 1 || op == 2 || op == 4) ? 4 : (op == 3 ? (size_t)kmer_bytes : (op == 5 ? 8 * kLevels : 1));
+		const size_t in_elem = (op <= 2) ? 4 : (op == 3 || op == 4 || op == 7) ? (size_t)kmer_bytes : (op == 5 ? 8 : 1);
+		const size_t out_elem =
+		    (op == 0 || op == 1 || op == 2 || op == 4) ? 4 : (op == 3 ? (size_t)kmer_bytes : (op == 5 ? 8 * kLevels : (op == 7 ? 16 : 1)));
 		DevBuf d_in, d_out;
 		BLMX_HIP(d_in.alloc(n * in_elem + 16, false, nullptr));
 		BLMX_HIP(d_out.alloc(n * out_elem + 16, false, nullptr));

@@ -553,6 +553,13 @@ __global__ void k_primitive(int op, const void* __restrict__ in, uint64_t n, int
 		reinterpret_cast<uint32_t*>(out)[i] = kmer_minimizer<KW>(x, kmer_rc<KW>(x, arg), arg, arg2);
 		break;
 	}
+	case 7: {  // MurmurHash3_x64_128 of the first arg2 (0: all) bytes of record i (8 * KW bytes each), seed = arg
+		uint64_t h[2];
+		murmur3_x64_128(reinterpret_cast<const uint8_t*>(in) + i * 8 * KW, arg2 > 0 ? arg2 : 8 * KW, (uint32_t)arg, h);
+		reinterpret_cast<uint64_t*>(out)[2 * i] = h[0];
+		reinterpret_cast<uint64_t*>(out)[2 * i + 1] = h[1];
+		break;
+	}
 	case 5: {
 		LevelHasher hs(reinterpret_cast<const uint64_t*>(in)[i]);
 		for (int l = 0; l < kLevels; l++)

@@ -205,6 +205,77 @@ struct LevelHasher {
 // fastmod64, bbhash.h:660-662
 __device__ __forceinline__ uint64_t reduce_level(uint64_t hash, uint64_t size) { return __umul64hi(hash, size); }
 
+// ---- MurmurHash3_x64_128 (Appleby; reference MurmurHash3.cpp:255-334) ---------------------------------------------------
+// Dead code in the reference (linked by nothing, the MPHF hashes are hash_bis/xorshift128+), shipped as a
+// device utility because the task names it; pinned by the known answers of SURVEY App. B-4 and, in the tests, against the
+// reference's own MurmurHash3.cpp.  `p` may be unaligned: bytes are assembled little-endian.
+__device__ __forceinline__ uint64_t murmur_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t murmur_fmix64(uint64_t k)  // MurmurHash3.cpp:81-90
+{
+	k ^= k >> 33;
+	k *= 0xff51afd7ed558ccdull;
+	k ^= k >> 33;
+	k *= 0xc4ceb9fe1a85ec53ull;
+	k ^= k >> 33;
+	return k;
+}
+__device__ __forceinline__ uint64_t murmur_le64(const uint8_t* p, int nbytes)  // nbytes <= 8
+{
+	uint64_t v = 0;
+	for (int i = 0; i < nbytes; i++)
+		v |= (uint64_t)p[i] << (8 * i);
+	return v;
+}
+__device__ inline void murmur3_x64_128(const uint8_t* p, int len, uint32_t seed, uint64_t out[2])
+{
+	const uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+	uint64_t h1 = seed, h2 = seed;
+	const int nblocks = len / 16;
+	for (int i = 0; i < nblocks; i++) {  // body, MurmurHash3.cpp:272-288
+		uint64_t k1 = murmur_le64(p + 16 * i, 8), k2 = murmur_le64(p + 16 * i + 8, 8);
+		k1 *= c1;
+		k1 = murmur_rotl64(k1, 31);
+		k1 *= c2;
+		h1 ^= k1;
+		h1 = murmur_rotl64(h1, 27);
+		h1 += h2;
+		h1 = h1 * 5 + 0x52dce729;
+		k2 *= c2;
+		k2 = murmur_rotl64(k2, 33);
+		k2 *= c1;
+		h2 ^= k2;
+		h2 = murmur_rotl64(h2, 31);
+		h2 += h1;
+		h2 = h2 * 5 + 0x38495ab5;
+	}
+	const uint8_t* tail = p + 16 * nblocks;  // tail, MurmurHash3.cpp:290-317
+	const int rem = len & 15;
+	if (rem > 8) {
+		uint64_t k2 = murmur_le64(tail + 8, rem - 8);
+		k2 *= c2;
+		k2 = murmur_rotl64(k2, 33);
+		k2 *= c1;
+		h2 ^= k2;
+	}
+	if (rem > 0) {
+		uint64_t k1 = murmur_le64(tail, rem > 8 ? 8 : rem);
+		k1 *= c1;
+		k1 = murmur_rotl64(k1, 31);
+		k1 *= c2;
+		h1 ^= k1;
+	}
+	h1 ^= (uint64_t)len;  // finalization, MurmurHash3.cpp:319-331
+	h2 ^= (uint64_t)len;
+	h1 += h2;
+	h2 += h1;
+	h1 = murmur_fmix64(h1);
+	h2 = murmur_fmix64(h2);
+	h1 += h2;
+	h2 += h1;
+	out[0] = h1;
+	out[1] = h2;
+}
+
 // ---- wave helpers (wave64) -----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

@@ -519,6 +519,59 @@ void orc_p_level_hashes(uint64_t key, unsigned nlevels, uint64_t *out)
 		out[l] = orc_level_hash_step(key, &s0, &s1, l);
 }
 uint64_t orc_p_mulhi64(uint64_t a, uint64_t b) { return orc_mulhi64(a, b); }
+/*
+ * MurmurHash3_x64_128 (reference MurmurHash3.cpp:255-334; Appleby, public domain).  DEAD CODE in the reference;
+ * restated because the product ships a device version of it.  Pinned by the known answers of SURVEY App. B-4 and against
+ * the reference's own MurmurHash3.cpp compiled into oracle/_ref/libmurmur3_ref.so.
+ */
+static uint64_t orc_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t orc_fmix64(uint64_t k) /* MurmurHash3.cpp:81-90 */
+{
+	k ^= k >> 33;
+	k *= 0xff51afd7ed558ccdull;
+	k ^= k >> 33;
+	k *= 0xc4ceb9fe1a85ec53ull;
+	k ^= k >> 33;
+	return k;
+}
+static uint64_t orc_le(const uint8_t *p, int nbytes)
+{
+	uint64_t v = 0;
+	for (int i = 0; i < nbytes; i++)
+		v |= (uint64_t)p[i] << (8 * i);
+	return v;
+}
+void orc_p_murmur3_x64_128(const void *key, int len, uint32_t seed, uint64_t out[2])
+{
+	const uint8_t *p = (const uint8_t *)key;
+	const uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+	uint64_t h1 = seed, h2 = seed;
+	const int nblocks = len / 16;
+	for (int i = 0; i < nblocks; i++) { /* :272-288 */
+		uint64_t k1 = orc_le(p + 16 * i, 8), k2 = orc_le(p + 16 * i + 8, 8);
+		k1 *= c1; k1 = orc_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+		h1 = orc_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+		k2 *= c2; k2 = orc_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+		h2 = orc_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+	}
+	const uint8_t *tail = p + 16 * nblocks; /* :290-317 */
+	const int rem = len & 15;
+	if (rem > 8) {
+		uint64_t k2 = orc_le(tail + 8, rem - 8);
+		k2 *= c2; k2 = orc_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+	}
+	if (rem > 0) {
+		uint64_t k1 = orc_le(tail, rem > 8 ? 8 : rem);
+		k1 *= c1; k1 = orc_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+	}
+	h1 ^= (uint64_t)len; h2 ^= (uint64_t)len; /* :319-331 */
+	h1 += h2; h2 += h1;
+	h1 = orc_fmix64(h1); h2 = orc_fmix64(h2);
+	h1 += h2; h2 += h1;
+	out[0] = h1;
+	out[1] = h2;
+}
+
 uint64_t orc_p_configure_levels(uint64_t n, uint64_t *sizes) { return orc_configure_levels(n, sizes); }
 /* str2num (kmer.h:90-98) for k <= 32; returns 0 and sets *err on an invalid character */
 uint64_t orc_p_str2num64(const char *s, int k, int *err)

@@ -37,4 +37,5 @@ fi
 CXXFLAGS="-DNDEBUG -O3 -march=x86-64-v3 -fopenmp -fPIC -shared -w"
 g++ -std=c++11 $CXXFLAGS -DREF_PATCHED_KMER_H="\"$T/p64/kmer.h\"" -I"$REF" "$HERE/ref_harness.cpp" -lz -o "$OUT/libblight_ref64.so"
 g++ -std=gnu++11 $CXXFLAGS -DREF_T128 -DREF_PATCHED_KMER_H="\"$T/p128/kmer.h\"" -I"$REF" "$HERE/ref_harness.cpp" -lz -o "$OUT/libblight_ref128.so"
-echo "built $OUT/libblight_ref64.so $OUT/libblight_ref128.so"
+g++ -std=c++11 -O2 -fPIC -shared -w -I"$REF" "$HERE/ref_murmur.cpp" "$REF/MurmurHash3.cpp" -o "$OUT/libmurmur3_ref.so"
+echo "built $OUT/libblight_ref64.so $OUT/libblight_ref128.so $OUT/libmurmur3_ref.so"

@@ -142,6 +142,8 @@ def _orc():
         lib.orc_p_mulhi64.restype = C.c_uint64
         lib.orc_p_configure_levels.argtypes = [C.c_uint64, u64p]
         lib.orc_p_configure_levels.restype = C.c_uint64
+        lib.orc_p_murmur3_x64_128.argtypes = [C.c_char_p, C.c_int, C.c_uint32, u64p]
+        lib.orc_p_murmur3_x64_128.restype = None
         lib.orc_p_str2num64.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
         lib.orc_p_str2num64.restype = C.c_uint64
         lib.orc_p_chop.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, u32p, u32p, u32p, C.c_uint64]
@@ -324,6 +326,26 @@ def p_level_hashes(key, n):
     out = (C.c_uint64 * n)()
     _orc().orc_p_level_hashes(key, n, out)
     return [int(x) for x in out]
+
+
+def p_murmur3_x64_128(data, seed=0):
+    """oracle restatement of MurmurHash3_x64_128 (reference MurmurHash3.cpp:255) -> (h1, h2)"""
+    b = bytes(data)
+    out = (C.c_uint64 * 2)()
+    _orc().orc_p_murmur3_x64_128(b, len(b), C.c_uint32(seed), out)
+    return int(out[0]), int(out[1])
+
+
+MURMUR_REF = os.path.join(HERE, "_ref", "libmurmur3_ref.so")
+
+
+def ref_murmur3_x64_128(data, seed=0):
+    """the reference's own MurmurHash3.cpp (oracle/_ref/libmurmur3_ref.so)"""
+    lib = C.CDLL(MURMUR_REF)
+    b = bytes(data)
+    out = (C.c_uint64 * 2)()
+    lib.ref_murmur3_x64_128(b, len(b), C.c_uint32(seed), out)
+    return int(out[0]), int(out[1])
 
 
 def p_configure_levels(n):

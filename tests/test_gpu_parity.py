@@ -343,3 +343,22 @@ def test_scan_filter_false_candidates(B, O, k, kb, b):
                 false_first += 1
                 break
     assert false_first > 0
+
+
+def test_device_murmur3_x64_128(B, O):
+    """device MurmurHash3_x64_128 (blmx_primitive op 7) == oracle restatement: SURVEY App. B-4 known answers and random
+    8- and 16-byte records (the k-mer widths), full and partial lengths."""
+    import struct
+    rec = np.frombuffer(struct.pack("<Q", 0x0123456789ABCDEF), dtype=np.uint8)
+    assert [int(x) for x in B.primitive(7, rec, 0, 0, 8)[0]] == [0x995bb6c03277035a, 0xa51c3d420fcd7479]
+    hello = np.frombuffer(b"hello\0\0\0", dtype=np.uint8)
+    assert [int(x) for x in B.primitive(7, hello, 42, 5, 8)[0]] == [0xc4b8b3c960af6f08, 0x2334b875b0efbc7a]
+    rng = np.random.default_rng(4)
+    for kb in (8, 16):
+        data = rng.integers(0, 256, size=(500, kb), dtype=np.uint8)
+        for length in (0, 3, kb - 1):
+            seed = int(rng.integers(0, 1 << 31))
+            got = B.primitive(7, data, seed, length, kb)
+            n = length or kb
+            want = [O.p_murmur3_x64_128(bytes(r[:n]), seed) for r in data]
+            assert [(int(a), int(b)) for a, b in got] == want

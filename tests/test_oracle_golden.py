@@ -160,3 +160,20 @@ def test_param_validation_and_errors():
     assert e.value.code == -2
     orc = O.Oracle(31, 7, 5, 6, ["ACGTTGCAACGTTGCAACGTTGCAACGTTGCA"])
     assert orc.query_sequence("ACGT").size == 0  # shorter than k: empty (blight.cpp:577-579)
+
+
+def test_murmur3_x64_128_known_answers():
+    """MurmurHash3 is dead code in the reference but named by the task: the oracle's restatement reproduces
+    the known answers of SURVEY App. B-4, and -- where oracle/_ref is present -- the reference's own MurmurHash3.cpp."""
+    import os
+    import struct
+    import numpy as np
+    from oracle import oracle as O
+    assert O.p_murmur3_x64_128(struct.pack("<Q", 0x0123456789ABCDEF), 0) == (0x995bb6c03277035a, 0xa51c3d420fcd7479)
+    assert O.p_murmur3_x64_128(b"hello", 42) == (0xc4b8b3c960af6f08, 0x2334b875b0efbc7a)
+    if os.path.exists(O.MURMUR_REF):
+        rng = np.random.default_rng(9)
+        for n in list(range(0, 40)) + [63, 64, 65, 100]:
+            data = rng.bytes(n)
+            seed = int(rng.integers(0, 1 << 32))
+            assert O.p_murmur3_x64_128(data, seed) == O.ref_murmur3_x64_128(data, seed), n

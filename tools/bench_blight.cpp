@@ -1,72 +1,82 @@
-// bench_blight.cpp -- the reference's CLI harness (reference bench_blight.cpp:37-107) on top of the facade include/blight.h:
-// same getopt flags (-g graph, -q query, -k, -m, -n, -s, -t, -b) and defaults (k=31 m=9 n=17 s=6 t=1 b=6), query file
-// defaults to the graph file, builds the index and runs file_query.  Host C++ only; all compute is in libblight_mi355x.so.
+// bench_blight.cpp -- command-line harness with the interface of the reference's tool of the same name (reference
+// bench_blight.cpp:37-107): flags -g (graph FASTA) -q (query FASTA) -k -m -n -s -t -b with the reference's defaults
+// (k 31, m 9, n 17, s 6, t 1, b 6); when only one of -g / -q is given it serves as both; the index is constructed and the
+// query file answered through the facade include/blight.h, which prints the reference's recaps.  Extensions: -d writes the
+// index image after construction, -l loads one instead of constructing.  Host C++ only; all compute is in
+// libblight_mi355x.so.
 //
 //   g++ -O2 -std=c++17 -Iinclude tools/bench_blight.cpp -o tools/bench_blight -Lblight_amd -lblight_mi355x -lz
 //       -Wl,-rpath,'$ORIGIN/../blight_amd'
 #include <unistd.h>
 
+#include <cstdio>
 #include <iostream>
+#include <map>
 #include <string>
 
 #include "blight.h"
 
-using namespace std;
+namespace {
+
+struct Options {
+	std::map<char, std::string> text;      // -g -q -d -l
+	std::map<char, unsigned> number{{'k', 31}, {'m', 9}, {'n', 17}, {'s', 6}, {'t', 1}, {'b', 6}};
+};
+
+void usage(const Options& o)
+{
+	std::printf("bench_blight (MI355X)  --  build a Blight index from unitigs and query it\n\n"
+	            "  required\n"
+	            "    -g FILE   unitig FASTA to index          (defaults to -q)\n"
+	            "    -q FILE   FASTA whose k-mers are queried (defaults to -g)\n"
+	            "    -k INT    k-mer length [%u]\n\n"
+	            "  tuning\n"
+	            "    -m INT    minimizer length, odd [%u]\n"
+	            "    -n INT    log2 of the number of MPHFs, at most 2m-1 [%u]\n"
+	            "    -b INT    position bits dropped per k-mer: a query scans 2^b positions [%u]\n"
+	            "    -s INT    log2 of the reference's temp-file count; kept for compatibility, at most n [%u]\n"
+	            "    -t INT    host threads of the reference; kept for compatibility [%u]\n\n"
+	            "  extensions\n"
+	            "    -d FILE   write the index image after construction\n"
+	            "    -l FILE   load an index image (same -k -m -n -b) instead of reading -g\n",
+	            o.number.at('k'), o.number.at('m'), o.number.at('n'), o.number.at('b'), o.number.at('s'), o.number.at('t'));
+}
+
+}  // namespace
 
 int main(int argc, char** argv)
 {
-	int ch;
-	string input, query, dump, load;
-	uint k(31), m1(9), m2(17), m3(6), c(1), bit(6);
-	while ((ch = getopt(argc, argv, "g:q:k:m:n:s:t:b:d:l:")) != -1) {
-		switch (ch) {
-		case 'q': query = optarg; break;
-		case 'g': input = optarg; break;
-		case 'k': k = stoi(optarg); break;
-		case 'm': m1 = stoi(optarg); break;
-		case 'n': m2 = stoi(optarg); break;
-		case 's': m3 = stoi(optarg); break;
-		case 't': c = stoi(optarg); break;
-		case 'b': bit = stoi(optarg); break;
-		case 'd': dump = optarg; break;  // extension: write the index image after construction
-		case 'l': load = optarg; break;  // extension: load an index image instead of constructing
-		}
+	Options opt;
+	for (int c; (c = getopt(argc, argv, "g:q:d:l:k:m:n:s:t:b:")) != -1;) {
+		if (opt.number.count((char)c))
+			opt.number[(char)c] = (unsigned)std::stoul(optarg);
+		else if (c != '?')
+			opt.text[(char)c] = optarg;
 	}
-	if (query == "" and input != "")
-		query = input;
-	if (input == "" and query != "")
-		input = query;
-	if (query == "" or input == "" or k == 0) {
-		cout << "Mandatory arguments" << endl
-		     << "\t-g graph file" << endl
-		     << "\t-q query file" << endl
-		     << "\t-k k value used for graph (" << k << ")" << endl
-		     << endl
-		     << "Performances arguments" << endl
-		     << "\t-m minimizer size (" << m1 << ")" << endl
-		     << "\t-n to create 2^n mphf (2^" << m2 << "=" << (1u << m2) << "). More mean slower construction but better index, must be <=2*m-1" << endl
-		     << "\t-s to use 2^s files (2^" << m3 << "=" << (1u << m3) << "). Accepted for compatibility (no temp files are used), must be <=n" << endl
-		     << "\t-t core used (" << c << "). Accepted for compatibility (the GPU path has no host threads)" << endl
-		     << "\t-d file: also write the index image (extension)" << endl
-		     << "\t-l file: load an index image written with the same -k -m -n -b instead of building from -g (extension)" << endl
-		     << "\t-b bit saved to encode positions (" << bit << "). Will reduce the memory usage of b bit per kmer but query have to check 2^b kmers" << endl;
+	std::string graph = opt.text['g'], reads = opt.text['q'];
+	if (graph.empty())
+		graph = reads;
+	if (reads.empty())
+		reads = graph;
+	const unsigned k = opt.number['k'], m = opt.number['m'], n = opt.number['n'], s = opt.number['s'], t = opt.number['t'], b = opt.number['b'];
+	if (graph.empty() || k == 0) {
+		usage(opt);
 		return 0;
 	}
 	try {
-		cout << "I use -g " + input + " -q " + query + " -k " + to_string(k) + " -m  " + to_string(m1) + " -n  " + to_string(m2) + " -s  " + to_string(m3) +
-		            " -t " + to_string(c) + " -b " + to_string(bit)
-		     << endl;
-		kmer_Set_Light ksl(k, m1, m2, m3, c, bit);
-		if (load != "")
-			ksl.load(load);
+		std::cout << "I use -g " << graph << " -q " << reads << " -k " << k << " -m  " << m << " -n  " << n << " -s  " << s << " -t " << t
+		          << " -b " << b << std::endl;
+		kmer_Set_Light index(k, m, n, s, t, b);
+		if (!opt.text['l'].empty())
+			index.load(opt.text['l']);
 		else
-			ksl.construct_index(input);
-		if (dump != "")
-			ksl.dump_disk(dump);
-		ksl.file_query(query);
-		cout << "I am glad you are here with me. Here at the end of all things." << endl;
+			index.construct_index(graph);
+		if (!opt.text['d'].empty())
+			index.dump_disk(opt.text['d']);
+		index.file_query(reads);
+		std::cout << "I am glad you are here with me. Here at the end of all things." << std::endl;
 	} catch (const std::exception& e) {
-		cerr << "error: " << e.what() << endl;
+		std::cerr << "error: " << e.what() << std::endl;
 		return 1;
 	}
 	return 0;
