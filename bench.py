@@ -15,7 +15,9 @@ Workload naming: C3 = chr1-scale 2.3e8 31-mers (k31 m9 n7
 
 N > 1: `--mode sharded` (default) partitions the MPHF groups (contiguous minimizer-bucket ranges) over the ranks and routes
 every query k-mer to its owner with an RCCL all-to-all over xGMI (and the IDs back); `--mode replicas` keeps a full index
-per GPU with no data-path collective (upper bound).  Per-GPU query batch is fixed: weak scaling.
+per GPU with no data-path collective (upper bound).  Per-GPU query batch is fixed: weak scaling.  A sharded run also
+measures the replicas layout right after the timed region (same batch, same timing protocol) and reports it under the
+extra key `replicas` together with `ids_equal_to_sharded`; `value` is always the sharded number.
 """
 import argparse
 import json
@@ -55,6 +57,7 @@ def parse_args():
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=4)
+    ap.add_argument("--no-replicas-leg", action="store_true", help="N > 1, sharded: skip the secondary replicas measurement")
     ap.add_argument("--present", type=float, default=0.5, help="fraction of the queries that are indexed k-mers (headline: 0.5)")
     return ap.parse_args()
 
@@ -311,7 +314,9 @@ def main():
             ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
             t_build = time.time() - t0
             st = ix.stats()
-    del ascii_
+    keep_input = querier is not None and not args.no_replicas_leg
+    if not keep_input:
+        del ascii_
 
     if querier is not None:
         def step():
@@ -343,6 +348,35 @@ def main():
         tt = torch.tensor([dt], device=("cpu" if rehearsal else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- N > 1, sharded: also report the communication-free alternative (full index on every GPU, queries split), measured the
+    # same way right after the sharded run ("report both").  `value` stays the sharded number.
+    replicas = None
+    if querier is not None and keep_input:
+        ids_sharded = ids
+        full = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
+        full.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+        del ascii_
+        ids_r = torch.empty(nq, device=dev, dtype=torch.int64)
+        for _ in range(args.warmup):
+            full.query_kmers_device(q.data_ptr(), nq, ids_r.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            full.query_kmers_device(q.data_ptr(), nq, ids_r.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tr = torch.tensor([time.perf_counter() - t0], device=("cpu" if rehearsal else dev), dtype=torch.float64)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        same = torch.tensor([1 if torch.equal(ids_r, ids_sharded) else 0], device=("cpu" if rehearsal else dev), dtype=torch.int32)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        replicas = {"value": world * nq * args.steps / float(tr.item()), "unit": "queries/s", "ms_per_step": float(tr.item()) / args.steps * 1e3,
+                    "parallelism": "replicas x%d (full index per GPU, no data-path collective)" % world,
+                    "ids_equal_to_sharded": bool(same.item())}
+        full.close()
 
     # ---- sanity: every indexed query found, no random query found, IDs in range
     found = ids >= 0
@@ -387,6 +421,8 @@ def main():
                 out["cpu_reference"] = {"value": None, "kind": "reference", "sample": "failed: %r" % (e,)}
         else:
             out["cpu_baseline"] = None
+        if replicas is not None:
+            out["replicas"] = replicas
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
