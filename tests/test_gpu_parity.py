@@ -161,6 +161,14 @@ def test_errors(B, tmp_path):
     ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
     ix.construct_index_from_sequences([])
     assert ix.number_kmer == 0 and ix.query_kmer_hash([0, 5, 77]).tolist() == [-1, -1, -1]
+    # an empty file through the streaming ingest, then a file made of blank lines only
+    for content in ("", "\n\n\n"):
+        f = tmp_path / "empty.fa"
+        f.write_text(content)
+        ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+        ix.construct_index(str(f))
+        assert ix.number_kmer == 0 and ix.query_kmer_bool([123]).tolist() == [False]
+        assert ix.file_query(str(f)) == (0, 0)
 
 
 def _rand_seq(rng, n, alphabet="ACGT"):
