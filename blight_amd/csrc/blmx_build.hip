@@ -526,7 +526,7 @@ template <int KW>
 __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, const uint64_t* __restrict__ keys, uint32_t* __restrict__ listA,
                                                                 uint32_t* __restrict__ listB, uint32_t* __restrict__ gbits32,
                                                                 uint32_t* __restrict__ fb_count, int* __restrict__ levels_max,
-                                                                const uint32_t* __restrict__ order)
+                                                                const uint32_t* __restrict__ order, uint32_t* __restrict__ bitcache)
 {
 	__shared__ uint32_t s_bits[kLdsLevelWords];
 	__shared__ uint32_t s_coll[kLdsLevelWords];
@@ -562,6 +562,8 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 				for (int l = 0; l <= level; l++)
 					h = hs.next(l);
 				const uint32_t b = (uint32_t)reduce_level(h, size);
+				if (w0 == 0)
+					bitcache[kb + i] = b;  // the survivor pass below reads the bit back instead of hashing the key again
 				const uint32_t lw = (b >> 5) - w0;
 				if (lw < wn) {
 					const uint32_t m = 1u << (b & 31);
@@ -578,11 +580,7 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 				uint32_t j = 0;
 				if (i < count) {
 					j = level == 0 ? i : cur[i];
-					LevelHasher hs(KW == 1 ? keys[kb + j] : keys[2 * (kb + j)]);
-					uint64_t h = 0;
-					for (int l = 0; l <= level; l++)
-						h = hs.next(l);
-					const uint32_t b = (uint32_t)reduce_level(h, size);
+					const uint32_t b = bitcache[kb + i];
 					const uint32_t lw = (b >> 5) - w0;
 					surv = lw < wn && ((s_coll[lw] >> (b & 31)) & 1u);
 				}
@@ -1312,7 +1310,8 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	uint64_t F_lds = 0;
 	std::vector<uint64_t> h_fboff;
 	if (n_small) {
-		DevBuf d_lA, d_lB;
+		DevBuf d_lA, d_lB, d_bitcache;
+		BLMX_HIP(d_bitcache.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_lA.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_lB.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_fbcnt.alloc((size_t)ngroups * 4, true, s));
@@ -1330,7 +1329,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		BLMX_HIP(hipMemcpyAsync(d_gorder.p, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, s));
 		hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3((unsigned)h_order.size()), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(),
 		                   d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>(),
-		                   d_gorder.as<uint32_t>());
+		                   d_gorder.as<uint32_t>(), d_bitcache.as<uint32_t>());
 		BLMX_HIP(hipGetLastError());
 		std::vector<uint32_t> h_fbcnt(ngroups);
 		BLMX_HIP(hipMemcpyAsync(h_fbcnt.data(), d_fbcnt.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
