@@ -861,15 +861,16 @@ __global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ p
 }
 
 // int_to_bool for a whole group (blight.cpp:464-469): one workgroup packs the group's 32-bit fields (indexed by rank)
-// into its nbits-wide little-endian slice of `positions`.  Per chunk of 128 output words the fields that touch the chunk
+// into its nbits-wide little-endian slice of `positions`.  Per chunk of up to 512 output words the fields that touch the chunk
 // are staged in LDS with coalesced loads, then one lane assembles one 64-bit word (all offsets relative to the chunk:
 // 32-bit arithmetic).  Only the first and last word of a slice can be shared with the neighbouring groups: those are
 // ORed atomically (the array is zero-initialised), every other word is a plain store.
-constexpr int kPackWords = 128;
-__global__ __launch_bounds__(kPackWords) void k_pack_positions(const GroupDesc* __restrict__ groups, uint64_t id_base,
-                                                               const uint32_t* __restrict__ field_of_rank, unsigned long long* __restrict__ positions)
+constexpr int kPackThreads = 512;       // one output word per thread and chunk
+constexpr uint32_t kPackFields = 16384;  // fields staged per chunk (64 KB of LDS)
+__global__ __launch_bounds__(kPackThreads) void k_pack_positions(const GroupDesc* __restrict__ groups, uint64_t id_base,
+                                                                 const uint32_t* __restrict__ field_of_rank, unsigned long long* __restrict__ positions)
 {
-	__shared__ uint32_t s_f[kPackWords * 64 + 8];
+	__shared__ uint32_t s_f[kPackFields];
 	const GroupDesc* gd = &groups[blockIdx.x];
 	const uint64_t n = gd->nkeys;
 	const uint32_t nbits = gd->nbits;
@@ -879,17 +880,20 @@ __global__ __launch_bounds__(kPackWords) void k_pack_positions(const GroupDesc* 
 	const uint32_t* __restrict__ f = field_of_rank + (gd->prefix - id_base);
 	const uint64_t w_first = ps >> 6, w_last = (pe - 1) >> 6;
 	const uint32_t fmask = nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u);
-	for (uint64_t wc = w_first; wc <= w_last; wc += kPackWords) {
-		const uint64_t wend = min(wc + (uint64_t)kPackWords - 1, w_last);
+	// words per chunk: as many as there are threads, fewer when the fields that touch them would not fit the LDS stage
+	// (a chunk of W words is touched by at most W * 64 / nbits + 2 fields)
+	const uint32_t chunk = min((uint32_t)kPackThreads, max(1u, (uint32_t)(((uint64_t)(kPackFields - 2) * nbits) >> 6)));
+	for (uint64_t wc = w_first; wc <= w_last; wc += chunk) {
+		const uint64_t wend = min(wc + (uint64_t)chunk - 1, w_last);
 		const uint64_t cb0 = max(wc << 6, ps), cb1 = min((wend << 6) + 64, pe);  // bits of the slice inside this chunk
 		const uint64_t hA = (cb0 - ps) / nbits, hB = (cb1 - 1 - ps) / nbits;     // fields touching the chunk (uniform)
 		const uint32_t nf = (uint32_t)(hB - hA + 1);
 		__syncthreads();  // the previous chunk has been consumed
-		for (uint32_t i = threadIdx.x; i < nf; i += kPackWords)
+		for (uint32_t i = threadIdx.x; i < nf; i += kPackThreads)
 			s_f[i] = f[hA + i] & fmask;
 		__syncthreads();
 		const uint64_t w = wc + threadIdx.x;
-		if (w <= wend) {
+		if (threadIdx.x < chunk && w <= wend) {
 			const int32_t r0 = (int32_t)((int64_t)(w << 6) - (int64_t)(ps + hA * nbits));  // word start relative to field hA
 			const int32_t r1 = (int32_t)((int64_t)min((w << 6) + 64, pe) - (int64_t)(ps + hA * nbits));
 			const uint32_t lo = r0 < 0 ? 0u : (uint32_t)r0;
@@ -1495,7 +1499,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			                   ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(),
 			                   d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, id_base, d_field.as<uint32_t>());
 		if (N)
-			hipLaunchKernelGGL(k_pack_positions, dim3(ngroups), dim3(kPackWords), 0, s, ix.groups.as<GroupDesc>(), id_base, d_field.as<uint32_t>(),
+			hipLaunchKernelGGL(k_pack_positions, dim3(ngroups), dim3(kPackThreads), 0, s, ix.groups.as<GroupDesc>(), id_base, d_field.as<uint32_t>(),
 			                   ix.positions.as<unsigned long long>());
 		BLMX_HIP(hipGetLastError());
 		BLMX_HIP(hipStreamSynchronize(s));
