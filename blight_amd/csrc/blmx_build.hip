@@ -526,7 +526,7 @@ template <int KW>
 __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, const uint64_t* __restrict__ keys, uint32_t* __restrict__ listA,
                                                                 uint32_t* __restrict__ listB, uint32_t* __restrict__ gbits32,
                                                                 uint32_t* __restrict__ fb_count, int* __restrict__ levels_max,
-                                                                const uint32_t* __restrict__ order, uint32_t* __restrict__ bitcache)
+                                                                const uint32_t* __restrict__ order)
 {
 	__shared__ uint32_t s_bits[kLdsLevelWords];
 	__shared__ uint32_t s_coll[kLdsLevelWords];
@@ -543,6 +543,11 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 	for (; level < kLevels && count > 0; level++) {
 		const uint64_t size = gd->size[level];
 		const uint32_t words = (uint32_t)(size >> 5);
+		// Each key's level bit is cached between the mark and the survivor pass, so that a key is hashed once per level.
+		// The cache borrows list space: at level 0 the current list is implicit, its slice is free; deeper, the tail of the
+		// next list's slice is free as long as no more than half of the group's keys are still alive (the appended survivors
+		// cannot reach it).  Otherwise (mass duplicates) the survivor pass hashes again.
+		uint32_t* bitcache = level == 0 ? cur : (count <= n / 2 ? nxt + (n - count) : nullptr);
 		if (threadIdx.x == 0)
 			s_cnt = 0;
 		// a level larger than the LDS arrays is built in slices of kLdsLevelWords words: every pass walks the level's keys
@@ -562,8 +567,8 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 				for (int l = 0; l <= level; l++)
 					h = hs.next(l);
 				const uint32_t b = (uint32_t)reduce_level(h, size);
-				if (w0 == 0)
-					bitcache[kb + i] = b;  // the survivor pass below reads the bit back instead of hashing the key again
+				if (w0 == 0 && bitcache)
+					bitcache[i] = b;
 				const uint32_t lw = (b >> 5) - w0;
 				if (lw < wn) {
 					const uint32_t m = 1u << (b & 31);
@@ -580,7 +585,16 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 				uint32_t j = 0;
 				if (i < count) {
 					j = level == 0 ? i : cur[i];
-					const uint32_t b = bitcache[kb + i];
+					uint32_t b;
+					if (bitcache) {
+						b = bitcache[i];
+					} else {
+						LevelHasher hs(KW == 1 ? keys[kb + j] : keys[2 * (kb + j)]);
+						uint64_t h = 0;
+						for (int l = 0; l <= level; l++)
+							h = hs.next(l);
+						b = (uint32_t)reduce_level(h, size);
+					}
 					const uint32_t lw = (b >> 5) - w0;
 					surv = lw < wn && ((s_coll[lw] >> (b & 31)) & 1u);
 				}
@@ -1314,8 +1328,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	uint64_t F_lds = 0;
 	std::vector<uint64_t> h_fboff;
 	if (n_small) {
-		DevBuf d_lA, d_lB, d_bitcache;
-		BLMX_HIP(d_bitcache.alloc((N + 1) * 4, false, s));
+		DevBuf d_lA, d_lB;
 		BLMX_HIP(d_lA.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_lB.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_fbcnt.alloc((size_t)ngroups * 4, true, s));
@@ -1333,7 +1346,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		BLMX_HIP(hipMemcpyAsync(d_gorder.p, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, s));
 		hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3((unsigned)h_order.size()), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(),
 		                   d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>(),
-		                   d_gorder.as<uint32_t>(), d_bitcache.as<uint32_t>());
+		                   d_gorder.as<uint32_t>());
 		BLMX_HIP(hipGetLastError());
 		std::vector<uint32_t> h_fbcnt(ngroups);
 		BLMX_HIP(hipMemcpyAsync(h_fbcnt.data(), d_fbcnt.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
