@@ -819,7 +819,10 @@ PartitionPlan partition_batch(Index& ix, const void* d_kmers, uint64_t nq, bool 
 		const int v = e ? atoi(e) : kBinBitsDefault;
 		return v < 1 ? 1 : (v > kBinBitsMax ? kBinBitsMax : v);
 	}();
-	const int tbits = mbits < env_bits ? mbits : env_bits;
+	int tbits = mbits < env_bits ? mbits : env_bits;
+	const uint32_t nbound = (owner_bins && ix.shard_world > 1) ? ix.shard_world - 1 : 0;
+	while (tbits > 1 && (1u << tbits) + nbound > (1u << kBinBitsMax))  // the kernels hold at most 2^kBinBitsMax bins
+		tbits--;
 	PartitionPlan pl;
 	pl.bm.shift = mbits - tbits;
 	pl.bm.nbound = 0;

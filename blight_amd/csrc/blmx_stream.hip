@@ -468,13 +468,14 @@ void load_index(Index& ix, const char* path)
 // ---- payload kernels --------------------------------------------------------------------------------------------------
 // abundance[id]++ on uint8 counters (Abundance_De_Bruijn_graph_snippet.cpp:147-150: wraps at 256 like the reference's
 // uint8_t): four counters share a 32-bit word, the increment is a CAS on the word that touches only its own byte.
-__global__ __launch_bounds__(256) void k_payload_abundance(const int64_t* __restrict__ ids, uint64_t n, uint32_t* __restrict__ words)
+__global__ __launch_bounds__(256) void k_payload_abundance(const int64_t* __restrict__ ids, uint64_t n, uint64_t nids,
+                                                           uint32_t* __restrict__ words)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
 	const int64_t id = ids[i];
-	if (id < 0)
+	if (id < 0 || (uint64_t)id >= nids)  // absent k-mer, or an ID that is not of this index
 		return;
 	uint32_t* w = &words[(uint64_t)id >> 2];
 	const uint32_t sh = 8u * ((uint32_t)id & 3u);
@@ -488,14 +489,14 @@ __global__ __launch_bounds__(256) void k_payload_abundance(const int64_t* __rest
 
 // color_me_amaze[id * color_number + i_file] = true (Colored_De_Bruijn_graph_snippet.cpp:146-150); bit index order of the
 // reference's vector<bool>, 32 bits per word, least significant first.
-__global__ __launch_bounds__(256) void k_payload_color(const int64_t* __restrict__ ids, uint64_t n, uint32_t color, uint32_t ncolors,
-                                                       uint32_t* __restrict__ bits)
+__global__ __launch_bounds__(256) void k_payload_color(const int64_t* __restrict__ ids, uint64_t n, uint64_t nids, uint32_t color,
+                                                       uint32_t ncolors, uint32_t* __restrict__ bits)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
 	const int64_t id = ids[i];
-	if (id < 0)
+	if (id < 0 || (uint64_t)id >= nids)
 		return;
 	const uint64_t bit = (uint64_t)id * ncolors + color;
 	atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
@@ -525,9 +526,9 @@ void payload_add_ids(Payload& pl, const int64_t* d_ids, uint64_t n, uint32_t col
 		throw StatusError{BLMX_EINVAL, "colour out of range"};
 	const unsigned grid = (unsigned)((n + 255) / 256);
 	if (pl.kind == 0)
-		hipLaunchKernelGGL(k_payload_abundance, dim3(grid), dim3(256), 0, s, d_ids, n, pl.data.as<uint32_t>());
+		hipLaunchKernelGGL(k_payload_abundance, dim3(grid), dim3(256), 0, s, d_ids, n, pl.nids, pl.data.as<uint32_t>());
 	else
-		hipLaunchKernelGGL(k_payload_color, dim3(grid), dim3(256), 0, s, d_ids, n, color, pl.ncolors, pl.data.as<uint32_t>());
+		hipLaunchKernelGGL(k_payload_color, dim3(grid), dim3(256), 0, s, d_ids, n, pl.nids, color, pl.ncolors, pl.data.as<uint32_t>());
 	BLMX_HIP(hipGetLastError());
 }
 
