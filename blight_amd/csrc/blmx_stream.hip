@@ -5,11 +5,17 @@
 // the GPU; two batches are in flight so that parsing, H2D, the kernels (rolling canonical k-mers -> query pipeline ->
 // on-device count of found / not found) and the 16-byte D2H of the counters overlap.  Nothing but the two counters
 // comes back over PCIe.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <thread>
 
 #include "blmx_internal.h"
 
@@ -20,18 +26,56 @@ namespace blmx {
 // Lines are returned as views into an internal buffer that is refilled in 8 MiB chunks (gzread reads plain files too).
 class RecordReader {
 public:
-	explicit RecordReader(const char* path) : f_(gzopen(path, "rb"))
+	// A plain file is mapped and scanned in place (no read() copy through zlib's buffers: the parse is the slowest stage of
+	// ingest and file_query); a gzip file goes through gzread in 8 MiB chunks.
+	explicit RecordReader(const char* path)
 	{
-		if (f_)
-			gzbuffer(f_, 1 << 20);
-		buf_.resize(kChunk);
+		const int fd = open(path, O_RDONLY);
+		if (fd < 0)
+			return;
+		unsigned char magic[2] = {0, 0};
+		const ssize_t got = pread(fd, magic, 2, 0);
+		struct stat st;
+		const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+		if (!gz && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+			if (st.st_size == 0) {
+				opened_ = true;
+				eof_ = true;
+			} else {
+				void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+				if (m != MAP_FAILED) {
+					(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+					map_ = static_cast<const char*>(m);
+					map_bytes_ = (size_t)st.st_size;
+					data_ = map_;
+					end_ = map_bytes_;
+					eof_ = true;  // everything is already "read"
+					opened_ = true;
+				}
+			}
+		}
+		close(fd);
+		if (!opened_) {
+			f_ = gzopen(path, "rb");
+			if (f_) {
+				gzbuffer(f_, 1 << 20);
+				buf_.resize(kChunk);
+				data_ = buf_.data();
+				opened_ = true;
+			}
+		}
 	}
 	~RecordReader()
 	{
 		if (f_)
 			gzclose(f_);
+		if (map_)
+			munmap(const_cast<char*>(map_), map_bytes_);
 	}
-	bool ok() const { return f_ != nullptr; }
+	RecordReader(const RecordReader&) = delete;
+	RecordReader& operator=(const RecordReader&) = delete;
+	bool ok() const { return opened_; }
+	bool mapped() const { return map_ != nullptr; }
 
 	// next sequence line (header already skipped); false at end of file
 	bool next_sequence(const char*& p, size_t& len)
@@ -52,6 +96,152 @@ public:
 		}
 	}
 
+	// Bulk fast path for mapped plain files: parses the next window of up to `cap` bytes with several host threads and
+	// appends every sequence of at least `minlen` characters to dst (concatenated) / offs (cumulative ends, continuing from
+	// offs.back()) / koffs (cumulative k-mer counts len - k + 1, when given).  The reader's record rule (header line,
+	// sequence line; an empty header swallows a line, an empty sequence is skipped) depends on everything before a line, so
+	// the threads only take over when the window is REGULAR -- no empty line in it -- where the rule reduces to "odd lines
+	// are sequences": pass A counts lines and empties per sub-range, a prefix over the sub-ranges gives every thread its line
+	// parity and its output offsets, pass B copies.  Returns the number of sequences appended; 0 means "not applicable here"
+	// (gzip input, an irregular window, nothing left) and the caller continues with next_sequence().
+	size_t bulk(char* dst, size_t cap, std::vector<uint64_t>& offs, std::vector<uint64_t>* koffs, uint64_t k, size_t minlen)
+	{
+		if (!map_ || beg_ >= end_ || cap < (1u << 20) || beg_ < no_bulk_before_)
+			return 0;
+		static const unsigned nthreads = [] {
+			const char* e = getenv("BLIGHT_PARSE_THREADS");
+			const unsigned v = e ? (unsigned)atoi(e) : 8u;
+			return v < 1 ? 1u : (v > 64 ? 64u : v);
+		}();
+		size_t wend = beg_ + cap < end_ ? beg_ + cap : end_;
+		if (wend < end_) {  // end the window after a newline
+			const char* nl = (const char*)memrchr(data_ + beg_, '\n', wend - beg_);
+			if (!nl)
+				return 0;  // one line longer than the window
+			wend = (size_t)(nl - data_) + 1;
+		}
+		struct Part {
+			size_t a = 0, z = 0;  // lines STARTING in [a, z)
+			uint64_t lines = 0;
+			bool empty = false;
+			uint64_t nseq[2] = {0, 0}, bytes[2] = {0, 0}, kmers[2] = {0, 0};  // by local line parity
+		};
+		std::vector<Part> part(nthreads);
+		const size_t span = wend - beg_;
+		for (unsigned t = 0; t < nthreads; t++) {
+			size_t a = beg_ + span * t / nthreads;
+			if (t > 0) {  // move to the start of the next line
+				const char* nl = a < wend ? (const char*)memchr(data_ + a - 1, '\n', wend - (a - 1)) : nullptr;
+				a = nl ? (size_t)(nl - data_) + 1 : wend;
+			}
+			part[t].a = a;
+			if (t > 0)
+				part[t - 1].z = a;
+		}
+		part[nthreads - 1].z = wend;
+		const char* base = data_;
+		auto scan = [base, wend, k, minlen](Part& pt) {
+			size_t p = pt.a;
+			while (p < pt.z) {
+				const char* nl = (const char*)memchr(base + p, '\n', wend - p);
+				const size_t e = nl ? (size_t)(nl - base) : wend;  // last line of the file may lack its newline
+				const size_t len = e - p;
+				const unsigned par = (unsigned)(pt.lines & 1);
+				if (len == 0)
+					pt.empty = true;
+				if (len >= minlen && len >= k) {
+					pt.nseq[par]++;
+					pt.bytes[par] += len;
+					pt.kmers[par] += len - k + 1;
+				}
+				pt.lines++;
+				p = e + 1;
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (unsigned t = 1; t < nthreads; t++)
+				th.emplace_back(scan, std::ref(part[t]));
+			scan(part[0]);
+			for (auto& x : th)
+				x.join();
+		}
+		uint64_t lines = 0;
+		for (const Part& pt : part) {
+			if (pt.empty) {
+				no_bulk_before_ = wend;  // irregular window: the sequential rule decides it; do not scan it again
+				return 0;
+			}
+			lines += pt.lines;
+		}
+		if (lines < 2)
+			return 0;
+		// an odd number of lines: the last one is a header whose sequence lies beyond the window (or beyond the end of the
+		// file) -- it is left for the next call; as a line of parity 0 it contributes nothing to the sums below
+		size_t new_beg = wend;
+		if (lines & 1) {
+			const size_t content_end = data_[wend - 1] == '\n' ? wend - 1 : wend;
+			const char* nl = content_end > beg_ ? (const char*)memrchr(data_ + beg_, '\n', content_end - beg_) : nullptr;
+			if (!nl)
+				return 0;
+			new_beg = (size_t)(nl - data_) + 1;
+		}
+		// global parity of every part's first line; sequences are the lines of global parity 1
+		uint64_t before = 0, nseq_total = 0, bytes_total = 0;
+		std::vector<uint64_t> seq_at(nthreads), byte_at(nthreads), kmer_at(nthreads);
+		std::vector<unsigned> seqpar(nthreads);
+		uint64_t kmers_total = 0;
+		for (unsigned t = 0; t < nthreads; t++) {
+			seqpar[t] = (unsigned)((before & 1) ^ 1);  // local parity of the sequence lines in this part
+			seq_at[t] = nseq_total;
+			byte_at[t] = bytes_total;
+			kmer_at[t] = kmers_total;
+			nseq_total += part[t].nseq[seqpar[t]];
+			bytes_total += part[t].bytes[seqpar[t]];
+			kmers_total += part[t].kmers[seqpar[t]];
+			before += part[t].lines;
+		}
+		if (bytes_total > cap)
+			return 0;
+		const uint64_t off0 = offs.back(), koff0 = koffs ? koffs->back() : 0;
+		const size_t idx0 = offs.size();
+		offs.resize(idx0 + nseq_total);
+		if (koffs)
+			koffs->resize(idx0 + nseq_total);
+		uint64_t* offp = offs.data() + idx0;
+		uint64_t* koffp = koffs ? koffs->data() + idx0 : nullptr;
+		auto emit = [base, wend, k, minlen, dst, offp, koffp, off0, koff0](const Part& pt, unsigned sp, uint64_t si, uint64_t bi, uint64_t ki) {
+			size_t p = pt.a;
+			uint64_t line = 0;
+			while (p < pt.z) {
+				const char* nl = (const char*)memchr(base + p, '\n', wend - p);
+				const size_t e = nl ? (size_t)(nl - base) : wend;
+				const size_t len = e - p;
+				if ((line & 1) == sp && len >= minlen && len >= k) {
+					memcpy(dst + bi, base + p, len);
+					bi += len;
+					ki += len - k + 1;
+					offp[si] = off0 + bi;
+					if (koffp)
+						koffp[si] = koff0 + ki;
+					si++;
+				}
+				line++;
+				p = e + 1;
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (unsigned t = 1; t < nthreads; t++)
+				th.emplace_back(emit, std::cref(part[t]), seqpar[t], seq_at[t], byte_at[t], kmer_at[t]);
+			emit(part[0], seqpar[0], seq_at[0], byte_at[0], kmer_at[0]);
+			for (auto& x : th)
+				x.join();
+		}
+		beg_ = new_beg;
+		return (size_t)nseq_total;
+	}
+
 	// next line that starts with A/C/G/T (the payload snippets treat every such LINE as a sequence, whatever the record
 	// structure: Colored_De_Bruijn_graph_snippet.cpp:139); false at end of file
 	bool next_acgt_line(const char*& p, size_t& len)
@@ -65,10 +255,14 @@ public:
 
 private:
 	static constexpr size_t kChunk = 8u << 20;
-	gzFile f_;
+	gzFile f_ = nullptr;
 	std::vector<char> buf_;
+	const char* map_ = nullptr;
+	size_t map_bytes_ = 0;
+	const char* data_ = nullptr;  // buf_.data() or the mapping
 	size_t beg_ = 0, end_ = 0;
-	bool eof_ = false;
+	size_t no_bulk_before_ = 0;
+	bool eof_ = false, opened_ = false;
 
 	bool refill()
 	{
@@ -81,6 +275,7 @@ private:
 		}
 		if (buf_.size() - end_ < kChunk)
 			buf_.resize(end_ + kChunk);
+		data_ = buf_.data();
 		const int n = gzread(f_, buf_.data() + end_, (unsigned)kChunk);
 		if (n <= 0) {
 			eof_ = true;
@@ -95,17 +290,17 @@ private:
 	{
 		size_t scan_from = beg_;
 		for (;;) {
-			const char* nl = (const char*)memchr(buf_.data() + scan_from, '\n', end_ - scan_from);
+			const char* nl = end_ > scan_from ? (const char*)memchr(data_ + scan_from, '\n', end_ - scan_from) : nullptr;
 			if (nl) {
-				p = buf_.data() + beg_;
+				p = data_ + beg_;
 				len = (size_t)(nl - p);
-				beg_ = (size_t)(nl - buf_.data()) + 1;
+				beg_ = (size_t)(nl - data_) + 1;
 				return true;
 			}
 			const size_t had = end_ - beg_;
 			if (!refill()) {
 				if (end_ > beg_) {  // last line without a newline
-					p = buf_.data() + beg_;
+					p = data_ + beg_;
 					len = end_ - beg_;
 					beg_ = end_;
 					return true;
@@ -256,7 +451,17 @@ void build_from_fasta_streamed(Index& ix, const char* path)
 	};
 	const char* p;
 	size_t len;
-	while (rd.next_sequence(p, len)) {
+	for (;;) {
+		if (rd.mapped()) {  // plain file: whole windows are parsed by several threads straight into the pinned buffer
+			if (pin[cur].bytes - fill < (16u << 20))
+				flush();
+			if (rd.bulk(pin[cur].as<char>() + fill, pin[cur].bytes - fill, offs, nullptr, 0, 1)) {
+				fill = (size_t)(offs.back() - total);
+				continue;
+			}
+		}
+		if (!rd.next_sequence(p, len))
+			break;
 		if (fill + len > pin[cur].bytes) {
 			flush();
 			pin[cur].ensure(len);  // a single sequence longer than the chunk
@@ -578,6 +783,11 @@ static void stream_file(Index& ix, const char* path, bool acgt_lines, Payload* p
 		b.total = 0;
 		b.h_seq.ensure(kBatchBytes + (1u << 20));
 		while (b.total < kBatchBytes) {
+			if (!acgt_lines && rd.mapped() &&
+			    rd.bulk(b.h_seq.as<char>() + b.total, b.h_seq.bytes - b.total - 64, b.offs, &b.koffs, k, (size_t)k)) {
+				b.total = b.offs.back();  // sequences shorter than k were skipped (blight.cpp:782)
+				continue;
+			}
 			more = acgt_lines ? rd.next_acgt_line(p, len) : rd.next_sequence(p, len);
 			if (!more)
 				break;
