@@ -159,3 +159,16 @@ def test_streaming_file_query_multi_batch(tmp_path):
     assert good == (n_idx + 1) * per  # + the tail record, a copy of an indexed sequence
     assert bad == n_other * per
     assert ix.number_query == good + bad
+    # the same 130 MB through the streaming INGEST (several parse windows and pinned chunks, parallel bulk parse, a last
+    # line without newline): every record becomes part of the index, so a self-query finds everything
+    fb = tmp_path / "big2.fa"
+    with open(fb, "wb") as f:
+        f.write(rows[perm].tobytes())
+        f.write(b">tail-without-newline\n" + bytes(seqs[0]))
+    ix2 = B.kmer_Set_Light(k, 9, 7, 6, 1, 6)
+    ix2.construct_index(str(fb))
+    assert ix2.number_kmer == (n_idx + n_other + 1) * per
+    good2, bad2 = ix2.file_query(str(fb))
+    assert (good2, bad2) == ((n_idx + n_other + 1) * per, 0)
+    sample = [bytes(s_) for s_ in seqs[n_idx:n_idx + 50]]
+    assert (ix2.query_sequences_hash(sample) >= 0).all() and (ix.query_sequences_hash(sample) < 0).all()
