@@ -110,7 +110,8 @@ public:
 			return 0;
 		static const unsigned nthreads = [] {
 			const char* e = getenv("BLIGHT_PARSE_THREADS");
-			const unsigned v = e ? (unsigned)atoi(e) : 8u;
+			const unsigned hw = std::thread::hardware_concurrency();
+			const unsigned v = e ? (unsigned)atoi(e) : (hw && hw < 16 ? hw : 16u);
 			return v < 1 ? 1u : (v > 64 ? 64u : v);
 		}();
 		size_t wend = beg_ + cap < end_ ? beg_ + cap : end_;
