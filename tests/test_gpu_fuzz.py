@@ -1,0 +1,15 @@
+"""A short slice of the randomised parity sweep (tools/fuzz_parity.py; 3000 configurations were swept once by hand):
+random (k, m, n, b, k-mer width) and random inputs with low-complexity, tandem and duplicated stretches; counters, exported
+arrays, IDs (direct and partitioned pipeline), negatives and near misses against the CPU oracle."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_parameter_sweep():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    fuzz_parity.sweep(80, 20261004, verbose=False)

@@ -9,60 +9,64 @@ import numpy as np
 import blight_amd as B
 from oracle import oracle as O
 
-runs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
-t0 = time.time()
-for it in range(runs):
-    kb = 8 if rng.random() < 0.6 else 16
-    k = int(rng.integers(9, 33)) if kb == 8 else int(rng.integers(9, 64))
-    m = int(rng.choice([x for x in (3, 5, 7, 9, 11) if x <= k]))
-    n = int(rng.integers(0, 2 * m))          # <= 2m - 1
-    b = int(rng.integers(0, 11))
-    alpha = "ACGT" if rng.random() < 0.7 else ("AC" if rng.random() < 0.5 else "ACG")
-    nseq = int(rng.integers(1, 400))
-    seqs = []
-    for _ in range(nseq):
-        L = k + int(rng.geometric(1 / 50)) - 1
-        s = "".join(alpha[i] for i in rng.integers(0, len(alpha), L))
-        if rng.random() < 0.1:
-            s = s[: max(k, L // 2)] * 2      # tandem duplication
-        if rng.random() < 0.05:
-            s = "A" * (k + int(rng.integers(0, 30)))
-        seqs.append(s)
-    if rng.random() < 0.3:
-        seqs += seqs[: max(1, nseq // 5)]    # duplicated unitigs
-    tag = "run %d: k=%d m=%d n=%d b=%d kb=%d nseq=%d alpha=%s" % (it, k, m, n, b, kb, len(seqs), alpha)
-    try:
-        ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
-        ix.construct_index_from_sequences(seqs)
-        orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
-        st = ix.stats()
-        for f, g in (("number_kmer", "number_kmer"), ("number_super_kmer", "number_super_kmer"), ("total_nt", "total_nt"),
-                     ("largest_mphf", "largest_mphf"), ("positions_total_size", "positions_bits")):
-            assert st[f] == orc.stats[g], (tag, f, st[f], orc.stats[g])
-        a = orc.arrays()
-        for key in ("bucket_nt", "bucket_start", "seq", "positions", "g_nkeys", "g_prefix", "g_posstart"):
-            assert np.array_equal(ix.export(key), a[key]), (tag, key)
-        q = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
-        neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(2000)]
-        neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
-        allq = np.ascontiguousarray(np.concatenate([q, neg]))
-        want = orc.query_kmers(allq.reshape(-1) if kb == 8 else allq)
-        for pol in (-1, 1):
-            ix.set_query_binning(pol)
-            got = ix.query_kmer_hash(allq.reshape(-1))
-            assert np.array_equal(got, want), (tag, "ids", pol, int((got != want).sum()))
-        assert (want[: len(q)] >= 0).all(), tag
-        mut = []
-        for s in seqs[:50]:
-            p = int(rng.integers(0, len(s)))
-            mut.append(s[:p] + "ACGT"[("ACGT".index(s[p]) + 1) % 4] + s[p + 1:])
-        assert np.array_equal(ix.query_sequences_hash(mut), np.concatenate([orc.query_sequence(s) for s in mut])), (tag, "mut")
-        ix.close(); orc.close()
-    except Exception as e:
-        print("FAIL", tag, repr(e)[:400], flush=True)
-        raise
-    if it % 10 == 9:
-        print("ok through", tag, "%.0f s" % (time.time() - t0), flush=True)
-print("FUZZ-OK %d runs" % runs)
+def sweep(runs, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    for it in range(runs):
+        kb = 8 if rng.random() < 0.6 else 16
+        k = int(rng.integers(9, 33)) if kb == 8 else int(rng.integers(9, 64))
+        m = int(rng.choice([x for x in (3, 5, 7, 9, 11) if x <= k]))
+        n = int(rng.integers(0, 2 * m))          # <= 2m - 1
+        b = int(rng.integers(0, 11))
+        alpha = "ACGT" if rng.random() < 0.7 else ("AC" if rng.random() < 0.5 else "ACG")
+        nseq = int(rng.integers(1, 400))
+        seqs = []
+        for _ in range(nseq):
+            L = k + int(rng.geometric(1 / 50)) - 1
+            s = "".join(alpha[i] for i in rng.integers(0, len(alpha), L))
+            if rng.random() < 0.1:
+                s = s[: max(k, L // 2)] * 2      # tandem duplication
+            if rng.random() < 0.05:
+                s = "A" * (k + int(rng.integers(0, 30)))
+            seqs.append(s)
+        if rng.random() < 0.3:
+            seqs += seqs[: max(1, nseq // 5)]    # duplicated unitigs
+        tag = "run %d: k=%d m=%d n=%d b=%d kb=%d nseq=%d alpha=%s" % (it, k, m, n, b, kb, len(seqs), alpha)
+        try:
+            ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+            ix.construct_index_from_sequences(seqs)
+            orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+            st = ix.stats()
+            for f, g in (("number_kmer", "number_kmer"), ("number_super_kmer", "number_super_kmer"), ("total_nt", "total_nt"),
+                         ("largest_mphf", "largest_mphf"), ("positions_total_size", "positions_bits")):
+                assert st[f] == orc.stats[g], (tag, f, st[f], orc.stats[g])
+            a = orc.arrays()
+            for key in ("bucket_nt", "bucket_start", "seq", "positions", "g_nkeys", "g_prefix", "g_posstart"):
+                assert np.array_equal(ix.export(key), a[key]), (tag, key)
+            q = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
+            neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(2000)]
+            neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
+            allq = np.ascontiguousarray(np.concatenate([q, neg]))
+            want = orc.query_kmers(allq.reshape(-1) if kb == 8 else allq)
+            for pol in (-1, 1):
+                ix.set_query_binning(pol)
+                got = ix.query_kmer_hash(allq.reshape(-1))
+                assert np.array_equal(got, want), (tag, "ids", pol, int((got != want).sum()))
+            assert (want[: len(q)] >= 0).all(), tag
+            mut = []
+            for s in seqs[:50]:
+                p = int(rng.integers(0, len(s)))
+                mut.append(s[:p] + "ACGT"[("ACGT".index(s[p]) + 1) % 4] + s[p + 1:])
+            assert np.array_equal(ix.query_sequences_hash(mut), np.concatenate([orc.query_sequence(s) for s in mut])), (tag, "mut")
+            ix.close(); orc.close()
+        except Exception as e:
+            print("FAIL", tag, repr(e)[:400], flush=True)
+            raise
+        if it % 10 == 9 and verbose:
+            print("ok through", tag, "%.0f s" % (time.time() - t0), flush=True)
+    if verbose:
+        print("FUZZ-OK %d runs" % runs)
+
+
+if __name__ == "__main__":
+    sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
