@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (not part of the test suite: minutes of GPU time): random (k, m, n, b, width) and random inputs with
 low-complexity and duplicated stretches; every run compares the GPU with the CPU oracle on counters, all exported arrays, IDs
-of all k-mers, negatives, near misses, positions, and the partition -> query -> gather pipeline.  Usage: fuzz_parity.py [runs] [seed]"""
+of all k-mers, negatives, near misses, positions, and the partition -> query -> gather pipeline.  Usage: python tests/fuzz_parity.py [runs] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # test infrastructure: may use the oracle
 import numpy as np
 import blight_amd as B
 from oracle import oracle as O

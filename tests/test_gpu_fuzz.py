@@ -1,4 +1,4 @@
-"""A short slice of the randomised parity sweep (tools/fuzz_parity.py; 3000 configurations were swept once by hand):
+"""A short slice of the randomised parity sweep (tests/fuzz_parity.py; 3000 configurations were swept once by hand):
 random (k, m, n, b, k-mer width) and random inputs with low-complexity, tandem and duplicated stretches; counters, exported
 arrays, IDs (direct and partitioned pipeline), negatives and near misses against the CPU oracle."""
 import os
@@ -10,6 +10,6 @@ pytestmark = pytest.mark.gpu
 
 
 def test_random_parameter_sweep():
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fuzz_parity
     fuzz_parity.sweep(80, 20261004, verbose=False)
