@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
-ABI_VERSION = 7  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
+ABI_VERSION = 8  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 _u64p = C.POINTER(C.c_uint64)
@@ -96,6 +96,7 @@ def load_library():
                                               C.c_void_p, C.c_void_p]
     lib.blmx_unpermute_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_set_query_binning.argtypes = [C.c_void_p, C.c_int]
+    lib.blmx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     lib.blmx_export.restype = C.c_int64
@@ -129,6 +130,8 @@ def _kmers_array(kmers, kmer_bytes):
     """ints / uint64 array -> contiguous little-endian array of kmer_bytes per k-mer"""
     if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint64:
         a = np.ascontiguousarray(kmers)
+        if a.size % (kmer_bytes // 8):
+            raise ValueError("a %d-byte k-mer array needs a multiple of %d uint64 words" % (kmer_bytes, kmer_bytes // 8))
         return a, a.size // (kmer_bytes // 8)
     kl = [int(x) for x in (kmers if hasattr(kmers, "__iter__") else [kmers])]
     if kmer_bytes == 8:
@@ -251,6 +254,8 @@ class kmer_Set_Light:
         scalar = not hasattr(canon, "__iter__")
         a, nq = _kmers_array(canon, self.kmer_bytes)
         mi = np.ascontiguousarray(np.atleast_1d(minimizer), dtype=np.uint32)
+        if mi.size != nq:
+            raise ValueError("%d minimizers for %d k-mers" % (mi.size, nq))
         out = np.empty(nq, dtype=np.int64)
         self._check(self._lib.blmx_query_kmers_with_minimizer(self._h, a.ctypes.data, mi.ctypes.data_as(_u32p), nq,
                                                               out.ctypes.data_as(_i64p)))
@@ -261,6 +266,8 @@ class kmer_Set_Light:
         scalar = not hasattr(canon, "__iter__")
         a, nq = _kmers_array(canon, self.kmer_bytes)
         mi = np.ascontiguousarray(np.atleast_1d(minimizer), dtype=np.uint32)
+        if mi.size != nq:
+            raise ValueError("%d minimizers for %d k-mers" % (mi.size, nq))
         out = np.empty(nq, dtype=np.int32)
         self._check(self._lib.blmx_query_positions(self._h, a.ctypes.data, mi.ctypes.data_as(_u32p), nq,
                                                    out.ctypes.data_as(C.POINTER(C.c_int32))))
@@ -329,6 +336,10 @@ class kmer_Set_Light:
     def set_query_binning(self, policy):
         """0 automatic, 1 always partition large batches by minimizer prefix before querying, -1 never"""
         self._check(self._lib.blmx_set_query_binning(self._h, policy))
+
+    def set_tuning(self, key, value):
+        """per-index tuning knob (see blmx_set_tuning in include/blight_mi355x.h); results never depend on it"""
+        self._check(self._lib.blmx_set_tuning(self._h, key.encode(), int(value)))
 
     # -- multi-GPU sharding (SURVEY 8e)
     def set_shard(self, rank, world):

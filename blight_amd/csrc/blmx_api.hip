@@ -24,13 +24,21 @@ struct blmx_payload {
 
 namespace {
 
+// Error texts are per calling thread (the reference's callers query from OpenMP threads): blmx_last_error returns the text of
+// the calling thread's last failed call.
 thread_local std::string g_create_err;
+thread_local std::string g_last_err;
 
-int fail(blmx_index* h, int code, const std::string& msg)
+int fail(blmx_index*, int code, const std::string& msg)
 {
-	if (h)
-		h->ix.err = msg;
+	g_last_err = msg;
 	return code;
+}
+
+int env_int(const char* name, int dflt)
+{
+	const char* e = getenv(name);
+	return e ? atoi(e) : dflt;
 }
 
 template <typename F> int guarded(blmx_index* h, F&& f)
@@ -73,36 +81,6 @@ void build_host(blmx_index* h, const char* concat, const uint64_t* offsets, uint
 	ix.built = true;
 }
 
-// host-buffer query: stage in, run, stage out
-void query_host(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode)
-{
-	Index& ix = h->ix;
-	if (!ix.built)
-		throw StatusError{BLMX_ESTATE, "index not built"};
-	if (nq == 0)
-		return;
-	std::lock_guard<std::mutex> lock(ix.mu);
-	BLMX_HIP(hipSetDevice(ix.prm.device));
-	const size_t kb = (size_t)ix.KW * 8;
-	const size_t ob = mode == kQueryIds ? 8 : (mode == kQueryPos ? 4 : 1);
-	ensure(ix.q_in, nq * kb, ix.stream);
-	ensure(ix.q_out, nq * ob, ix.stream);
-	BLMX_HIP(hipMemcpyAsync(ix.q_in.p, kmers, nq * kb, hipMemcpyHostToDevice, ix.stream));
-	const uint32_t* d_minis = nullptr;
-	if (minis) {
-		ensure(ix.q_aux, nq * 4, ix.stream);
-		BLMX_HIP(hipMemcpyAsync(ix.q_aux.p, minis, nq * 4, hipMemcpyHostToDevice, ix.stream));
-		d_minis = ix.q_aux.as<uint32_t>();
-	}
-	if (mode == kQueryIds && !d_minis)
-		launch_query_ids_auto(ix, ix.q_in.p, nq, ix.q_out.as<int64_t>(), ix.stream);
-	else
-		launch_query(ix, ix.q_in.p, d_minis, nq, ix.q_out.p, mode, ix.stream);
-	BLMX_HIP(hipMemcpyAsync(out, ix.q_out.p, nq * ob, hipMemcpyDeviceToHost, ix.stream));
-	BLMX_HIP(hipStreamSynchronize(ix.stream));
-	ix.st.number_query += nq;  // blight.cpp:717-718
-}
-
 }  // namespace
 
 extern "C" {
@@ -110,7 +88,7 @@ extern "C" {
 const char* blmx_version(void) { return "blight-mi355x 0.1 (gfx950)"; }
 int blmx_abi_version(void) { return BLMX_ABI_VERSION; }
 const char* blmx_create_error(void) { return g_create_err.c_str(); }
-const char* blmx_last_error(const blmx_index* ix) { return ix ? ix->ix.err.c_str() : g_create_err.c_str(); }
+const char* blmx_last_error(const blmx_index* ix) { return ix ? g_last_err.c_str() : g_create_err.c_str(); }
 
 int blmx_create(const blmx_params* p, blmx_index** out)
 {
@@ -169,6 +147,13 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.gshift = (int)(2 * prm.m - 1 - prm.log2_mphf);
 	h->ix.nbuckets = 1u << (2 * prm.m - 1);
 	h->ix.ngroups = 1u << prm.log2_mphf;
+	// tuning knobs: seeded from the environment once per index (blmx_set_tuning changes them later)
+	h->ix.bin_policy = env_int("BLIGHT_QUERY_BINNING", 0);
+	h->ix.tune_bin_bits = env_int("BLIGHT_BIN_BITS", 0);
+	h->ix.tune_mini_handoff = env_int("BLIGHT_MINI_HANDOFF", -1);
+	h->ix.tune_query_heads = env_int("BLIGHT_QUERY_HEADS", 1);
+	h->ix.tune_reads_mode = env_int("BLIGHT_READS_MODE", 0);
+	h->ix.tune_window_kb = env_int("BLIGHT_WINDOW_KB", 0);
 	if (hipSetDevice(prm.device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
 		g_create_err = "hipStreamCreate failed";
 		delete h;
@@ -184,6 +169,8 @@ void blmx_destroy(blmx_index* h)
 		return;
 	(void)hipSetDevice(h->ix.prm.device);
 	(void)hipDeviceSynchronize();  // device-pointer calls may still be running on the caller's streams
+	destroy_host_front(h->ix.hf);
+	h->ix.hf = nullptr;
 	if (h->ix.bin_done)
 		(void)hipEventDestroy(h->ix.bin_done);
 	if (h->ix.stream) {
@@ -225,28 +212,28 @@ int blmx_query_kmers(blmx_index* h, const void* kmers, uint64_t nq, int64_t* ids
 {
 	if (!h || (nq && (!kmers || !ids_out)))
 		return BLMX_EINVAL;
-	return guarded(h, [&] { query_host(h, kmers, nullptr, nq, ids_out, kQueryIds); });
+	return guarded(h, [&] { query_kmers_host(h->ix, kmers, nullptr, nq, ids_out, kQueryIds); });
 }
 
 int blmx_query_kmers_with_minimizer(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_t nq, int64_t* ids_out)
 {
 	if (!h || (nq && (!kmers || !ids_out || !minis)))
 		return BLMX_EINVAL;
-	return guarded(h, [&] { query_host(h, kmers, minis, nq, ids_out, kQueryIds); });
+	return guarded(h, [&] { query_kmers_host(h->ix, kmers, minis, nq, ids_out, kQueryIds); });
 }
 
 int blmx_query_positions(blmx_index* h, const void* kmers, const uint32_t* minis, uint64_t nq, int32_t* pos_out)
 {
 	if (!h || (nq && (!kmers || !pos_out || !minis)))
 		return BLMX_EINVAL;
-	return guarded(h, [&] { query_host(h, kmers, minis, nq, pos_out, kQueryPos); });
+	return guarded(h, [&] { query_kmers_host(h->ix, kmers, minis, nq, pos_out, kQueryPos); });
 }
 
 int blmx_query_membership(blmx_index* h, const void* kmers, uint64_t nq, uint8_t* present_out)
 {
 	if (!h || (nq && (!kmers || !present_out)))
 		return BLMX_EINVAL;
-	return guarded(h, [&] { query_host(h, kmers, nullptr, nq, present_out, kQueryBool); });
+	return guarded(h, [&] { query_kmers_host(h->ix, kmers, nullptr, nq, present_out, kQueryBool); });
 }
 
 uint64_t blmx_sequence_kmer_count(const blmx_index* h, const uint64_t* offsets, uint64_t nseq)
@@ -267,46 +254,7 @@ int blmx_query_sequences(blmx_index* h, const char* concat, const uint64_t* offs
 {
 	if (!h || (nseq && (!concat || !offsets)))
 		return BLMX_EINVAL;
-	return guarded(h, [&] {
-		Index& ix = h->ix;
-		if (!ix.built)
-			throw StatusError{BLMX_ESTATE, "index not built"};
-		const uint64_t k = ix.prm.k;
-		std::vector<uint64_t> koffs(nseq + 1, 0);
-		for (uint64_t i = 0; i < nseq; i++) {
-			const uint64_t len = offsets[i + 1] - offsets[i];
-			koffs[i + 1] = koffs[i] + (len >= k ? len - k + 1 : 0);  // blight.cpp:577-579: shorter than k -> nothing
-		}
-		const uint64_t nk = koffs[nseq];
-		if (nk == 0)
-			return;
-		if (!ids_out)
-			throw StatusError{BLMX_EINVAL, "ids_out is null"};
-		std::lock_guard<std::mutex> lock(ix.mu);
-		BLMX_HIP(hipSetDevice(ix.prm.device));
-		hipStream_t s = ix.stream;
-		const uint64_t total = offsets[nseq];
-		DevBuf d_ascii, d_offs, d_koffs, d_err;
-		BLMX_HIP(d_ascii.alloc(total + 64, false, s));
-		BLMX_HIP(d_offs.alloc((nseq + 1) * 8, false, s));
-		BLMX_HIP(d_koffs.alloc((nseq + 1) * 8, false, s));
-		BLMX_HIP(d_err.alloc(4, true, s));
-		BLMX_HIP(hipMemcpyAsync(d_ascii.p, concat, total, hipMemcpyHostToDevice, s));
-		BLMX_HIP(hipMemcpyAsync(d_offs.p, offsets, (nseq + 1) * 8, hipMemcpyHostToDevice, s));
-		BLMX_HIP(hipMemcpyAsync(d_koffs.p, koffs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, s));
-		ensure(ix.q_in, nk * 8 * (size_t)ix.KW, s);
-		ensure(ix.q_out, nk * 8, s);
-		launch_sequence_kmers(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), d_koffs.as<uint64_t>(), nseq, nk, ix.q_in.p,
-		                      d_err.as<int>(), s);
-		launch_query(ix, ix.q_in.p, nullptr, nk, ix.q_out.p, kQueryIds, s);
-		int e = 0;
-		BLMX_HIP(hipMemcpyAsync(&e, d_err.p, 4, hipMemcpyDeviceToHost, s));
-		BLMX_HIP(hipMemcpyAsync(ids_out, ix.q_out.p, nk * 8, hipMemcpyDeviceToHost, s));
-		BLMX_HIP(hipStreamSynchronize(s));
-		if (e)
-			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
-		ix.st.number_query += nk;
-	});
+	return guarded(h, [&] { query_sequences_host(h->ix, concat, offsets, nseq, ids_out); });
 }
 
 int blmx_save(blmx_index* h, const char* path)
@@ -414,9 +362,10 @@ int blmx_query_kmers_device(blmx_index* h, const void* d_kmers, uint64_t nq, int
 	return guarded(h, [&] {
 		if (!h->ix.built)
 			throw StatusError{BLMX_ESTATE, "index not built"};
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_query_ids_auto(h->ix, d_kmers, nq, d_ids, s);
-		h->ix.st.number_query += nq;
+		h->ix.number_query.fetch_add(nq, std::memory_order_relaxed);
 	});
 }
 
@@ -425,6 +374,7 @@ int blmx_kmer_groups_device(blmx_index* h, const void* d_kmers, uint64_t nq, uin
 	if (!h || (nq && (!d_kmers || !d_groups)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_kmer_groups(h->ix, d_kmers, nq, d_groups, s);
 	});
@@ -435,6 +385,7 @@ int blmx_kmers_at_device(blmx_index* h, const void* d_ascii, const uint64_t* d_p
 	if (!h || (nq && (!d_ascii || !d_positions || !d_out)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_kmers_at(h->ix, reinterpret_cast<const uint8_t*>(d_ascii), d_positions, nq, d_out, d_err, s);
 	});
@@ -445,6 +396,7 @@ int blmx_canonicalize_device(blmx_index* h, void* d_kmers, uint64_t nq, void* st
 	if (!h || (nq && !d_kmers))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_canonicalize(h->ix, d_kmers, nq, s);
 	});
@@ -456,8 +408,8 @@ int blmx_set_shard(blmx_index* h, uint32_t rank, uint32_t world)
 		return BLMX_EINVAL;
 	if (h->ix.built)
 		return fail(h, BLMX_ESTATE, "blmx_set_shard must precede the build");
-	if (world == 0 || world > 255 || rank >= world)
-		return fail(h, BLMX_EINVAL, "need rank < world <= 255");
+	if (world == 0 || world > 16 || rank >= world)  // the partitioned exchange splits its bins at up to 15 shard boundaries
+		return fail(h, BLMX_EINVAL, "need rank < world <= 16");
 	h->ix.shard_rank = rank;
 	h->ix.shard_world = world;
 	return BLMX_OK;
@@ -478,6 +430,7 @@ int blmx_route_count_device(blmx_index* h, const void* d_kmers, uint64_t nq, con
 	if (!h || !d_bounds || !d_counts || world == 0 || world > 255 || (nq && (!d_kmers || !d_dest)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_route_count(h->ix, d_kmers, nq, d_bounds, world, d_dest, d_counts, s);
 	});
@@ -489,6 +442,7 @@ int blmx_route_scatter_device(blmx_index* h, const void* d_kmers, const uint8_t*
 	if (!h || !d_offsets || !d_cursor || world == 0 || world > 255 || nq >= 0xffffffffull || (nq && (!d_kmers || !d_dest || !d_sorted || !d_order)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_route_scatter(h->ix, d_kmers, d_dest, nq, d_offsets, world, d_sorted, d_order, d_cursor, s);
 	});
@@ -499,6 +453,7 @@ int blmx_unpermute_device(blmx_index* h, const int64_t* d_vals, const uint32_t* 
 	if (!h || (nq && (!d_vals || !d_order || !d_out)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		hipStream_t s = reinterpret_cast<hipStream_t>(stream);  // NULL = HIP's null stream, like any other stream
 		launch_unpermute(d_vals, d_order, nq, d_out, s);
 	});
@@ -526,7 +481,7 @@ int blmx_query_partitioned_device(blmx_index* h, const void* d_sorted_kmers, uin
 			throw StatusError{BLMX_ESTATE, "index not built"};
 		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		launch_query_partitioned(h->ix, d_sorted_kmers, nq, d_ids, reinterpret_cast<hipStream_t>(stream));
-		h->ix.st.number_query += nq;
+		h->ix.number_query.fetch_add(nq, std::memory_order_relaxed);
 	});
 }
 
@@ -548,11 +503,35 @@ int blmx_set_query_binning(blmx_index* h, int policy)
 	return BLMX_OK;
 }
 
+int blmx_set_tuning(blmx_index* h, const char* key, int value)
+{
+	if (!h || !key)
+		return BLMX_EINVAL;
+	Index& ix = h->ix;
+	const std::string k(key);
+	if (k == "bin_bits")
+		ix.tune_bin_bits = value;
+	else if (k == "mini_handoff")
+		ix.tune_mini_handoff = value;
+	else if (k == "query_heads")
+		ix.tune_query_heads = value;
+	else if (k == "reads_mode")
+		ix.tune_reads_mode = value;
+	else if (k == "window_kb")
+		ix.tune_window_kb = value;
+	else if (k == "query_binning")
+		ix.bin_policy = value < 0 ? -1 : (value > 0 ? 1 : 0);
+	else
+		return fail(h, BLMX_EINVAL, "unknown tuning key");
+	return BLMX_OK;
+}
+
 int blmx_stats(const blmx_index* h, blmx_stats_t* out)
 {
 	if (!h || !out)
 		return BLMX_EINVAL;
 	*out = h->ix.st;
+	out->number_query = h->ix.number_query.load(std::memory_order_relaxed);
 	out->nbuckets = h->ix.nbuckets;
 	out->ngroups = h->ix.ngroups;
 	out->k = h->ix.prm.k;

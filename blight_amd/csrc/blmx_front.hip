@@ -1,0 +1,687 @@
+// blmx_front.hip -- host side of the host-buffer and file entry points: query_sequence_hash / query_sequence_bool
+// (reference blight.cpp:554-591), query_kmer_hash / query_kmer_bool for batches (blight.cpp:537-550) and file_query
+// (blight.cpp:746-799) + the payload applications on top of it.
+//
+// The host never parses or encodes: it moves bytes.
+//   * One call on a few short sequences (what the reference's callers do: one query_sequence_hash per read, from OpenMP
+//     threads): the characters are copied into a pinned slot that the device reads directly, ONE fused kernel (front end +
+//     query body, blmx_reads.hip) writes the IDs straight back into the pinned slot, one stream synchronisation.  No
+//     allocation, no hipMemcpy, no lock around the GPU work: callers run concurrently on a pool of slots.
+//   * Large inputs go through two window slots (pinned staging + device scratch that persist with the index): copy-in by
+//     several host threads | H2D | kernels | D2H | copy-out overlap across windows.
+//   * Files are read into the pinned window as RAW bytes (pread by several threads, or gzread) and cut at a newline; lines,
+//     the reference's record rule and k-mer starts are found on the device (blmx_reads.hip).  Only the two recap counters
+//     come back.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+
+#include "blmx_internal.h"
+
+namespace blmx {
+
+namespace {
+
+// ---- persistent host threads for parallel copies and reads -------------------------------------------------------------------
+class WorkerPool {
+public:
+	explicit WorkerPool(unsigned nthreads)
+	{
+		for (unsigned i = 1; i < nthreads; i++)
+			th_.emplace_back([this] { loop(); });
+	}
+	~WorkerPool()
+	{
+		{
+			std::lock_guard<std::mutex> l(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto& t : th_)
+			t.join();
+	}
+	// f(i) for i in [0, njobs); returns when all are done (the caller works too).  One run at a time.
+	void run(size_t njobs, const std::function<void(size_t)>& f)
+	{
+		if (njobs == 0)
+			return;
+		if (njobs == 1 || th_.empty()) {
+			for (size_t i = 0; i < njobs; i++)
+				f(i);
+			return;
+		}
+		{
+			std::lock_guard<std::mutex> l(mu_);
+			job_ = &f;
+			njobs_ = njobs;
+			next_.store(0);
+			active_ = th_.size();
+			gen_++;
+		}
+		cv_.notify_all();
+		work();
+		std::unique_lock<std::mutex> l(mu_);
+		cv_done_.wait(l, [this] { return active_ == 0; });
+		job_ = nullptr;
+	}
+	unsigned size() const { return (unsigned)th_.size() + 1; }
+
+private:
+	void work()
+	{
+		for (;;) {
+			const size_t i = next_.fetch_add(1);
+			if (i >= njobs_)
+				break;
+			(*job_)(i);
+		}
+	}
+	void loop()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> l(mu_);
+				cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+				if (stop_)
+					return;
+				seen = gen_;
+			}
+			work();
+			std::lock_guard<std::mutex> l(mu_);
+			if (--active_ == 0)
+				cv_done_.notify_one();
+		}
+	}
+	std::vector<std::thread> th_;
+	std::mutex mu_;
+	std::condition_variable cv_, cv_done_;
+	const std::function<void(size_t)>* job_ = nullptr;
+	size_t njobs_ = 0;
+	std::atomic<size_t> next_{0};
+	size_t active_ = 0;
+	uint64_t gen_ = 0;
+	bool stop_ = false;
+};
+
+constexpr size_t kCopyPiece = 4u << 20;
+
+void parallel_copy(WorkerPool& pool, void* dst, const void* src, size_t n)
+{
+	if (n <= kCopyPiece) {
+		memcpy(dst, src, n);
+		return;
+	}
+	const size_t pieces = (n + kCopyPiece - 1) / kCopyPiece;
+	pool.run(pieces, [&](size_t i) {
+		const size_t a = i * kCopyPiece, z = std::min(n, a + kCopyPiece);
+		memcpy((char*)dst + a, (const char*)src + a, z - a);
+	});
+}
+
+// ---- slots -----------------------------------------------------------------------------------------------------------------------
+struct WindowSlot {
+	Pinned h_in, h_aux, h_out, h_flags;
+	DevBuf d_in, d_aux, d_kmers, d_minis, d_ids, d_flags;
+	FrontScratch fs;
+	hipStream_t s = nullptr;
+	hipEvent_t done = nullptr;
+	bool in_flight = false;
+	uint64_t nk = 0, out_index = 0;  // results of the window in flight: count and where they go in the caller's array
+	size_t out_elem = 8;
+	~WindowSlot()
+	{
+		if (done)
+			(void)hipEventDestroy(done);
+		if (s)
+			(void)hipStreamDestroy(s);
+	}
+};
+
+constexpr size_t kSmallSlotBytes = 1u << 20;
+constexpr unsigned kSmallSlots = 8;
+constexpr uint64_t kSmallChars = 48u << 10;  // one fused launch answers up to this many characters ...
+constexpr uint64_t kSmallSeqs = 1024;        // ... of up to this many sequences, read directly from the pinned slot
+constexpr uint64_t kSmallKmers = 8192;       // k-mer batches up to this size: one launch on a pinned slot
+
+struct SmallSlot {
+	Pinned h;
+	hipStream_t s = nullptr;
+	~SmallSlot()
+	{
+		if (s)
+			(void)hipStreamDestroy(s);
+	}
+};
+
+void grow(DevBuf& b, size_t bytes, hipStream_t s)
+{
+	if (bytes > b.bytes)
+		BLMX_HIP(b.alloc(bytes + bytes / 4 + 256, false, s));
+}
+
+}  // namespace
+
+struct HostFront {
+	WindowSlot win[2];
+	std::vector<std::unique_ptr<SmallSlot>> small_all;
+	std::vector<SmallSlot*> small_free;
+	std::mutex small_mu;
+	std::condition_variable small_cv;
+	std::unique_ptr<WorkerPool> pool;
+	DevBuf d_counts, d_carry;  // file streaming: found / not found, line carry between windows
+};
+
+void destroy_host_front(HostFront* hf) { delete hf; }
+
+namespace {
+
+HostFront& host_front(Index& ix)
+{
+	std::lock_guard<std::mutex> l(ix.hf_mu);
+	if (!ix.hf) {
+		std::unique_ptr<HostFront> hf(new HostFront());
+		const char* e = getenv("BLIGHT_HOST_THREADS");
+		if (!e)
+			e = getenv("BLIGHT_PARSE_THREADS");
+		const unsigned hw = std::thread::hardware_concurrency();
+		unsigned nt = e ? (unsigned)atoi(e) : (hw && hw < 16 ? hw : 16u);
+		nt = nt < 1 ? 1u : (nt > 64 ? 64u : nt);
+		hf->pool.reset(new WorkerPool(nt));
+		ix.hf = hf.release();
+	}
+	return *ix.hf;
+}
+
+void prepare_window_slot(WindowSlot& w)
+{
+	if (!w.s)
+		BLMX_HIP(hipStreamCreateWithFlags(&w.s, hipStreamNonBlocking));
+	if (!w.done)
+		BLMX_HIP(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+	w.h_flags.ensure(64);
+	if (!w.d_flags.p)
+		BLMX_HIP(w.d_flags.alloc(64, true, w.s));
+}
+
+struct SmallLease {
+	HostFront& hf;
+	SmallSlot* sl;
+	SmallLease(Index& ix, HostFront& h) : hf(h), sl(nullptr)
+	{
+		std::unique_lock<std::mutex> l(hf.small_mu);
+		for (;;) {
+			if (!hf.small_free.empty()) {
+				sl = hf.small_free.back();
+				hf.small_free.pop_back();
+				return;
+			}
+			if (hf.small_all.size() < kSmallSlots) {
+				std::unique_ptr<SmallSlot> n(new SmallSlot());
+				BLMX_HIP(hipSetDevice(ix.prm.device));
+				n->h.ensure(kSmallSlotBytes);
+				BLMX_HIP(hipStreamCreateWithFlags(&n->s, hipStreamNonBlocking));
+				sl = n.get();
+				hf.small_all.push_back(std::move(n));
+				return;
+			}
+			hf.small_cv.wait(l);
+		}
+	}
+	~SmallLease()
+	{
+		{
+			std::lock_guard<std::mutex> l(hf.small_mu);
+			hf.small_free.push_back(sl);
+		}
+		hf.small_cv.notify_one();
+	}
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+uint64_t window_positions(const Index& ix)
+{
+	const uint64_t kb = ix.tune_window_kb > 0 ? (uint64_t)ix.tune_window_kb : 32768;
+	return std::min<uint64_t>(kb << 10, 1ull << 31);
+}
+
+// front end -> IDs of the nk k-mers of a window whose VALID bitmap is in w.fs (or counters only)
+void query_window(Index& ix, WindowSlot& w, uint64_t nbytes, uint64_t npos, uint64_t nk, bool want_ids, unsigned long long* d_counts)
+{
+	const bool binned = !read_query_fusable(ix) || ix.tune_reads_mode == 2 || (ix.tune_reads_mode == 0 && query_batch_worth_binning(ix, nk));
+	int* d_err = w.d_flags.as<int>();
+	if (binned) {
+		grow(w.d_kmers, nk * 8 * (size_t)ix.KW, w.s);
+		grow(w.d_minis, nk * 4, w.s);
+		grow(w.d_ids, nk * 8, w.s);
+		launch_read_front(ix, &w.fs, w.d_in.as<uint8_t>(), nbytes, npos, nullptr, nullptr, 0, w.d_kmers.p, w.d_minis.as<uint32_t>(), d_err, w.s);
+		launch_query_ids_with_minis(ix, w.d_kmers.p, w.d_minis.as<uint32_t>(), nk, w.d_ids.as<int64_t>(), w.s);
+		if (d_counts)
+			launch_count_found(w.d_ids.as<int64_t>(), nk, d_counts, w.s);
+	} else {
+		if (want_ids)
+			grow(w.d_ids, nk * 8, w.s);
+		launch_read_query(ix, &w.fs, w.d_in.as<uint8_t>(), nbytes, npos, nullptr, nullptr, 0, want_ids ? w.d_ids.as<int64_t>() : nullptr, d_counts,
+		                  d_err, w.s);
+	}
+}
+
+}  // namespace
+
+// ---- query_sequence_hash for nseq sequences (reference blight.cpp:575-591) -----------------------------------------------------
+void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	const uint64_t k = ix.prm.k;
+	if (nseq == 0)
+		return;
+	for (uint64_t i = 0; i < nseq; i++)
+		if (offsets[i + 1] < offsets[i])
+			throw StatusError{BLMX_EINVAL, "offsets must be non-decreasing"};
+	const uint64_t a0 = offsets[0], total = offsets[nseq];
+	std::vector<uint64_t> koffs(nseq + 1, 0);
+	for (uint64_t i = 0; i < nseq; i++) {
+		const uint64_t len = offsets[i + 1] - offsets[i];
+		koffs[i + 1] = koffs[i] + (len >= k ? len - k + 1 : 0);  // blight.cpp:577-579: shorter than k -> nothing
+	}
+	const uint64_t nk_all = koffs[nseq];
+	if (nk_all == 0)
+		return;
+	if (!ids_out)
+		throw StatusError{BLMX_EINVAL, "ids_out is null"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	HostFront& hf = host_front(ix);
+	// ---- one launch on a pinned slot
+	if (total - a0 <= kSmallChars && nseq <= kSmallSeqs && read_query_fusable(ix)) {
+		SmallLease lease(ix, hf);
+		SmallSlot& sl = *lease.sl;
+		const uint64_t nbytes = total - a0;
+		char* base = sl.h.as<char>();
+		const size_t o_offs = align_up(nbytes + 64, 64), o_koffs = o_offs + (nseq + 1) * 8, o_err = o_koffs + (nseq + 1) * 8,
+		             o_ids = align_up(o_err + 8, 64);
+		memcpy(base, concat + a0, nbytes);
+		uint64_t* h_offs = reinterpret_cast<uint64_t*>(base + o_offs);
+		for (uint64_t i = 0; i <= nseq; i++)
+			h_offs[i] = offsets[i] - a0;
+		memcpy(base + o_koffs, koffs.data(), (nseq + 1) * 8);
+		int* h_err = reinterpret_cast<int*>(base + o_err);
+		*h_err = 0;
+		launch_read_query(ix, nullptr, reinterpret_cast<const uint8_t*>(base), nbytes, nbytes, h_offs, reinterpret_cast<const uint64_t*>(base + o_koffs), nseq,
+		                  reinterpret_cast<int64_t*>(base + o_ids), nullptr, h_err, sl.s);
+		BLMX_HIP(hipStreamSynchronize(sl.s));
+		if (*h_err)
+			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
+		memcpy(ids_out, base + o_ids, nk_all * 8);
+		ix.number_query.fetch_add(nk_all, std::memory_order_relaxed);
+		return;
+	}
+	// ---- windows in position space: k-mers may start at [A, B), the window holds the characters [A, B + k - 1)
+	std::lock_guard<std::mutex> lock(ix.mu);
+	const uint64_t W = window_positions(ix);
+	auto kmers_before = [&](uint64_t P) -> uint64_t {  // k-mers that start before position P
+		if (P <= a0)
+			return 0;
+		if (P >= total)
+			return nk_all;
+		const uint64_t s = (uint64_t)(std::upper_bound(offsets, offsets + nseq + 1, P) - offsets) - 1;  // offsets[s] <= P < offsets[s+1]
+		return koffs[s] + std::min(P - offsets[s], koffs[s + 1] - koffs[s]);
+	};
+	auto finish = [&](WindowSlot& w) {
+		if (!w.in_flight)
+			return;
+		BLMX_HIP(hipEventSynchronize(w.done));
+		w.in_flight = false;
+		if (w.h_flags.as<int>()[0])
+			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
+		parallel_copy(*hf.pool, ids_out + w.out_index, w.h_out.p, w.nk * 8);
+	};
+	struct Drain {  // an exception must not leave copies into the caller's buffers in flight
+		HostFront& hf;
+		~Drain()
+		{
+			for (auto& w : hf.win)
+				if (w.in_flight) {
+					(void)hipEventSynchronize(w.done);
+					w.in_flight = false;
+				}
+		}
+	} drain{hf};
+	int cur = 0;
+	for (uint64_t A = a0; A < total; A += W) {
+		const uint64_t B = std::min(A + W, total), nbytes = std::min(B + k - 1, total) - A, npos = B - A;
+		const uint64_t nk0 = kmers_before(A), nk = kmers_before(B) - nk0;
+		if (nk == 0)
+			continue;
+		WindowSlot& w = hf.win[cur];
+		cur ^= 1;
+		prepare_window_slot(w);
+		finish(w);
+		// sequences that overlap the window's characters: their starts break k-mers
+		const uint64_t s_lo = (uint64_t)(std::upper_bound(offsets, offsets + nseq + 1, A) - offsets) - 1;
+		const uint64_t s_hi = (uint64_t)(std::lower_bound(offsets, offsets + nseq + 1, A + nbytes) - offsets);  // first start >= end of window
+		const uint64_t ns = std::min(s_hi, nseq) - s_lo;
+		w.h_in.ensure(nbytes + 64);
+		parallel_copy(*hf.pool, w.h_in.p, concat + A, nbytes);
+		w.h_aux.ensure((ns + 1) * 8);
+		memcpy(w.h_aux.p, offsets + s_lo, (ns + 1) * 8);
+		grow(w.d_in, nbytes + 64, w.s);
+		grow(w.d_aux, (ns + 1) * 8, w.s);
+		BLMX_HIP(hipMemcpyAsync(w.d_in.p, w.h_in.p, nbytes, hipMemcpyHostToDevice, w.s));
+		BLMX_HIP(hipMemcpyAsync(w.d_aux.p, w.h_aux.p, (ns + 1) * 8, hipMemcpyHostToDevice, w.s));
+		BLMX_HIP(hipMemsetAsync(w.d_flags.p, 0, 16, w.s));
+		front_valid_concat(ix, w.fs, w.d_aux.as<uint64_t>(), ns + 1, A, npos, nbytes, w.s);
+		query_window(ix, w, nbytes, npos, nk, true, nullptr);
+		w.h_out.ensure(nk * 8);
+		BLMX_HIP(hipMemcpyAsync(w.h_out.p, w.d_ids.p, nk * 8, hipMemcpyDeviceToHost, w.s));
+		BLMX_HIP(hipMemcpyAsync(w.h_flags.p, w.d_flags.p, 4, hipMemcpyDeviceToHost, w.s));
+		BLMX_HIP(hipEventRecord(w.done, w.s));
+		w.in_flight = true;
+		w.nk = nk;
+		w.out_index = nk0;
+	}
+	finish(hf.win[0]);
+	finish(hf.win[1]);
+	ix.number_query.fetch_add(nk_all, std::memory_order_relaxed);
+}
+
+// ---- query_kmer_hash / query_kmer_bool / query_get_hash / query_get_pos_unitig for a host batch (blight.cpp:537-550, 686-742) ----
+void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	if (nq == 0)
+		return;
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	HostFront& hf = host_front(ix);
+	const size_t kb = (size_t)ix.KW * 8;
+	const size_t ob = mode == kQueryIds ? 8 : (mode == kQueryPos ? 4 : 1);
+	if (nq <= kSmallKmers) {  // one launch on a pinned slot the device reads and writes directly (scalar calls of the facade land here)
+		SmallLease lease(ix, hf);
+		SmallSlot& sl = *lease.sl;
+		char* base = sl.h.as<char>();
+		const size_t o_minis = align_up(nq * kb, 64), o_out = o_minis + align_up(nq * 4, 64);
+		memcpy(base, kmers, nq * kb);
+		if (minis)
+			memcpy(base + o_minis, minis, nq * 4);
+		launch_query(ix, base, minis ? reinterpret_cast<const uint32_t*>(base + o_minis) : nullptr, nq, base + o_out, mode, sl.s);
+		BLMX_HIP(hipStreamSynchronize(sl.s));
+		memcpy(out, base + o_out, nq * ob);
+		ix.number_query.fetch_add(nq, std::memory_order_relaxed);  // blight.cpp:717-718
+		return;
+	}
+	// chunks through the two window slots: copy-in (host threads) | H2D | kernels | D2H | copy-out overlap
+	std::lock_guard<std::mutex> lock(ix.mu);
+	const uint64_t C = std::max<uint64_t>(1u << 16, window_positions(ix) / 2);  // k-mers per chunk
+	auto finish = [&](WindowSlot& w) {
+		if (!w.in_flight)
+			return;
+		BLMX_HIP(hipEventSynchronize(w.done));
+		w.in_flight = false;
+		parallel_copy(*hf.pool, (char*)out + w.out_index * w.out_elem, w.h_out.p, w.nk * w.out_elem);
+	};
+	struct Drain {
+		HostFront& hf;
+		~Drain()
+		{
+			for (auto& w : hf.win)
+				if (w.in_flight) {
+					(void)hipEventSynchronize(w.done);
+					w.in_flight = false;
+				}
+		}
+	} drain{hf};
+	int cur = 0;
+	for (uint64_t a = 0; a < nq; a += C) {
+		const uint64_t n = std::min(C, nq - a);
+		WindowSlot& w = hf.win[cur];
+		cur ^= 1;
+		prepare_window_slot(w);
+		finish(w);
+		w.h_in.ensure(n * kb);
+		parallel_copy(*hf.pool, w.h_in.p, (const char*)kmers + a * kb, n * kb);
+		grow(w.d_kmers, n * kb, w.s);
+		grow(w.d_ids, n * 8, w.s);
+		BLMX_HIP(hipMemcpyAsync(w.d_kmers.p, w.h_in.p, n * kb, hipMemcpyHostToDevice, w.s));
+		const uint32_t* d_minis = nullptr;
+		if (minis) {
+			w.h_aux.ensure(n * 4);
+			memcpy(w.h_aux.p, minis + a, n * 4);
+			grow(w.d_minis, n * 4, w.s);
+			BLMX_HIP(hipMemcpyAsync(w.d_minis.p, w.h_aux.p, n * 4, hipMemcpyHostToDevice, w.s));
+			d_minis = w.d_minis.as<uint32_t>();
+		}
+		if (mode == kQueryIds && !d_minis)
+			launch_query_ids_auto(ix, w.d_kmers.p, n, w.d_ids.as<int64_t>(), w.s);
+		else
+			launch_query(ix, w.d_kmers.p, d_minis, n, w.d_ids.p, mode, w.s);
+		w.h_out.ensure(n * ob);
+		BLMX_HIP(hipMemcpyAsync(w.h_out.p, w.d_ids.p, n * ob, hipMemcpyDeviceToHost, w.s));
+		BLMX_HIP(hipEventRecord(w.done, w.s));
+		w.in_flight = true;
+		w.nk = n;
+		w.out_index = a;
+		w.out_elem = ob;
+	}
+	finish(hf.win[0]);
+	finish(hf.win[1]);
+	ix.number_query.fetch_add(nq, std::memory_order_relaxed);
+}
+
+// ---- file_query (reference blight.cpp:746-799) and the payload applications' file pass ------------------------------------------
+namespace {
+
+// raw bytes of a plain or gzip file, window after window, each cut behind its last newline
+class RawFile {
+public:
+	explicit RawFile(const char* path)
+	{
+		fd_ = open(path, O_RDONLY);
+		if (fd_ < 0)
+			return;
+		unsigned char magic[2] = {0, 0};
+		const ssize_t got = pread(fd_, magic, 2, 0);
+		struct stat st;
+		const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+		if (!gz && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode)) {
+			size_ = (uint64_t)st.st_size;
+			ok_ = true;
+			return;
+		}
+		close(fd_);
+		fd_ = -1;
+		gz_ = gzopen(path, "rb");
+		if (gz_) {
+			gzbuffer(gz_, 1 << 20);
+			ok_ = true;
+		}
+	}
+	~RawFile()
+	{
+		if (fd_ >= 0)
+			close(fd_);
+		if (gz_)
+			gzclose(gz_);
+	}
+	RawFile(const RawFile&) = delete;
+	RawFile& operator=(const RawFile&) = delete;
+	bool ok() const { return ok_; }
+
+	// Fills `pin` with the next window (about `want` bytes, more when a line is longer) and returns its length; 0 = end of file.
+	// Every window but the last ends behind a newline.
+	uint64_t next(Pinned& pin, uint64_t want, WorkerPool& pool)
+	{
+		uint64_t have = 0;
+		if (!tail_.empty()) {  // gzip: the bytes behind the previous window's last newline
+			pin.ensure(tail_.size() + want + 64);
+			memcpy(pin.p, tail_.data(), tail_.size());
+			have = tail_.size();
+			tail_.clear();
+		}
+		for (;;) {
+			pin.ensure(have + want + 64, have);
+			const uint64_t got = read_more(pin.as<char>() + have, want, pool);
+			have += got;
+			const bool eof = got < want;
+			if (have == 0)
+				return 0;
+			if (eof)
+				return have;
+			const char* nl = (const char*)memrchr(pin.as<char>(), '\n', have);
+			if (nl) {
+				const uint64_t wlen = (uint64_t)(nl - pin.as<char>()) + 1;
+				if (fd_ >= 0)
+					pos_ -= have - wlen;  // plain file: the rest is read again with the next window
+				else
+					tail_.assign(pin.as<char>() + wlen, pin.as<char>() + have);
+				return wlen;
+			}
+			want = std::max<uint64_t>(want, have);  // one line longer than the window: double it
+		}
+	}
+
+private:
+	uint64_t read_more(char* dst, uint64_t want, WorkerPool& pool)
+	{
+		if (fd_ >= 0) {
+			const uint64_t n = pos_ < size_ ? std::min(want, size_ - pos_) : 0;
+			const size_t pieces = (size_t)((n + kCopyPiece - 1) / kCopyPiece);
+			std::atomic<bool> bad{false};
+			const uint64_t pos = pos_;
+			const int fd = fd_;
+			pool.run(pieces, [&](size_t i) {
+				uint64_t a = (uint64_t)i * kCopyPiece;
+				const uint64_t z = std::min(n, a + kCopyPiece);
+				while (a < z) {
+					const ssize_t r = pread(fd, dst + a, z - a, (off_t)(pos + a));
+					if (r <= 0) {
+						bad = true;
+						return;
+					}
+					a += (uint64_t)r;
+				}
+			});
+			if (bad)
+				throw StatusError{BLMX_EIO, "read error"};
+			pos_ += n;
+			return n;
+		}
+		uint64_t n = 0;
+		while (n < want) {
+			const int r = gzread(gz_, dst + n, (unsigned)std::min<uint64_t>(want - n, 1u << 30));
+			if (r < 0)
+				throw StatusError{BLMX_EIO, "gzip read error"};
+			if (r == 0)
+				break;
+			n += (uint64_t)r;
+		}
+		return n;
+	}
+	int fd_ = -1;
+	gzFile gz_ = nullptr;
+	uint64_t size_ = 0, pos_ = 0;
+	std::vector<char> tail_;
+	bool ok_ = false;
+};
+
+// mode 0: 2-line FASTA records (file_query); mode 1: every line that starts with A/C/G/T (the payload snippets)
+void stream_file(Index& ix, const char* path, int mode, Payload* payload, uint32_t color, uint64_t& good, uint64_t& erroneous)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	RawFile rf(path);
+	if (!rf.ok())
+		throw StatusError{BLMX_EIO, "Problem with files opening"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	HostFront& hf = host_front(ix);
+	for (auto& w : hf.win)
+		prepare_window_slot(w);
+	hipStream_t s0 = hf.win[0].s;
+	if (!hf.d_counts.p)
+		BLMX_HIP(hf.d_counts.alloc(16, false, s0));
+	if (!hf.d_carry.p)
+		BLMX_HIP(hf.d_carry.alloc(32, false, s0));
+	BLMX_HIP(hipMemsetAsync(hf.d_counts.p, 0, 16, s0));
+	BLMX_HIP(hipMemsetAsync(hf.d_carry.p, 0, 32, s0));
+	BLMX_HIP(hipStreamSynchronize(s0));
+	auto finish = [&](WindowSlot& w) {
+		if (!w.in_flight)
+			return;
+		BLMX_HIP(hipEventSynchronize(w.done));
+		w.in_flight = false;
+		if (w.h_flags.as<int>()[4])
+			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
+	};
+	struct Drain {
+		HostFront& hf;
+		~Drain()
+		{
+			for (auto& w : hf.win)
+				if (w.in_flight) {
+					(void)hipEventSynchronize(w.done);
+					w.in_flight = false;
+				}
+		}
+	} drain{hf};
+	const uint64_t W = window_positions(ix);
+	uint64_t queries = 0;
+	unsigned long long* d_counts = hf.d_counts.as<unsigned long long>();
+	for (uint64_t i = 0;; i++) {
+		WindowSlot& w = hf.win[i & 1];
+		finish(w);
+		const uint64_t nbytes = rf.next(w.h_in, W, *hf.pool);
+		if (nbytes == 0)
+			break;
+		if (nbytes >= 0xffffffc0ull)
+			throw StatusError{BLMX_ELIMIT, "a line of 4 GiB or more"};
+		grow(w.d_in, nbytes + 64, w.s);
+		BLMX_HIP(hipMemcpyAsync(w.d_in.p, w.h_in.p, nbytes, hipMemcpyHostToDevice, w.s));
+		BLMX_HIP(hipMemsetAsync(w.d_flags.p, 0, 16, w.s));
+		uint64_t* carry = hf.d_carry.as<uint64_t>();
+		front_valid_raw(ix, w.fs, w.d_in.as<uint8_t>(), nbytes, mode, carry + 2 * (i & 1), carry + 2 * ((i + 1) & 1), nullptr, w.s);
+		const uint64_t nwords = (nbytes + 63) / 64;
+		BLMX_HIP(hipMemcpyAsync(w.h_flags.p, w.fs.vpre.as<uint32_t>() + nwords, 4, hipMemcpyDeviceToHost, w.s));
+		BLMX_HIP(hipStreamSynchronize(w.s));  // the number of k-mers sizes the rest of the window's work
+		const uint64_t nk = w.h_flags.as<uint32_t>()[0];
+		if (nk) {
+			query_window(ix, w, nbytes, nbytes, nk, payload != nullptr, d_counts);
+			if (payload)
+				payload_add_ids(*payload, w.d_ids.as<int64_t>(), nk, color, w.s);
+		}
+		BLMX_HIP(hipMemcpyAsync(w.h_flags.as<int>() + 4, w.d_flags.p, 4, hipMemcpyDeviceToHost, w.s));
+		BLMX_HIP(hipEventRecord(w.done, w.s));
+		w.in_flight = true;
+		queries += nk;
+	}
+	finish(hf.win[0]);
+	finish(hf.win[1]);
+	uint64_t h_counts[2] = {0, 0};
+	BLMX_HIP(hipMemcpy(h_counts, hf.d_counts.p, 16, hipMemcpyDeviceToHost));
+	good = h_counts[0];
+	erroneous = h_counts[1];
+	ix.number_query.fetch_add(queries, std::memory_order_relaxed);
+}
+
+}  // namespace
+
+// file_query: returns good / erroneous k-mer counts (the reference prints them: "Good kmer", "Erroneous kmers").
+void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous) { stream_file(ix, path, 0, nullptr, 0, good, erroneous); }
+
+void payload_add_file(Payload& pl, const char* path, uint32_t color, uint64_t& found, uint64_t& absent)
+{
+	if (pl.kind == 1 && color >= pl.ncolors)
+		throw StatusError{BLMX_EINVAL, "colour out of range"};
+	stream_file(*pl.ix, path, 1, &pl, color, found, absent);
+}
+
+}  // namespace blmx

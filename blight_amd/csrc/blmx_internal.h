@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -164,6 +165,35 @@ struct StatusError {
 	std::string msg;
 };
 
+// ---- pinned host staging buffer (grow-only; `keep` bytes survive a grow) -----------------------------------------------------
+struct Pinned {
+	void* p = nullptr;
+	size_t bytes = 0;
+	Pinned() = default;
+	Pinned(const Pinned&) = delete;
+	Pinned& operator=(const Pinned&) = delete;
+	~Pinned()
+	{
+		if (p)
+			(void)hipHostFree(p);
+	}
+	void ensure(size_t n, size_t keep = 0);  // blmx_stream.hip
+	template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// device scratch of the sequence / read front end (blmx_reads.hip): bitmaps of one window and their popcount prefixes
+struct FrontScratch {
+	DevBuf marks;  // sequence-start bitmap (concatenated sequences) or newline bitmap (raw FASTA bytes)
+	DevBuf mpre;   // raw: newlines before each 64-position word
+	DevBuf nlpos;  // raw: position of every newline (+ the end of the unterminated last line)
+	DevBuf ok;     // raw: per line, 1 = its k-mers are queried
+	DevBuf valid;  // bit q = a k-mer starts at window position q
+	DevBuf vpre;   // k-mers that start before each 64-position word (the last entry = all of them)
+	DevBuf tmp;    // rocPRIM scan scratch
+};
+struct HostFront;  // blmx_stream.hip: pinned staging, window slots, small-call slots and worker threads of one index
+void destroy_host_front(HostFront*);
+
 #define BLMX_HIP(expr)                                                                                         \
 	do {                                                                                                       \
 		hipError_t _e = (expr);                                                                                \
@@ -181,8 +211,10 @@ struct Index {
 	uint32_t shard_rank = 0, shard_world = 1;
 	std::vector<uint32_t> shard_bounds;  // world + 1 group boundaries (identical on every rank)
 	hipStream_t stream = nullptr;
-	std::string err;
-	std::mutex mu;  // serialises host-buffer queries (shared staging buffers)
+	std::mutex mu;  // serialises the large host-buffer / file operations (they share the window slots)
+	std::atomic<uint64_t> number_query{0};  // blight.h:56; incremented atomically like the reference (blight.cpp:687-688, 717-718)
+	HostFront* hf = nullptr;                // created on first use (blmx_stream.hip)
+	std::mutex hf_mu;
 
 	// finished index (HBM)
 	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks;
@@ -201,7 +233,13 @@ struct Index {
 	hipEvent_t bin_done = nullptr;       // recorded after each binned pipeline: a call on another stream waits for it
 	hipStream_t bin_last_stream = nullptr;
 	bool bin_used = false;
-	int bin_policy = 0;  // 0 = automatic, 1 = always bin, -1 = never (BLIGHT_QUERY_BINNING env / blmx_set_query_binning)
+	int bin_policy = 0;  // 0 = automatic, 1 = always bin, -1 = never (BLIGHT_QUERY_BINNING env at creation / blmx_set_query_binning)
+	// per-index tuning knobs (blmx_set_tuning; the BLIGHT_* environment variables of the same name seed them at creation)
+	int tune_bin_bits = 0;       // partition bins = 2^bits (0 = default)
+	int tune_mini_handoff = -1;  // partition pass hands the minimizers to the query kernel: 1 / 0 / -1 = automatic
+	int tune_query_heads = 1;    // 0 = query kernels read the full group descriptor instead of the compact 32-B head
+	int tune_reads_mode = 0;     // sequence / file queries: 0 = automatic, 1 = always fused front end + query, 2 = always front end -> binned pipeline
+	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
 
 	Index()
 	{
@@ -221,7 +259,7 @@ struct Index {
 		v.ngroups = ngroups;
 		v.buckets = buckets.as<BucketDesc>();
 		v.groups = groups.as<GroupDesc>();
-		v.qheads = has_qheads ? qheads.as<QueryHead>() : nullptr;
+		v.qheads = (has_qheads && tune_query_heads) ? qheads.as<QueryHead>() : nullptr;
 		v.seq = seq.as<uint64_t>();
 		v.positions = positions.as<uint64_t>();
 		v.lines = lines.as<uint64_t>();
@@ -248,9 +286,27 @@ void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorte
 void launch_query_partitioned(Index& ix, const void* d_sorted_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s);
 void launch_gather_ids(Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s);
 void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s);
-// rolling canonical k-mers of ASCII sequences -> canonical k-mer array (KW words each); returns via d_err (BLMX_EDNA)
-void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, const uint64_t* d_kmer_offs,
-                           uint64_t nseq, uint64_t total_len, void* d_kmers_out, int* d_err, hipStream_t s);
+// same with the minimizers already known (read front end): the partition pass reads them instead of hashing 23 m-mers per
+// k-mer, and they travel with the k-mers to the query kernel
+void launch_query_ids_with_minis(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, hipStream_t s);
+bool query_batch_worth_binning(const Index& ix, uint64_t nq);
+// sequence / read front end (blmx_reads.hip).  A window = nbytes characters in device-visible memory; k-mers may start at its
+// first npos positions.  front_valid_* fill fs.valid / fs.vpre; launch_read_front writes canonical k-mers + minimizers in
+// position order, launch_read_query answers them in the same launch (ids and / or found / not-found counters).  With
+// fs == nullptr the k-mer positions come from a binary search in offs / koffs (few sequences; pointers may be pinned host memory).
+void front_valid_concat(const Index& ix, FrontScratch& fs, const uint64_t* d_offs, uint64_t nseq, uint64_t origin, uint64_t npos, uint64_t nbytes,
+                        hipStream_t s);
+void front_valid_raw(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, uint64_t nbytes, int mode, const uint64_t* d_carry_in,
+                     uint64_t* d_carry_out, int* d_short_flag, hipStream_t s);
+void launch_read_front(const Index& ix, const FrontScratch* fs, const uint8_t* d_bytes, uint64_t nbytes, uint64_t npos, const uint64_t* offs,
+                       const uint64_t* koffs, uint64_t nseq, void* d_kmers, uint32_t* d_minis, int* d_err, hipStream_t s);
+void launch_read_query(const Index& ix, const FrontScratch* fs, const uint8_t* d_bytes, uint64_t nbytes, uint64_t npos, const uint64_t* offs,
+                       const uint64_t* koffs, uint64_t nseq, int64_t* d_ids, unsigned long long* d_counts, int* d_err, hipStream_t s);
+bool read_query_fusable(const Index& ix);
+// host-buffer entry points (blmx_stream.hip): pinned staging, windows in flight, small-call slots
+void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
+void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode);
+void launch_count_found(const int64_t* d_ids, uint64_t n, unsigned long long* d_counts, hipStream_t s);
 void launch_kmers_at(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_pos, uint64_t nq, void* d_out, int* d_err, hipStream_t s);
 void launch_canonicalize(const Index& ix, void* d_kmers, uint64_t nq, hipStream_t s);
 void launch_route_count(const Index& ix, const void* d_kmers, uint64_t nq, const uint32_t* d_bounds, uint32_t world, uint8_t* d_dest,

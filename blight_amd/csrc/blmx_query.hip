@@ -1,225 +1,23 @@
-// blmx_query.hip -- gfx950 query kernels of the Blight hot path.
+// blmx_query.hip -- gfx950 batch query kernels of the Blight hot path.
 //
 // One lane answers one k-mer (reference query_kmer_hash -> query_get_hash, blight.cpp:545-550, 716-742):
 //   canonical k-mer -> minimizer (kmer.h:791-810) -> bucket descriptor (16 B) -> group descriptor -> BBHash probe
-//   (bbhash.h:561-577, 617-663; one 64-B line per probed level, rank word interleaved) -> position field
+//   (bbhash.h:561-577, 617-663; one 16-B line [u32 rank | 96 level bits] per probed level) -> position field
 //   (blight.cpp:473-482) -> 2^b window of the packed sequence (blight.cpp:729-739) compared in registers.
-// The path is a chain of ~4 dependent random 64-B sector reads per k-mer: HBM-latency/sector bound, no MFMA.
+// The path is a chain of ~5 dependent random accesses per k-mer (query_device.h): latency / line-rate bound, no MFMA.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "blmx_internal.h"
 #include "index_device.h"
+#include "query_device.h"
 
 namespace blmx {
-
-// The 2^b scan of query_get_hash / query_get_pos_unitig (blight.cpp:729-739 / 699-709).
-// canon(stored) == x  <=>  stored in {x, rc(x)} when x is canonical (x <= rc(x)); a non-canonical x never matches, so
-// no reverse complement is computed inside the loop.  Like the reference the scan ignores super-k-mer and bucket
-// boundaries.  Branch-free formulation for wave64: the window (NW words) is preloaded into registers, the 32*KW
-// nucleotides at the current position are kept TOP-ALIGNED in 32-bit words c[0..2KW) and advanced by one nucleotide
-// with a v_alignbit chain; the stream of following nucleotides is pre-aligned per lane (S[r] = the 32 nucleotides that
-// enter during segment r), so that every lane runs exactly 2^b steps with wave-uniform trip counts and refills.
-// A step = mask + xor/or compare against x and rc(x) + one v_min3; no exec-mask juggling, no branches.
-// ID / membership mode: returns 0 on any match, -1 otherwise (the ID does not depend on WHICH position matched,
-// blight.cpp:736).  WANT_POS: returns the index j of the FIRST match in [0, 2^LOGP) (blight.cpp:706) or -1.
-template <int KW, int LOGP, bool WANT_POS, int NW>
-__device__ __forceinline__ int scan_window_exact(const uint64_t (&W)[NW], int s0, int k, Kmer<KW> x, Kmer<KW> xr)
-{
-	constexpr int P = 1 << LOGP;
-	constexpr int NSEG = (P + 31) / 32;  // 32-step segments, one pre-aligned stream word each
-	constexpr int NWORD = 2 * KW;
-	// top-aligned window and query words, most significant first
-	uint32_t c[NWORD], X[NWORD], XR[NWORD], M[NWORD];
-	const int sh = 64 * KW - 2 * k;  // insignificant low bits of the top-aligned window
-	if constexpr (KW == 1) {
-		const uint64_t cur = funnel_left(W[0], W[1], 2 * s0);
-		const uint64_t xt = x.lo << sh, xrt = xr.lo << sh;
-		c[0] = (uint32_t)(cur >> 32);
-		c[1] = (uint32_t)cur;
-		X[0] = (uint32_t)(xt >> 32);
-		X[1] = (uint32_t)xt;
-		XR[0] = (uint32_t)(xrt >> 32);
-		XR[1] = (uint32_t)xrt;
-	} else {
-		const uint64_t ch = funnel_left(W[0], W[1], 2 * s0), cl = funnel_left(W[1], W[2], 2 * s0);
-		uint64_t xh, xl, xrh, xrl;
-		if (sh >= 64) {
-			xh = x.lo << (sh - 64);
-			xl = 0;
-			xrh = xr.lo << (sh - 64);
-			xrl = 0;
-		} else {
-			xh = (x.hi << sh) | (sh ? (x.lo >> (64 - sh)) : 0ull);
-			xl = x.lo << sh;
-			xrh = (xr.hi << sh) | (sh ? (xr.lo >> (64 - sh)) : 0ull);
-			xrl = xr.lo << sh;
-		}
-		c[0] = (uint32_t)(ch >> 32);
-		c[1] = (uint32_t)ch;
-		c[2] = (uint32_t)(cl >> 32);
-		c[3] = (uint32_t)cl;
-		X[0] = (uint32_t)(xh >> 32);
-		X[1] = (uint32_t)xh;
-		X[2] = (uint32_t)(xl >> 32);
-		X[3] = (uint32_t)xl;
-		XR[0] = (uint32_t)(xrh >> 32);
-		XR[1] = (uint32_t)xrh;
-		XR[2] = (uint32_t)(xrl >> 32);
-		XR[3] = (uint32_t)xrl;
-	}
-#pragma unroll
-	for (int i = 0; i < NWORD; i++) {  // word i covers bits [32i, 32i+32) from the top; 2k bits are significant
-		const int nb = 2 * k - 32 * i;
-		M[i] = nb >= 32 ? 0xffffffffu : (nb <= 0 ? 0u : (0xffffffffu << (32 - nb)));
-	}
-	uint32_t acc = 0xffffffffu;  // ID mode: min over steps of the xor distance (0 = match)
-	int first = 0x7fffffff;      // POS mode: first matching step
-#pragma unroll
-	for (int r = 0; r < NSEG; r++) {
-		const uint64_t sw = funnel_left(W[KW + r], W[KW + r + 1], 2 * s0);  // the 32 nucleotides entering in this segment
-		uint32_t n_hi = (uint32_t)(sw >> 32), n_lo = (uint32_t)sw;
-		constexpr int kSteps = P < 32 ? P : 32;
-#pragma unroll 8
-		for (int t = 0; t < kSteps; t++) {
-			uint32_t d1 = 0, d2 = 0;
-#pragma unroll
-			for (int i = 0; i < NWORD; i++) {
-				const uint32_t a = c[i] & M[i];
-				d1 |= a ^ X[i];
-				d2 |= a ^ XR[i];
-			}
-			const uint32_t d = min(d1, d2);
-			if constexpr (WANT_POS)
-				first = min(first, d == 0 ? (32 * r + t) : 0x7fffffff);
-			else
-				acc = min(acc, d);
-#pragma unroll
-			for (int i = 0; i + 1 < NWORD; i++)
-				c[i] = __builtin_amdgcn_alignbit(c[i], c[i + 1], 30);
-			c[NWORD - 1] = __builtin_amdgcn_alignbit(c[NWORD - 1], n_hi, 30);
-			n_hi = __builtin_amdgcn_alignbit(n_hi, n_lo, 30);
-			n_lo <<= 2;
-		}
-		// all lanes of the wave that are scanning have their answer: stop (self-queries end after the first segments)
-		if constexpr (NSEG > 1) {
-			if (WANT_POS ? __all(first != 0x7fffffff) : __all(acc == 0))
-				break;
-		}
-	}
-	if constexpr (WANT_POS)
-		return first == 0x7fffffff ? -1 : first;
-	else
-		return acc == 0 ? 0 : -1;
-}
-
-// The k-mer at nucleotide offset T of the register window W (T < 32 * (NW - KW)): the two or three words are picked with
-// compares against the (lane-varying) word index, then shifted like packed_kmer.
-template <int KW, int NW> __device__ __forceinline__ Kmer<KW> window_kmer(const uint64_t (&W)[NW], int T, int k)
-{
-	const int wi = T >> 5, sb = 2 * (T & 31);
-	uint64_t a = 0, b = 0, c = 0;
-#pragma unroll
-	for (int i = 0; i + KW < NW; i++) {
-		if (wi == i) {
-			a = W[i];
-			b = W[i + 1];
-			if constexpr (KW == 2)
-				c = W[i + 2];
-		}
-	}
-	Kmer<KW> r;
-	if constexpr (KW == 1) {
-		r.lo = funnel_left(a, b, sb) >> (64 - 2 * k);
-	} else {
-		const uint64_t v0 = funnel_left(a, b, sb), v1 = funnel_left(b, c, sb);
-		const int sh = 128 - 2 * k;
-		if (sh >= 64) {
-			r.lo = v0 >> (sh - 64);
-			r.hi = 0;
-		} else {
-			r.lo = (v1 >> sh) | (v0 << (64 - sh));
-			r.hi = v0 >> sh;
-		}
-	}
-	return r;
-}
-
-// The scan as the query kernel runs it: a FILTER on the 16 leading nucleotides, then one exact comparison.
-// A stored k-mer can equal x or rc(x) only if its top 32 bits equal theirs, so every step is: one v_alignbit with a
-// compile-time shift (the lane's stream is pre-aligned once per 32-step segment), two v_cmp_eq, one v_cndmask -- 4 VALU
-// instead of the 12 of the exact step, and no serial dependency between steps.  Steps run downwards inside a segment so
-// that "candidate = this step" needs no min.  The first candidate (smallest step) is then compared exactly in registers;
-// it is the first full match unless the filter was hit by a different k-mer with the same 16-nucleotide prefix
-// (~2^-32 per step on random data, common in repeats): only then the exact scan above runs.  k < 16 (top word not fully
-// significant) always takes the exact scan.
-template <int KW, int LOGP, bool WANT_POS>
-__device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uint64_t g0, int k, Kmer<KW> x, Kmer<KW> xr)
-{
-	constexpr int P = 1 << LOGP;
-	constexpr int NSEG = (P + 31) / 32;
-	constexpr int NW = KW + NSEG + 1;
-	constexpr int kNone = 0x7fffffff;
-	const uint64_t w0 = g0 >> 5;
-	const int s0 = (int)(g0 & 31);
-	uint64_t W[NW];
-#pragma unroll
-	for (int i = 0; i < NW; i++)
-		W[i] = seq[w0 + i];
-	if (k >= 16) {
-	uint32_t X0, XR0;  // top 32 bits of the top-aligned queries
-	if constexpr (KW == 1) {
-		const int sh = 64 - 2 * k;
-		X0 = (uint32_t)((x.lo << sh) >> 32);
-		XR0 = (uint32_t)((xr.lo << sh) >> 32);
-	} else {
-		const int sh = 128 - 2 * k;
-		uint64_t xh, xrh;
-		if (sh >= 64) {
-			xh = x.lo << (sh - 64);
-			xrh = xr.lo << (sh - 64);
-		} else {
-			xh = (x.hi << sh) | (sh ? (x.lo >> (64 - sh)) : 0ull);
-			xrh = (xr.hi << sh) | (sh ? (xr.lo >> (64 - sh)) : 0ull);
-		}
-		X0 = (uint32_t)(xh >> 32);
-		XR0 = (uint32_t)(xrh >> 32);
-	}
-	int first = kNone;
-	uint64_t sw = funnel_left(W[0], W[1], 2 * s0);
-#pragma unroll
-	for (int r = 0; r < NSEG; r++) {
-		const uint64_t swn = funnel_left(W[r + 1], W[r + 2], 2 * s0);
-		const uint32_t A0 = (uint32_t)(sw >> 32), A1 = (uint32_t)sw, A2 = (uint32_t)(swn >> 32);
-		constexpr int kSteps = P < 32 ? P : 32;
-		int f = kNone;
-#pragma unroll
-		for (int t = kSteps - 1; t >= 0; t--) {
-			const uint32_t hi = t < 16 ? A0 : A1, lo = t < 16 ? A1 : A2;
-			const int sft = 2 * (t & 15);
-			const uint32_t c0 = sft == 0 ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - sft);
-			f = ((c0 == X0) | (c0 == XR0)) ? 32 * r + t : f;
-		}
-		first = min(first, f);
-		sw = swn;
-		// all lanes of the wave that are scanning have a candidate: stop (self-queries end after the first segments)
-		if constexpr (NSEG > 1) {
-			if (__all(first != kNone))
-				break;
-		}
-	}
-	if (first == kNone)
-		return -1;
-	const Kmer<KW> cand = window_kmer<KW, NW>(W, s0 + first, k);
-	if (cand == x || cand == xr)
-		return first;
-	}
-	return scan_window_exact<KW, LOGP, WANT_POS, NW>(W, s0, k, x, xr);
-}
 
 template <int KW, int LOGP, bool WANT_POS>
 __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t* __restrict__ kmers,
@@ -240,37 +38,16 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 	const Kmer<KW> xr = kmer_rc<KW>(x, v.k);
 	int64_t id = -1;
 	int32_t posj = -1;
-	do {
-		uint32_t mini;
-		if (minis) {
-			mini = minis[i];
-			if (mini >= v.nbuckets)  // the reference reads all_buckets[] out of bounds here: defined as absent
-				break;
-		} else {
-			mini = kmer_minimizer<KW>(x, xr, v.k, v.m);
-		}
-		// bucket descriptor + group head: one round trip (both addresses depend only on the minimizer)
-		uint64_t bstart;
-		uint32_t bnt;
-		const GroupDesc* gd = &v.groups[mini >> v.gshift];
-		const GroupHead gh = v.qheads ? load_bucket_and_qhead(&v.buckets[mini], &v.qheads[mini >> v.gshift], bstart, bnt)
-		                              : load_bucket_and_head(&v.buckets[mini], gd, bstart, bnt);
-		if (bnt == 0)  // blight.cpp:719-720
-			break;
-		const uint64_t h = mphf_lookup<KW>(v, gd, gh, x);
-		if (h == kNotFound)  // blight.cpp:725-726
-			break;
-		const uint64_t pos = read_position(v.positions, gh.posstart, gh.nbits, h, v.b);
-		if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bnt))  // blight.cpp:729
-			break;
-		if (xr < x)  // non-canonical query: canonR == canon can never hold (blight.cpp:733-735)
-			break;
-		const int j = scan_window<KW, LOGP, WANT_POS>(v.seq, bstart + pos, v.k, x, xr);
-		if (j >= 0) {
-			id = (int64_t)(h + gh.prefix);        // blight.cpp:736
-			posj = (int32_t)(pos + (uint64_t)j);  // blight.cpp:706
-		}
-	} while (0);
+	uint32_t mini;
+	bool in_range = true;
+	if (minis) {
+		mini = minis[i];
+		in_range = mini < v.nbuckets;  // the reference reads all_buckets[] out of bounds here: defined as absent
+	} else {
+		mini = kmer_minimizer<KW>(x, xr, v.k, v.m);
+	}
+	if (in_range)
+		query_one<KW, LOGP, WANT_POS>(v, x, xr, mini, id, posj);
 	const uint64_t o = i;
 	if (mode == kQueryIds)
 		reinterpret_cast<int64_t*>(out)[o] = id;
@@ -341,54 +118,6 @@ __global__ __launch_bounds__(256) void k_kmer_groups(int k, int m, int gshift, c
 		return;
 	const Kmer<KW> x = load_kmer<KW>(kmers, i);
 	groups[i] = kmer_minimizer<KW>(x, kmer_rc<KW>(x, k), k, m) >> gshift;
-}
-
-// query_sequence_hash front end (blight.cpp:575-591): one lane per k-mer start; each lane encodes its own k
-// characters (str2num, kmer.h:90-98) -- the rolling update of the reference (updateK/updateRCK, blight.cpp:78-98)
-// yields exactly these values.  d_kmer_offs[s] = index of the first k-mer of sequence s in the output.
-template <int KW>
-__global__ __launch_bounds__(256) void k_sequence_kmers(int k, const uint8_t* __restrict__ ascii, const uint64_t* __restrict__ offs,
-                                                        const uint64_t* __restrict__ kmer_offs, uint64_t nseq, uint64_t nk_total,
-                                                        uint64_t* __restrict__ out, int* __restrict__ err)
-{
-	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= nk_total)
-		return;
-	// sequence of k-mer i: last s with kmer_offs[s] <= i
-	uint64_t lo = 0, hi = nseq;
-	while (hi - lo > 1) {
-		const uint64_t mid = (lo + hi) >> 1;
-		if (kmer_offs[mid] <= i)
-			lo = mid;
-		else
-			hi = mid;
-	}
-	const uint64_t p = offs[lo] + (i - kmer_offs[lo]);
-	Kmer<KW> x;
-	x.lo = 0;
-	if constexpr (KW == 2)
-		x.hi = 0;
-	bool bad = false;
-	for (int t = 0; t < k; t++) {
-		const uint32_t c = nuc_code(ascii[p + t]);
-		bad |= c > 3;
-		if constexpr (KW == 2)
-			x.hi = (x.hi << 2) | (x.lo >> 62);
-		x.lo = (x.lo << 2) | (c & 3u);
-	}
-	if constexpr (KW == 1) {
-		if (k < 32)
-			x.lo &= (1ull << (2 * k)) - 1ull;
-	}
-	if (bad)
-		atomicOr(err, 1);
-	const Kmer<KW> c = kmer_canon<KW>(x, k);
-	if constexpr (KW == 1) {
-		out[i] = c.lo;
-	} else {
-		out[2 * i] = c.lo;
-		out[2 * i + 1] = c.hi;
-	}
 }
 
 // canonical k-mer starting at byte position pos[i] of an ASCII buffer (str2num, kmer.h:90-98 + min_k, blight.cpp:86-91)
@@ -679,6 +408,27 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, BinMap b
 		hist[(uint64_t)b * nblk + blockIdx.x] = s_hist[b];
 }
 
+// the same histogram when the minimizers are already known (read front end): 4 B per k-mer instead of 23 m-mer hashes
+template <int KW>
+__global__ __launch_bounds__(kBinThreads) void k_bin_hist_minis(BinMap bm, uint32_t nbins, const uint32_t* __restrict__ minis, uint64_t nq,
+                                                                uint32_t* __restrict__ hist, uint32_t nblk)
+{
+	constexpr int kTile = BinTile<KW>::value;
+	__shared__ uint32_t s_hist[1 << kBinBitsMax];
+	for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads)
+		s_hist[b] = 0;
+	__syncthreads();
+	const uint64_t base = (uint64_t)blockIdx.x * kTile;
+	for (int it = 0; it < kTile / kBinThreads; it++) {
+		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
+		if (i < nq)
+			atomicAdd(&s_hist[bm.bin_of(minis[i])], 1u);
+	}
+	__syncthreads();
+	for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads)
+		hist[(uint64_t)b * nblk + blockIdx.x] = s_hist[b];
+}
+
 // Scatter with a tile-local sort in LDS: the tile's k-mers are first placed in bin order in LDS, then copied out so that
 // each (tile, bin) run is written as consecutive 8-B elements (64-128 B per run) instead of isolated 8-B stores
 // (measured: isolated stores wrote 2.8x the payload to HBM).  inv[i] = final position of query i (coalesced by i).
@@ -810,16 +560,12 @@ void partition_end(Index& ix, hipStream_t s)
 }
 
 // k_bin_hist -> scan -> k_bin_scatter.  d_sorted / d_inv are the outputs; d_sorted_minis may be null.
-PartitionPlan partition_batch(Index& ix, const void* d_kmers, uint64_t nq, bool owner_bins, void* d_sorted, uint32_t* d_sorted_minis,
-                              uint32_t* d_inv, hipStream_t s)
+PartitionPlan partition_batch(Index& ix, const void* d_kmers, const uint32_t* d_minis_in, uint64_t nq, bool owner_bins, void* d_sorted,
+                              uint32_t* d_sorted_minis, uint32_t* d_inv, hipStream_t s)
 {
 	const int mbits = 2 * (int)ix.prm.m - 1;
-	static const int env_bits = [] {
-		const char* e = getenv("BLIGHT_BIN_BITS");  // experiment knob
-		const int v = e ? atoi(e) : kBinBitsDefault;
-		return v < 1 ? 1 : (v > kBinBitsMax ? kBinBitsMax : v);
-	}();
-	int tbits = mbits < env_bits ? mbits : env_bits;
+	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsDefault;
+	int tbits = mbits < want_bits ? mbits : want_bits;
 	const uint32_t nbound = (owner_bins && ix.shard_world > 1) ? ix.shard_world - 1 : 0;
 	while (tbits > 1 && (1u << tbits) + nbound > (1u << kBinBitsMax))  // the kernels hold at most 2^kBinBitsMax bins
 		tbits--;
@@ -838,11 +584,18 @@ PartitionPlan partition_batch(Index& ix, const void* d_kmers, uint64_t nq, bool 
 	pl.handoff = d_sorted_minis != nullptr;
 	const uint32_t nblk = pl.nblk, nbins = pl.nbins;
 	const size_t nh = (size_t)nbins * nblk;
-	ensure_buf(ix.b_bins, nq * 4, s);
+	if (!d_minis_in)
+		ensure_buf(ix.b_bins, nq * 4, s);
 	ensure_buf(ix.b_hist, nh * 4, s);
 	ensure_buf(ix.b_offs, nh * 4, s);
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
-	if (ix.KW == 1)
+	const uint32_t* minibuf = d_minis_in ? d_minis_in : ix.b_bins.as<uint32_t>();
+	if (d_minis_in) {
+		if (ix.KW == 1)
+			hipLaunchKernelGGL((k_bin_hist_minis<1>), dim3(nblk), dim3(kBinThreads), 0, s, pl.bm, nbins, d_minis_in, nq, ix.b_hist.as<uint32_t>(), nblk);
+		else
+			hipLaunchKernelGGL((k_bin_hist_minis<2>), dim3(nblk), dim3(kBinThreads), 0, s, pl.bm, nbins, d_minis_in, nq, ix.b_hist.as<uint32_t>(), nblk);
+	} else if (ix.KW == 1)
 		hipLaunchKernelGGL((k_bin_hist<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, pl.bm, nbins, km, nq,
 		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
 	else
@@ -854,10 +607,10 @@ PartitionPlan partition_batch(Index& ix, const void* d_kmers, uint64_t nq, bool 
 	ensure_buf(ix.b_tmp, bytes, s);
 	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
 	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), pl.bm,
+		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm,
 		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
 	else
-		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, ix.b_bins.as<uint32_t>(), pl.bm,
+		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm,
 		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
 	BLMX_HIP(hipGetLastError());
 	return pl;
@@ -876,44 +629,50 @@ void gather_ids(const Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_
 
 }  // namespace
 
-void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s)
+bool query_batch_worth_binning(const Index& ix, uint64_t nq)
+{
+	int policy = ix.bin_policy;
+	const int mbits = 2 * (int)ix.prm.m - 1;
+	if (nq >= 0xffffffffull || policy < 0)
+		return false;
+	if (policy > 0)
+		return true;
+	return nq >= (1ull << 20) && ix.st.device_bytes >= (64ull << 20) && mbits >= 4;
+}
+
+// d_minis: minimizers of the k-mers when the caller already has them (read front end), else nullptr
+static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, hipStream_t s)
 {
 	if (nq == 0)
 		return;
-	int policy = ix.bin_policy;
-	if (policy == 0) {
-		static const int env = [] {
-			const char* e = getenv("BLIGHT_QUERY_BINNING");
-			return e ? atoi(e) : 0;
-		}();
-		policy = env;
-	}
-	const int mbits = 2 * (int)ix.prm.m - 1;
-	const bool worth = nq >= (1ull << 20) && nq < 0xffffffffull && ix.st.device_bytes >= (64ull << 20) && mbits >= 4;
-	if (policy < 0 || (policy == 0 && !worth) || nq >= 0xffffffffull) {
-		launch_query(ix, d_kmers, nullptr, nq, d_out, kQueryIds, s);
+	if (!query_batch_worth_binning(ix, nq)) {
+		launch_query(ix, d_kmers, d_minis, nq, d_out, kQueryIds, s);
 		return;
 	}
 	std::lock_guard<std::mutex> lock(ix.bin_mu);
 	partition_begin(ix, s);
-	// hand the minimizers over to the query kernel?  (env BLIGHT_MINI_HANDOFF=0/1 overrides)
-	static const int env_handoff = [] {
-		const char* e = getenv("BLIGHT_MINI_HANDOFF");
-		return e ? atoi(e) : -1;
-	}();
-	const bool handoff = env_handoff >= 0 ? env_handoff != 0 : ix.KW == 2;
+	// hand the minimizers over to the query kernel?  Known minimizers always travel; computed ones only for 128-bit k-mers
+	// (55 m-mers hashed once instead of twice; for 64-bit k-mers the extra 8 B/query of traffic ate the gain) unless tuned.
+	const bool handoff = ix.tune_mini_handoff >= 0 ? ix.tune_mini_handoff != 0 : (d_minis != nullptr || ix.KW == 2);
 	if (handoff)
 		ensure_buf(ix.b_minis, nq * 4, s);
 	uint32_t* d_sorted_minis = handoff ? ix.b_minis.as<uint32_t>() : nullptr;
 	ensure_buf(ix.b_sorted, nq * 8 * (size_t)ix.KW, s);
 	ensure_buf(ix.b_inv, nq * 4, s);
 	ensure_buf(ix.b_ids, nq * 8, s);
-	partition_batch(ix, d_kmers, nq, false, ix.b_sorted.p, d_sorted_minis, ix.b_inv.as<uint32_t>(), s);
+	partition_batch(ix, d_kmers, d_minis, nq, false, ix.b_sorted.p, d_sorted_minis, ix.b_inv.as<uint32_t>(), s);
 	// (storing each ID straight into the caller's slot from k_query was measured 2.8 ms SLOWER per 1e8 queries than this
 	// separate gather: 1e8 scattered 8-B stores cost more than reading the IDs back through the inverse permutation)
 	launch_query(ix, ix.b_sorted.p, d_sorted_minis, nq, ix.b_ids.p, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
 	gather_ids(ix, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out, s);
 	partition_end(ix, s);
+}
+
+void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s) { query_ids_pipeline(ix, d_kmers, nullptr, nq, d_out, s); }
+
+void launch_query_ids_with_minis(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, hipStream_t s)
+{
+	query_ids_pipeline(ix, d_kmers, d_minis, nq, d_out, s);
 }
 
 // ---- the three stages as separate entry points: the sharded exchange (blight_amd/dist.py) partitions on the rank that
@@ -931,7 +690,7 @@ void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorte
 	}
 	std::lock_guard<std::mutex> lock(ix.bin_mu);
 	partition_begin(ix, s);
-	const PartitionPlan pl = partition_batch(ix, d_kmers, nq, true, d_sorted, nullptr, d_inv, s);
+	const PartitionPlan pl = partition_batch(ix, d_kmers, nullptr, nq, true, d_sorted, nullptr, d_inv, s);
 	if (d_rank_counts) {
 		uint32_t first_bin[18];
 		first_bin[0] = 0;
@@ -974,21 +733,6 @@ void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint3
 	else
 		hipLaunchKernelGGL((k_kmer_groups<2>), dim3(grid_for(nq, 256)), dim3(256), 0, s, (int)ix.prm.k, (int)ix.prm.m, ix.gshift, km,
 		                   nq, d_groups);
-	BLMX_HIP(hipGetLastError());
-}
-
-void launch_sequence_kmers(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, const uint64_t* d_kmer_offs,
-                           uint64_t nseq, uint64_t nk_total, void* d_kmers_out, int* d_err, hipStream_t s)
-{
-	if (nk_total == 0)
-		return;
-	uint64_t* out = reinterpret_cast<uint64_t*>(d_kmers_out);
-	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_sequence_kmers<1>), dim3(grid_for(nk_total, 256)), dim3(256), 0, s, (int)ix.prm.k, d_ascii, d_offs,
-		                   d_kmer_offs, nseq, nk_total, out, d_err);
-	else
-		hipLaunchKernelGGL((k_sequence_kmers<2>), dim3(grid_for(nk_total, 256)), dim3(256), 0, s, (int)ix.prm.k, d_ascii, d_offs,
-		                   d_kmer_offs, nseq, nk_total, out, d_err);
 	BLMX_HIP(hipGetLastError());
 }
 

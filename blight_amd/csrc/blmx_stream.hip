@@ -328,54 +328,29 @@ __global__ __launch_bounds__(256) void k_count_found(const int64_t* __restrict__
 	}
 }
 
-namespace {
-
-struct Pinned {
-	void* p = nullptr;
-	size_t bytes = 0;
-	~Pinned()
-	{
-		if (p)
-			(void)hipHostFree(p);
-	}
-	void ensure(size_t n)
-	{
-		if (n <= bytes)
-			return;
-		if (p)
-			(void)hipHostFree(p);
-		p = nullptr;
-		bytes = 0;
-		BLMX_HIP(hipHostMalloc(&p, n + n / 4 + 4096, hipHostMallocDefault));
-		bytes = n + n / 4 + 4096;
-	}
-	template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct Batch {
-	Pinned h_seq, h_offs, h_koffs, h_counts;
-	DevBuf d_seq, d_offs, d_koffs, d_kmers, d_ids, d_counts, d_err;
-	std::vector<uint64_t> offs, koffs;
-	uint64_t total = 0, nk = 0;
-	hipStream_t s = nullptr;
-	hipEvent_t done = nullptr;
-	bool in_flight = false;
-	~Batch()
-	{
-		if (done)
-			(void)hipEventDestroy(done);
-		if (s)
-			(void)hipStreamDestroy(s);
-	}
-};
-
-void grow(DevBuf& b, size_t bytes, hipStream_t s)
+void launch_count_found(const int64_t* d_ids, uint64_t n, unsigned long long* d_counts, hipStream_t s)
 {
-	if (bytes > b.bytes)
-		BLMX_HIP(b.alloc(bytes + bytes / 4 + 256, false, s));
+	if (n == 0)
+		return;
+	hipLaunchKernelGGL(k_count_found, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ids, n, d_counts);
+	BLMX_HIP(hipGetLastError());
 }
 
-}  // namespace
+void Pinned::ensure(size_t n, size_t keep)
+{
+	if (n <= bytes)
+		return;
+	const size_t nb = n + n / 4 + 4096;
+	void* q = nullptr;
+	BLMX_HIP(hipHostMalloc(&q, nb, hipHostMallocDefault));
+	if (p) {
+		if (keep)
+			memcpy(q, p, std::min(keep, bytes));
+		(void)hipHostFree(p);
+	}
+	p = q;
+	bytes = nb;
+}
 
 // ---- streaming ingest for construction (reference blight.cpp:212-229 reads line by line) ---------------------
 // The host only parses: sequence lines are packed into two pinned 64 MiB buffers that leave for HBM with asynchronous
@@ -657,7 +632,44 @@ void load_index(Index& ix, const char* path)
 		throw StatusError{BLMX_EIO, "index file is inconsistent (end tag)"};
 	ix.h_groups.resize(h.ngroups);
 	BLMX_HIP(hipMemcpyAsync(ix.h_groups.data(), ix.groups.p, (size_t)h.ngroups * sizeof(GroupDesc), hipMemcpyDeviceToHost, s));
+	std::vector<BucketDesc> hb(h.nbuckets);
+	BLMX_HIP(hipMemcpyAsync(hb.data(), ix.buckets.p, (size_t)h.nbuckets * sizeof(BucketDesc), hipMemcpyDeviceToHost, s));
 	BLMX_HIP(hipStreamSynchronize(s));
+	// Every offset the kernels follow must stay inside its array: a corrupted or foreign image with plausible sizes ends
+	// in BLMX_EIO here instead of a GPU memory fault later.
+	{
+		auto bad = [&](const char* what) {
+			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks})
+				b->release();
+			ix.h_groups.clear();
+			ix.h_fb_group.clear();
+			throw StatusError{BLMX_EIO, std::string("index file is inconsistent (") + what + ")"};
+		};
+		const uint64_t total_nt = h.st.total_nt;
+		if (total_nt / 32 + 1 > h.seq_words)
+			bad("sequence length");
+		for (uint32_t bkt = 0; bkt < h.nbuckets; bkt++)
+			if (hb[bkt].start > total_nt || (uint64_t)hb[bkt].nt > total_nt - hb[bkt].start)
+				bad("bucket table");
+		uint64_t keys = 0;
+		for (uint32_t g = 0; g < h.ngroups; g++) {
+			const GroupDesc& gd = ix.h_groups[g];
+			uint64_t bits = 0;
+			for (int l = 0; l < kLevels; l++) {
+				if (gd.size[l] == 0 || gd.size[l] > (1ull << 40))
+					bad("level sizes");
+				bits += gd.size[l];
+			}
+			const uint64_t glines = gd.nkeys ? (bits / 32 + kLineData32 - 1) / kLineData32 : 0;
+			if (gd.nbits == 0 || gd.nbits > 32 || gd.nkeys > (1ull << 40) || gd.line_base > h.total_lines || glines > h.total_lines - gd.line_base ||
+			    gd.posstart > h.positions_words * 64 || gd.nkeys * gd.nbits > h.positions_words * 64 - gd.posstart || gd.fb_start > h.nfb ||
+			    gd.fb_count > h.nfb - gd.fb_start)
+				bad("group table");
+			keys += gd.nkeys;
+		}
+		if (keys != h.st.local_number_kmer)
+			bad("key counts");
+	}
 	make_query_heads(ix);
 	ix.shard_rank = h.shard_rank;
 	ix.shard_world = h.shard_world;
@@ -665,9 +677,8 @@ void load_index(Index& ix, const char* path)
 	ix.seq_words = h.seq_words;
 	ix.total_lines = h.total_lines;
 	ix.total_logical_words = h.total_logical_words;
-	const uint64_t nq = ix.st.number_query;
 	ix.st = h.st;
-	ix.st.number_query = nq;
+	ix.st.number_query = 0;  // the live counter is ix.number_query
 	ix.built = true;
 }
 
@@ -736,116 +747,6 @@ void payload_add_ids(Payload& pl, const int64_t* d_ids, uint64_t n, uint32_t col
 	else
 		hipLaunchKernelGGL(k_payload_color, dim3(grid), dim3(256), 0, s, d_ids, n, pl.nids, color, pl.ncolors, pl.data.as<uint32_t>());
 	BLMX_HIP(hipGetLastError());
-}
-
-// The streaming front end shared by file_query (2-line FASTA records, blight.cpp:760-775) and the payload applications
-// (every line that starts with A/C/G/T): parse | H2D | rolling k-mers -> query pipeline -> on-device counters
-// [-> payload update], two pinned batches in flight.
-static void stream_file(Index& ix, const char* path, bool acgt_lines, Payload* payload, uint32_t color, uint64_t& good, uint64_t& erroneous)
-{
-	if (!ix.built)
-		throw StatusError{BLMX_ESTATE, "index not built"};
-	RecordReader rd(path);
-	if (!rd.ok())
-		throw StatusError{BLMX_EIO, "Problem with files opening"};
-	BLMX_HIP(hipSetDevice(ix.prm.device));
-	const uint64_t k = ix.prm.k;
-	constexpr size_t kBatchBytes = 48u << 20;  // sequence characters per batch
-	Batch batch[2];
-	for (auto& b : batch) {
-		BLMX_HIP(hipStreamCreateWithFlags(&b.s, hipStreamNonBlocking));
-		BLMX_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-		b.h_counts.ensure(16);
-		BLMX_HIP(b.d_counts.alloc(16, true, b.s));
-		BLMX_HIP(b.d_err.alloc(4, true, b.s));
-	}
-	good = erroneous = 0;
-	uint64_t queries = 0;
-	auto retire = [&](Batch& b) {
-		if (!b.in_flight)
-			return;
-		BLMX_HIP(hipEventSynchronize(b.done));
-		good += b.h_counts.as<uint64_t>()[0];
-		erroneous += b.h_counts.as<uint64_t>()[1];
-		if (reinterpret_cast<int*>(b.h_counts.as<uint64_t>() + 2)[0])
-			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
-		queries += b.nk;
-		b.in_flight = false;
-	};
-	const char* p;
-	size_t len;
-	bool more = true;
-	int cur = 0;
-	while (more) {
-		Batch& b = batch[cur];
-		retire(b);  // its pinned buffers are about to be overwritten
-		b.offs.assign(1, 0);
-		b.koffs.assign(1, 0);
-		b.total = 0;
-		b.h_seq.ensure(kBatchBytes + (1u << 20));
-		while (b.total < kBatchBytes) {
-			if (!acgt_lines && rd.mapped() &&
-			    rd.bulk(b.h_seq.as<char>() + b.total, b.h_seq.bytes - b.total - 64, b.offs, &b.koffs, k, (size_t)k)) {
-				b.total = b.offs.back();  // sequences shorter than k were skipped (blight.cpp:782)
-				continue;
-			}
-			more = acgt_lines ? rd.next_acgt_line(p, len) : rd.next_sequence(p, len);
-			if (!more)
-				break;
-			if (len < k)  // blight.cpp:782: shorter than k -> skipped
-				continue;
-			b.h_seq.ensure(b.total + len + 64);
-			memcpy(b.h_seq.as<char>() + b.total, p, len);
-			b.total += len;
-			b.offs.push_back(b.total);
-			b.koffs.push_back(b.koffs.back() + (len - k + 1));
-		}
-		const uint64_t nseq = b.offs.size() - 1;
-		b.nk = b.koffs.back();
-		if (nseq == 0)
-			continue;
-		b.h_offs.ensure((nseq + 1) * 8);
-		b.h_koffs.ensure((nseq + 1) * 8);
-		memcpy(b.h_offs.p, b.offs.data(), (nseq + 1) * 8);
-		memcpy(b.h_koffs.p, b.koffs.data(), (nseq + 1) * 8);
-		b.h_counts.ensure(32);
-		grow(b.d_seq, b.total + 64, b.s);
-		grow(b.d_offs, (nseq + 1) * 8, b.s);
-		grow(b.d_koffs, (nseq + 1) * 8, b.s);
-		grow(b.d_kmers, b.nk * 8 * (size_t)ix.KW, b.s);
-		grow(b.d_ids, b.nk * 8, b.s);
-		BLMX_HIP(hipMemcpyAsync(b.d_seq.p, b.h_seq.p, b.total, hipMemcpyHostToDevice, b.s));
-		BLMX_HIP(hipMemcpyAsync(b.d_offs.p, b.h_offs.p, (nseq + 1) * 8, hipMemcpyHostToDevice, b.s));
-		BLMX_HIP(hipMemcpyAsync(b.d_koffs.p, b.h_koffs.p, (nseq + 1) * 8, hipMemcpyHostToDevice, b.s));
-		BLMX_HIP(hipMemsetAsync(b.d_counts.p, 0, 16, b.s));
-		BLMX_HIP(hipMemsetAsync(b.d_err.p, 0, 4, b.s));
-		launch_sequence_kmers(ix, b.d_seq.as<uint8_t>(), b.d_offs.as<uint64_t>(), b.d_koffs.as<uint64_t>(), nseq, b.nk, b.d_kmers.p,
-		                      b.d_err.as<int>(), b.s);
-		launch_query_ids_auto(ix, b.d_kmers.p, b.nk, b.d_ids.as<int64_t>(), b.s);
-		hipLaunchKernelGGL(k_count_found, dim3((unsigned)((b.nk + 255) / 256)), dim3(256), 0, b.s, b.d_ids.as<int64_t>(), b.nk,
-		                   b.d_counts.as<unsigned long long>());
-		BLMX_HIP(hipGetLastError());
-		if (payload)
-			payload_add_ids(*payload, b.d_ids.as<int64_t>(), b.nk, color, b.s);
-		BLMX_HIP(hipMemcpyAsync(b.h_counts.p, b.d_counts.p, 16, hipMemcpyDeviceToHost, b.s));
-		BLMX_HIP(hipMemcpyAsync(b.h_counts.as<uint64_t>() + 2, b.d_err.p, 4, hipMemcpyDeviceToHost, b.s));
-		BLMX_HIP(hipEventRecord(b.done, b.s));
-		b.in_flight = true;
-		cur ^= 1;
-	}
-	retire(batch[0]);
-	retire(batch[1]);
-	ix.st.number_query += queries;
-}
-
-// file_query: returns good / erroneous k-mer counts (the reference prints them: "Good kmer", "Erroneous kmers").
-void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous) { stream_file(ix, path, false, nullptr, 0, good, erroneous); }
-
-void payload_add_file(Payload& pl, const char* path, uint32_t color, uint64_t& found, uint64_t& absent)
-{
-	if (pl.kind == 1 && color >= pl.ncolors)
-		throw StatusError{BLMX_EINVAL, "colour out of range"};
-	stream_file(*pl.ix, path, true, &pl, color, found, absent);
 }
 
 }  // namespace blmx

@@ -15,6 +15,7 @@
 #ifndef BLIGHT_MI355X_FACADE_H
 #define BLIGHT_MI355X_FACADE_H
 
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <iostream>
@@ -48,7 +49,7 @@ public:
 	size_t number_super_kmer = 0;
 	size_t largest_MPHF = 0;
 	size_t positions_total_size = 0;
-	size_t number_query = 0;
+	std::atomic<size_t> number_query{0};  // incremented atomically like the reference (blight.cpp:687-688): callers query from OpenMP threads
 	double bit_per_kmer = 0;
 	uint largest_bucket_nuc_all = 0;
 	const uint gammaFactor = 2;
@@ -192,7 +193,7 @@ public:
 		std::cout << "-----------------------QUERY RECAP 2----------------------------" << std::endl;
 		std::cout << "Good kmer: " << intToString(TP) << std::endl;
 		std::cout << "Erroneous kmers: " << intToString(FP) << std::endl;
-		std::cout << "Query performed: " << intToString(number_query) << std::endl;
+		std::cout << "Query performed: " << intToString(number_query.load()) << std::endl;
 		const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count();
 		std::cout << "The whole QUERY took me " << secs << " seconds." << std::endl;
 	}

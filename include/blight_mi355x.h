@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
  * so a stale caller binary is detected instead of corrupting memory. */
-#define BLMX_ABI_VERSION 7
+#define BLMX_ABI_VERSION 8
 
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
@@ -107,13 +107,16 @@ int blmx_query_positions(blmx_index* ix, const void* canon_kmers, const uint32_t
                          int32_t* pos_out);
 /* query_kmer_bool, reference blight.cpp:537-541: present_out[i] = 1/0. */
 int blmx_query_membership(blmx_index* ix, const void* canon_kmers, uint64_t nq, uint8_t* present_out);
-/* query_sequence_hash for nseq sequences (reference blight.cpp:575-591): rolling canonical k-mers on the GPU.
- * ids_out holds sum_i max(0, len_i - k + 1) entries, sequence after sequence; sequences shorter than k contribute
- * nothing.  Returns BLMX_EDNA on an invalid character. */
+/* query_sequence_hash for nseq sequences (reference blight.cpp:575-591): canonical k-mers and their minimizers are made on
+ * the GPU by a wave-cooperative front end (one m-mer hash per position, window minimum through LDS).  ids_out holds
+ * sum_i max(0, len_i - k + 1) entries, sequence after sequence; sequences shorter than k contribute nothing.  Returns
+ * BLMX_EDNA on an invalid character.  Thread-safe: calls on a few short sequences (one read) run concurrently, each as ONE
+ * kernel launch on a pinned slot the device reads and writes directly; large inputs stream through pinned windows. */
 int blmx_query_sequences(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
-/* file_query(file), reference blight.cpp:746-799: streams the 2-line FASTA records of `path` (plain or gzip) through the
- * GPU in pinned double-buffered batches (parse | H2D | kernels | 16-byte D2H overlap), skips sequences shorter than k
- * (blight.cpp:782) and returns the recap counters "Good kmer" / "Erroneous kmers".  Only the two counters cross PCIe back. */
+/* file_query(file), reference blight.cpp:746-799: the RAW bytes of `path` (plain or gzip) stream through the GPU in pinned
+ * windows; lines, the reference's record rule (lines are consumed in pairs; the second line of a pair is a sequence iff both
+ * are non-empty, blight.cpp:760-775) and k-mer starts are found on the device; sequences shorter than k are skipped
+ * (blight.cpp:782).  Returns the recap counters "Good kmer" / "Erroneous kmers"; only the two counters cross PCIe back. */
 int blmx_query_file(blmx_index* ix, const char* path, uint64_t* good_out, uint64_t* erroneous_out);
 /* Index image on disk.  This fork of the reference cannot persist an index (README: "no dump/load"); mainline
  * Blight's dump_disk(file) / kmer_Set_Light(file) pair is the model.  blmx_save writes the finished HBM arrays verbatim
@@ -164,7 +167,8 @@ int blmx_canonicalize_device(blmx_index* ix, void* d_kmers, uint64_t nq, void* s
 /* ---- multi-GPU sharding: ownership unit = MPHF group (a contiguous range of minimizer buckets, reference
  * blight.cpp:692).  blmx_set_shard (before the build) makes this index keep only the groups of rank `rank` of `world`;
  * every rank is given the SAME input, chops it, and derives the same key-balanced group boundaries, so no build-time
- * exchange is needed and IDs stay global.  blmx_shard_bounds returns the world+1 group boundaries.
+ * exchange is needed and IDs stay global.  world <= 16 (the partitioned exchange splits its bins at up to 15 boundaries).
+ * blmx_shard_bounds returns the world+1 group boundaries.
  * Routing helpers (device pointers): count -> destination rank of every k-mer + per-destination counts; scatter -> k-mers
  * grouped by destination (+ the permutation); unpermute -> out[order[i]] = vals[i]. */
 int blmx_set_shard(blmx_index* ix, uint32_t rank, uint32_t world);
@@ -195,6 +199,13 @@ int blmx_gather_ids_device(blmx_index* ix, const int64_t* d_ids_ordered, const u
  * L2 / Infinity Cache; results are identical and in the caller's order), 1 = always partition, -1 = never.
  * Environment override when 0: BLIGHT_QUERY_BINNING=1|-1. */
 int blmx_set_query_binning(blmx_index* ix, int policy);
+/* Per-index tuning knobs (experiments, tests; results never depend on them).  The environment variables BLIGHT_BIN_BITS,
+ * BLIGHT_MINI_HANDOFF, BLIGHT_QUERY_HEADS, BLIGHT_READS_MODE, BLIGHT_WINDOW_KB, BLIGHT_QUERY_BINNING seed them when the index is
+ * created.  Keys: "bin_bits" (partition bins = 2^value, 0 = default), "mini_handoff" (1/0/-1: the partition pass hands the
+ * minimizers to the query kernel / it recomputes them / automatic), "query_heads" (0: query kernels read the full group
+ * descriptor instead of the compact head), "reads_mode" (sequence / file queries: 0 automatic, 1 front end fused with the query
+ * body, 2 front end -> binned pipeline), "window_kb" (KiB of characters per front-end window), "query_binning" (as blmx_set_query_binning). */
+int blmx_set_tuning(blmx_index* ix, const char* key, int value);
 
 int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
 
