@@ -86,6 +86,9 @@ def load_library():
     lib.blmx_sequence_kmer_count.argtypes = [C.c_void_p, _u64p, C.c_uint64]
     lib.blmx_sequence_kmer_count.restype = C.c_uint64
     lib.blmx_query_kmers_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.blmx_query_sequences_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.blmx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.blmx_last_profile.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.blmx_kmer_groups_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_kmers_at_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.blmx_canonicalize_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
@@ -314,6 +317,22 @@ class kmer_Set_Light:
     # -- device-resident batch API (bench / pipelines): raw device pointers + hipStream_t
     def query_kmers_device(self, d_kmers_ptr, nq, d_ids_ptr, stream=None):
         self._check(self._lib.blmx_query_kmers_device(self._h, d_kmers_ptr, nq, d_ids_ptr, stream))
+
+    def query_sequences_device(self, d_concat_ptr, d_offsets_ptr, nseq, total_len, nk, d_ids_ptr, d_err_ptr=None, stream=None):
+        self._check(self._lib.blmx_query_sequences_device(self._h, d_concat_ptr, d_offsets_ptr, nseq, total_len, nk, d_ids_ptr, d_err_ptr, stream))
+
+    PROFILE_STAGES = ("front", "k_bin_hist", "scan", "k_bin_scatter", "k_query", "k_gather_ids")
+
+    def set_profiling(self, on):
+        self._check(self._lib.blmx_set_profiling(self._h, int(on)))
+
+    def last_profile(self):
+        """stage -> milliseconds of the last device-resident query call (HIP events on its stream)"""
+        ms = (C.c_float * 8)()
+        n = self._lib.blmx_last_profile(self._h, ms, 8)
+        if n < 0:
+            self._check(n)
+        return {self.PROFILE_STAGES[i]: float(ms[i]) for i in range(n)}
 
     def partition_device(self, d_kmers_ptr, nq, d_ordered_ptr, d_inv_ptr, d_rank_counts_ptr=None, stream=None):
         self._check(self._lib.blmx_partition_device(self._h, d_kmers_ptr, nq, d_ordered_ptr, d_inv_ptr, d_rank_counts_ptr, stream))

@@ -171,6 +171,9 @@ void blmx_destroy(blmx_index* h)
 	(void)hipDeviceSynchronize();  // device-pointer calls may still be running on the caller's streams
 	destroy_host_front(h->ix.hf);
 	h->ix.hf = nullptr;
+	for (hipEvent_t e : h->ix.prof_ev)
+		if (e)
+			(void)hipEventDestroy(e);
 	if (h->ix.bin_done)
 		(void)hipEventDestroy(h->ix.bin_done);
 	if (h->ix.stream) {
@@ -367,6 +370,55 @@ int blmx_query_kmers_device(blmx_index* h, const void* d_kmers, uint64_t nq, int
 		launch_query_ids_auto(h->ix, d_kmers, nq, d_ids, s);
 		h->ix.number_query.fetch_add(nq, std::memory_order_relaxed);
 	});
+}
+
+int blmx_query_sequences_device(blmx_index* h, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq, uint64_t total_len, uint64_t nk,
+                                int64_t* d_ids, int* d_err_flag, void* stream)
+{
+	if (!h || (nseq && (!d_concat || !d_offsets)) || (nk && !d_ids))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		query_sequences_device(h->ix, reinterpret_cast<const uint8_t*>(d_concat), d_offsets, nseq, total_len, nk, d_ids, d_err_flag,
+		                       reinterpret_cast<hipStream_t>(stream));
+	});
+}
+
+int blmx_set_profiling(blmx_index* h, int on)
+{
+	if (!h)
+		return BLMX_EINVAL;
+	h->ix.prof_on = on != 0;
+	h->ix.prof_reset();
+	return BLMX_OK;
+}
+
+int blmx_last_profile(blmx_index* h, float* ms_out, int cap)
+{
+	if (!h || !ms_out || cap < Index::kProfEvents - 1)
+		return BLMX_EINVAL;
+	Index& ix = h->ix;
+	int last = -1;
+	for (int i = 0; i < Index::kProfEvents; i++)
+		if (ix.prof_set[i])
+			last = i;
+	if (last < 0)
+		return 0;
+	if (hipEventSynchronize(ix.prof_ev[last]) != hipSuccess)
+		return BLMX_EHIP;
+	int prev = -1;
+	for (int i = 0; i < Index::kProfEvents; i++) {
+		if (i > 0)
+			ms_out[i - 1] = 0.0f;
+		if (!ix.prof_set[i])
+			continue;
+		if (prev >= 0) {
+			float ms = 0.0f;
+			(void)hipEventElapsedTime(&ms, ix.prof_ev[prev], ix.prof_ev[i]);
+			ms_out[i - 1] = ms;
+		}
+		prev = i;
+	}
+	return Index::kProfEvents - 1;
 }
 
 int blmx_kmer_groups_device(blmx_index* h, const void* d_kmers, uint64_t nq, uint32_t* d_groups, void* stream)

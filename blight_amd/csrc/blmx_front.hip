@@ -179,6 +179,18 @@ struct HostFront {
 	std::condition_variable small_cv;
 	std::unique_ptr<WorkerPool> pool;
 	DevBuf d_counts, d_carry;  // file streaming: found / not found, line carry between windows
+	// scratch of blmx_query_sequences_device (calls on different streams are ordered with an event)
+	FrontScratch dev_fs;
+	DevBuf dev_kmers, dev_minis, dev_err;
+	std::mutex dev_mu;
+	hipEvent_t dev_done = nullptr;
+	hipStream_t dev_last = nullptr;
+	bool dev_used = false;
+	~HostFront()
+	{
+		if (dev_done)
+			(void)hipEventDestroy(dev_done);
+	}
 };
 
 void destroy_host_front(HostFront* hf) { delete hf; }
@@ -393,6 +405,51 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 	finish(hf.win[0]);
 	finish(hf.win[1]);
 	ix.number_query.fetch_add(nk_all, std::memory_order_relaxed);
+}
+
+// The same for sequences that are already resident in HBM (concatenated characters + nseq + 1 offsets, offsets[0] = 0):
+// asynchronous on the caller's stream; nk = sum of max(0, len - k + 1) as the caller computed it.
+void query_sequences_device(Index& ix, const uint8_t* d_chars, const uint64_t* d_offs, uint64_t nseq, uint64_t total, uint64_t nk, int64_t* d_ids,
+                            int* d_err, hipStream_t s)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	if (nk == 0 || nseq == 0)
+		return;
+	if (total >= 0xffffffc0ull)
+		throw StatusError{BLMX_ELIMIT, "a device-resident batch holds fewer than 2^32 characters"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	HostFront& hf = host_front(ix);
+	std::lock_guard<std::mutex> lock(hf.dev_mu);
+	if (!hf.dev_done)
+		BLMX_HIP(hipEventCreateWithFlags(&hf.dev_done, hipEventDisableTiming));
+	if (hf.dev_used && hf.dev_last != s)
+		BLMX_HIP(hipStreamWaitEvent(s, hf.dev_done, 0));
+	if (!d_err) {
+		if (!hf.dev_err.p)
+			BLMX_HIP(hf.dev_err.alloc(64, true, s));
+		d_err = hf.dev_err.as<int>();
+	}
+	ix.prof_reset();
+	ix.prof_mark(0, s);
+	front_valid_concat(ix, hf.dev_fs, d_offs, nseq + 1, 0, total, total, s);
+	const bool binned = !read_query_fusable(ix) || ix.tune_reads_mode == 2 || (ix.tune_reads_mode == 0 && query_batch_worth_binning(ix, nk));
+	if (binned) {
+		grow(hf.dev_kmers, nk * 8 * (size_t)ix.KW, s);
+		grow(hf.dev_minis, nk * 4, s);
+		launch_read_front(ix, &hf.dev_fs, d_chars, total, total, nullptr, nullptr, 0, hf.dev_kmers.p, hf.dev_minis.as<uint32_t>(), d_err, s);
+		ix.prof_mark(1, s);
+		launch_query_ids_with_minis(ix, hf.dev_kmers.p, hf.dev_minis.as<uint32_t>(), nk, d_ids, s);
+	} else {
+		ix.prof_mark(1, s);
+		ix.prof_mark(4, s);
+		launch_read_query(ix, &hf.dev_fs, d_chars, total, total, nullptr, nullptr, 0, d_ids, nullptr, d_err, s);
+		ix.prof_mark(5, s);
+	}
+	BLMX_HIP(hipEventRecord(hf.dev_done, s));
+	hf.dev_last = s;
+	hf.dev_used = true;
+	ix.number_query.fetch_add(nk, std::memory_order_relaxed);
 }
 
 // ---- query_kmer_hash / query_kmer_bool / query_get_hash / query_get_pos_unitig for a host batch (blight.cpp:537-550, 686-742) ----

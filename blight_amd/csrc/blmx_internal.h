@@ -233,6 +233,12 @@ struct Index {
 	hipEvent_t bin_done = nullptr;       // recorded after each binned pipeline: a call on another stream waits for it
 	hipStream_t bin_last_stream = nullptr;
 	bool bin_used = false;
+	// stage timing of the last query pipeline (blmx_set_profiling): events at the stage boundaries
+	// [0] start | [1] front end done | [2] k_bin_hist | [3] scan | [4] k_bin_scatter | [5] k_query | [6] k_gather_ids
+	static constexpr int kProfEvents = 7;
+	bool prof_on = false;
+	hipEvent_t prof_ev[kProfEvents] = {};
+	bool prof_set[kProfEvents] = {};
 	int bin_policy = 0;  // 0 = automatic, 1 = always bin, -1 = never (BLIGHT_QUERY_BINNING env at creation / blmx_set_query_binning)
 	// per-index tuning knobs (blmx_set_tuning; the BLIGHT_* environment variables of the same name seed them at creation)
 	int tune_bin_bits = 0;       // partition bins = 2^bits (0 = default)
@@ -245,6 +251,21 @@ struct Index {
 	{
 		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks})
 			b->persistent = true;
+	}
+
+	void prof_mark(int i, hipStream_t s)
+	{
+		if (!prof_on)
+			return;
+		if (!prof_ev[i])
+			(void)hipEventCreate(&prof_ev[i]);
+		(void)hipEventRecord(prof_ev[i], s);
+		prof_set[i] = true;
+	}
+	void prof_reset()
+	{
+		for (bool& b : prof_set)
+			b = false;
 	}
 
 	DeviceIndexView view() const
@@ -306,6 +327,8 @@ bool read_query_fusable(const Index& ix);
 // host-buffer entry points (blmx_stream.hip): pinned staging, windows in flight, small-call slots
 void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
 void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode);
+void query_sequences_device(Index& ix, const uint8_t* d_chars, const uint64_t* d_offs, uint64_t nseq, uint64_t total, uint64_t nk, int64_t* d_ids,
+                            int* d_err, hipStream_t s);
 void launch_count_found(const int64_t* d_ids, uint64_t n, unsigned long long* d_counts, hipStream_t s);
 void launch_kmers_at(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_pos, uint64_t nq, void* d_out, int* d_err, hipStream_t s);
 void launch_canonicalize(const Index& ix, void* d_kmers, uint64_t nq, hipStream_t s);

@@ -602,10 +602,12 @@ PartitionPlan partition_batch(Index& ix, const void* d_kmers, const uint32_t* d_
 		hipLaunchKernelGGL((k_bin_hist<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, pl.bm, nbins, km, nq,
 		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
 	BLMX_HIP(hipGetLastError());
+	ix.prof_mark(2, s);
 	size_t bytes = 0;
 	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
 	ensure_buf(ix.b_tmp, bytes, s);
 	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
+	ix.prof_mark(3, s);
 	if (ix.KW == 1)
 		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm,
 		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
@@ -613,6 +615,7 @@ PartitionPlan partition_batch(Index& ix, const void* d_kmers, const uint32_t* d_
 		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm,
 		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
 	BLMX_HIP(hipGetLastError());
+	ix.prof_mark(4, s);
 	return pl;
 }
 
@@ -645,8 +648,15 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 {
 	if (nq == 0)
 		return;
+	if (!d_minis) {  // (the read front end has already marked 0 and 1)
+		ix.prof_reset();
+		ix.prof_mark(0, s);
+		ix.prof_mark(1, s);
+	}
 	if (!query_batch_worth_binning(ix, nq)) {
+		ix.prof_mark(4, s);
 		launch_query(ix, d_kmers, d_minis, nq, d_out, kQueryIds, s);
+		ix.prof_mark(5, s);
 		return;
 	}
 	std::lock_guard<std::mutex> lock(ix.bin_mu);
@@ -664,7 +674,9 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	// (storing each ID straight into the caller's slot from k_query was measured 2.8 ms SLOWER per 1e8 queries than this
 	// separate gather: 1e8 scattered 8-B stores cost more than reading the IDs back through the inverse permutation)
 	launch_query(ix, ix.b_sorted.p, d_sorted_minis, nq, ix.b_ids.p, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
+	ix.prof_mark(5, s);
 	gather_ids(ix, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out, s);
+	ix.prof_mark(6, s);
 	partition_end(ix, s);
 }
 

@@ -151,6 +151,18 @@ uint64_t blmx_sequence_kmer_count(const blmx_index* ix, const uint64_t* offsets,
  * return after enqueueing and are ordered with the caller's other work on that stream; the caller synchronises.
  * Calls on one index from several streams are serialised internally where they share scratch memory. */
 int blmx_query_kmers_device(blmx_index* ix, const void* d_canon_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
+/* query_sequence_hash for sequences that are already in HBM: d_concat = concatenated characters, d_offsets = nseq + 1 offsets
+ * (offsets[0] = 0), total_len = offsets[nseq] < 2^32, nk = sum_i max(0, len_i - k + 1) as the caller computed it; d_ids gets nk
+ * IDs, sequence after sequence.  *d_err_flag (device int, may be NULL) is set to 1 on a character outside ACGTacgt. */
+int blmx_query_sequences_device(blmx_index* ix, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq, uint64_t total_len, uint64_t nk,
+                                int64_t* d_ids, int* d_err_flag, void* stream);
+/* Stage timing (HIP events on the caller's stream) of the last blmx_query_kmers_device / blmx_query_sequences_device call:
+ * after blmx_set_profiling(ix, 1) every such call records events at its stage boundaries; blmx_last_profile waits for the last
+ * one and writes 6 durations in milliseconds: [0] read front end (VALID bitmap, scan, k_read_front) | [1] k_bin_hist |
+ * [2] scan | [3] k_bin_scatter | [4] k_query (or the fused k_read_query) | [5] k_gather_ids; stages that did not run are 0.
+ * Returns the number of values written (6), 0 when nothing was recorded. */
+int blmx_set_profiling(blmx_index* ix, int on);
+int blmx_last_profile(blmx_index* ix, float* ms_out, int cap);
 /* Minimizer -> owning MPHF group for a batch of canonical k-mers on the device (group = minimizer >> (2m-1-n),
  * reference blight.cpp:692); used by the multi-GPU router to pick the destination rank. */
 int blmx_kmer_groups_device(blmx_index* ix, const void* d_canon_kmers, uint64_t nq, uint32_t* d_groups_out, void* stream);

@@ -269,8 +269,8 @@ def test_host_batches_in_chunks(B, O, k, kb, b):
     q = np.concatenate([pos, neg])
     q = np.ascontiguousarray(q[rng.permutation(len(q))])
     want = orc.query_kmers(q.reshape(-1) if kb == 8 else q)
-    ix.set_tuning("window_kb", 256)  # 2^17 k-mers per chunk
-    assert len(q) > 3 * (1 << 17)
+    ix.set_tuning("window_kb", 128)  # 2^16 k-mers per chunk
+    assert len(q) > 5 * (1 << 16)
     for binning in (-1, 1):
         ix.set_query_binning(binning)
         assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want)
