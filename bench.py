@@ -11,18 +11,33 @@ seeded synthetic unitig set (BASELINE has no offline genomes: only lambda ships 
 the same library.  Rank 0 prints ONE JSON line.
 
 Workload naming: C3 = chr1-scale 2.3e8 31-mers (k31 m9 n7 b6), C4 = human-scale 2.5e9 31-mers
-(k31 m9 n14 b6); 50 % of the queries are indexed k-mers, 50 % uniform random 31-mers.
+(k31 m9 n14 b6), C5 = 5e8 63-mers (k63 m9 n14 b8, 128-bit k-mers); 50 % of the queries are indexed k-mers, 50 % uniform
+random k-mers.  --skew draws 10 % of the unitigs from a 2-symbol source (uneven minimizer buckets).
+
+Besides the headline (`value`: the query pipeline on k-mers resident in HBM) a single-GPU run reports, under extra keys:
+  roofline      the dominant kernel (k_query) by HIP events on the launching stream, per-kernel times of the whole pipeline,
+                fractions of the 8 TB/s spec, of the 6.29 TB/s measured copy rate and of the measured random-line ceiling,
+                HBM traffic and VALU issue from the rocprofv3 PMC summary of this source tree (profiles/, when present)
+  cpu_baseline  the CPU oracle (restated reference algorithm) on the host cores, IDs compared element-wise (both k-mer widths)
+  cpu_reference the REAL reference (-t 1) on a bounded sample of the same input
+  reads         the sequence front end on 150-nt reads (half cut from the indexed text, half foreign): reads resident in HBM,
+                blmx_query_sequences on host buffers, file_query on a FASTA file, one query_sequence_hash call per read
+                from OpenMP threads through the C++ facade (the reference's calling pattern)
+  host_buffers  blmx_query_kmers / blmx_query_membership on host arrays (PCIe and host copies included)
 
 N > 1: `--mode sharded` (default) partitions the MPHF groups (contiguous minimizer-bucket ranges) over the ranks and routes
 every query k-mer to its owner with an RCCL all-to-all over xGMI (and the IDs back); `--mode replicas` keeps a full index
 per GPU with no data-path collective (upper bound).  Per-GPU query batch is fixed: weak scaling.  A sharded run also
-measures the replicas layout right after the timed region (same batch, same timing protocol) and reports it under the
-extra key `replicas` together with `ids_equal_to_sharded`; `value` is always the sharded number.
+measures the replicas layout right after the timed region and reports it under `replicas`; `value` is the sharded number.
 """
 import argparse
+import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,11 +45,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {31: 145, 63: 209}  # algorithmic bytes per query, SURVEY.md section 8(d): B(k=31,b=6)=145, B(k=63,b=8)=209
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# HBM bytes per step (all kernels of the query pipeline: k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids) from
-# rocprofv3 PMC passes of this same command (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; FETCH_SIZE calibrated = 1.000 on random
-# 64-B lines with tools/gather_ceiling, so no x2 correction on this access pattern): profiles/r01_pmc_pipeline_c4_v14.txt.
-# Only quoted for the workload it was measured on.
-TRAFFIC_BYTES = {"C4": (18.440e6 + 3.494e6) * 1024}
+HBM_COPY_GBS = 6290.0            # MI355X_MICROARCH.md: measured float4 copy
 
 WORKLOADS = {
     # name: (k, m, log2_mphf, b, indexed k-mers, queries per step per GPU)
@@ -55,10 +66,14 @@ def parse_args():
     ap.add_argument("--kmers", type=int, default=0, help="override the number of indexed k-mers")
     ap.add_argument("--queries", type=int, default=0, help="override the queries per step per GPU")
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip every CPU leg)")
     ap.add_argument("--seed", type=int, default=4)
     ap.add_argument("--no-replicas-leg", action="store_true", help="N > 1, sharded: skip the secondary replicas measurement")
     ap.add_argument("--present", type=float, default=0.5, help="fraction of the queries that are indexed k-mers (headline: 0.5)")
+    ap.add_argument("--skew", action="store_true", help="10 %% of the unitigs from a 2-symbol source (uneven buckets)")
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads of the sequence front-end leg (0 = skip)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the host-buffer / file / per-read-call measurements")
     return ap.parse_args()
 
 
@@ -66,8 +81,9 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def synth_unitigs(torch, dev, n_kmers, k, seed):
-    """Seeded random unitigs in HBM: lengths k-1+Geometric(mean 80), uniform ACGT.  Returns (ascii u8, offsets i64)."""
+def synth_unitigs(torch, dev, n_kmers, k, seed, skew=False):
+    """Seeded random unitigs in HBM: lengths k-1+Geometric(mean 80), uniform ACGT; with `skew` every tenth unitig
+    is drawn from the 2-symbol source {A, C}.  Returns (ascii u8, offsets i64, total)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     n_unitigs = max(1, n_kmers // 80)
@@ -91,6 +107,10 @@ def synth_unitigs(torch, dev, n_kmers, k, seed):
     for s in range(0, total, chunk):
         e = min(total, s + chunk)
         c = torch.randint(0, 4, (e - s,), device=dev, dtype=torch.uint8, generator=g)
+        if skew:
+            u = torch.searchsorted(offs, torch.arange(s, e, device=dev, dtype=torch.int64), right=True) - 1
+            c = torch.where((u % 10) == 3, c & 1, c)  # codes 0/1 -> A/C only
+            del u
         # 0,1,2,3 -> A C G T  (65 67 71 84)
         ascii_[s:e] = 65 + 2 * c + 2 * (c == 2).to(torch.uint8) + 13 * (c == 3).to(torch.uint8)
     ascii_[total:] = 0
@@ -125,6 +145,30 @@ def synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, seed, kmer_words, 
     return q, is_pos
 
 
+def synth_reads(torch, dev, ascii_, total, k, nreads, read_len, present, seed):
+    """`nreads` reads of `read_len` characters in HBM: `present` of them are windows of the indexed unitig text (a window may
+    run over a unitig end: the k-mers across the junction are then foreign, as with real reads over graph junctions), the rest
+    uniform random ACGT; shuffled.  Returns (chars u8 [nreads * read_len], offsets i64 [nreads + 1], nreads, number of k-mers)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    npos = int(nreads * present)
+    rows = torch.empty((nreads, read_len), device=dev, dtype=torch.uint8)
+    ar = torch.arange(read_len, device=dev, dtype=torch.int64)
+    if npos:
+        starts = torch.randint(0, max(1, total - read_len), (npos,), device=dev, dtype=torch.int64, generator=g)
+        step = 1 << 18
+        for a in range(0, npos, step):
+            z = min(npos, a + step)
+            rows[a:z] = ascii_[(starts[a:z, None] + ar[None, :]).reshape(-1)].reshape(z - a, read_len)
+    if nreads > npos:
+        c = torch.randint(0, 4, (nreads - npos, read_len), device=dev, dtype=torch.uint8, generator=g)
+        rows[npos:] = 65 + 2 * c + 2 * (c == 2).to(torch.uint8) + 13 * (c == 3).to(torch.uint8)
+    perm = torch.randperm(nreads, device=dev, generator=g)
+    chars = rows[perm].reshape(-1).contiguous()
+    offs = torch.arange(nreads + 1, device=dev, dtype=torch.int64) * read_len
+    return chars, offs, nreads, nreads * max(0, read_len - k + 1)
+
+
 def host_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives one GPU's
     share of the host, not all of its cores)."""
@@ -155,15 +199,18 @@ def export_index(ix, st, k, b):
     return arrays
 
 
-def cpu_baseline(ix, st, args_k, m, n, b, q_host, gpu_ids_host, budget_s):
-    """Time the CPU oracle (restated reference algorithm) on the box's host cores over a bounded sample of the same
-    queries on the same index (image exported from HBM) and cross-check the IDs element-wise with the GPU's."""
-    import numpy as np
+def import_oracle(ix, st, k, m, n, b):
+    """The CPU oracle's query path over the index image exported from HBM (test infrastructure: the checker and the CPU leg)."""
     from oracle import oracle as O
     t0 = time.time()
-    arrays = export_index(ix, st, args_k, b)
-    orc = O.ImportedOracle(args_k, m, n, b, st["total_nt"], st["number_kmer"], st["positions_total_size"], arrays)
-    t_import = time.time() - t0
+    arrays = export_index(ix, st, k, b)
+    orc = O.ImportedOracle(k, m, n, b, st["total_nt"], st["number_kmer"], st["positions_total_size"], arrays, kmer_bytes=st["kmer_bytes"])
+    return orc, time.time() - t0
+
+
+def cpu_baseline(orc, t_import, q_host, gpu_ids_host, budget_s):
+    """Time the CPU oracle (restated reference algorithm) on the box's host cores over a bounded sample of the same
+    queries on the same index and cross-check the IDs element-wise with the GPU's.  q_host: (nq,) uint64 or (nq, 2)."""
     threads = host_cores()
     batch = 200_000
     done = 0
@@ -181,7 +228,6 @@ def cpu_baseline(ix, st, args_k, m, n, b, q_host, gpu_ids_host, budget_s):
         elapsed += time.time() - t
         mismatches += int((ids != gpu_ids_host[done:e]).sum())
         done = e
-    orc.close()
     return {
         "value": done / elapsed if elapsed > 0 else 0.0, "unit": "queries/s", "cores": threads, "kind": "port",
         "sample": "first %d queries of the same batch on the same index (image exported from HBM, import %.1f s); "
@@ -229,6 +275,191 @@ def cpu_reference_calibration(sample_ascii, sample_offs, k, m, n, b, nq=2_000_00
     return out
 
 
+def source_digest():
+    """sha256 over the kernel sources: ties a PMC summary under profiles/ to the source tree it was measured on"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "blight_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(workload):
+    """rocprofv3 PMC summary of the bench command of this workload (tools/pmc_collect.sh -> profiles/r*_pmc_<workload>.json),
+    newest round first; None when there is none."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload.lower()))):
+        best = f
+    if not best:
+        return None
+    try:
+        d = json.load(open(best))
+        d["file"] = os.path.relpath(best, ROOT)
+        return d
+    except Exception:
+        return None
+
+
+def stage_profile(ix, fn, reps=5):
+    """average HIP-event stage times (ms) of `reps` calls of fn (a device-resident query call of this index)"""
+    ix.set_profiling(1)
+    acc = {}
+    for _ in range(reps):
+        fn()
+        for key, v in ix.last_profile().items():
+            acc[key] = acc.get(key, 0.0) + v / reps
+    ix.set_profiling(0)
+    return acc
+
+
+def roofline_block(args, k, kw, b, nq, stages, step_ms, st):
+    """`roofline` of the JSON line: the dominant kernel (k_query) + the whole pipeline + what the PMC summary adds"""
+    algo = ALGO_BYTES.get(k, 145)
+    kq_ms = stages.get("k_query", 0.0) or step_ms
+    achieved = algo * nq / (kq_ms * 1e-3) / 1e9
+    pipe_ach = algo * nq / (step_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "kernel": "k_query<%d,%d,false> (dominant kernel of the pipeline)" % (kw, b), "kernel_ms": kq_ms,
+           "algorithmic_bytes_per_query": algo, "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
+           "per_kernel_ms": {a: round(v, 4) for a, v in stages.items()},
+           "pipeline": {"kernels": "k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids (what `value` times)", "ms": step_ms,
+                        "achieved": pipe_ach, "frac": pipe_ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": pipe_ach / HBM_COPY_GBS}}
+    pmc = load_pmc(args.workload)
+    if pmc and not args.skew and not args.kmers and not args.queries and args.present == 0.5:
+        kern = pmc.get("kernels", {})
+        out["pmc"] = {"file": pmc["file"], "source_digest_matches": pmc.get("source_digest") == source_digest()}
+        kq = next((v for name, v in kern.items() if name.startswith("k_query")), None)
+        if kq:
+            # FETCH_SIZE counts a coalesced 16-B-per-lane stream at half its bytes on gfx950 (MI355X_MICROARCH.md) and random
+            # 64-B lines exactly (tools/gather_ceiling): k_query's traffic is divergent line accesses -> no correction
+            out["traffic"] = kq["fetch_bytes"] + kq["write_bytes"]
+            out["pmc"]["k_query_hbm_lines_per_query"] = kq["fetch_bytes"] / 64.0 / nq
+            if kq.get("valu_insts"):
+                # VALU issue: wave-instructions x 4 cycles (measured integer rate, profiles/r01_valu_rate.jsonl: 3.1-4.65e13
+                # lane-ops/s chip-wide) over the SIMD cycles of the kernel
+                lane_ops = kq["valu_insts"] * 64.0
+                out["valu"] = {"wave_insts_per_launch": kq["valu_insts"], "insts_per_query": kq["valu_insts"] * 64.0 / nq,
+                               "lane_ops_per_s": lane_ops / (kq_ms * 1e-3),
+                               "frac_of_measured_valu_rate": [lane_ops / (kq_ms * 1e-3) / 4.65e13, lane_ops / (kq_ms * 1e-3) / 3.1e13]}
+            ceil = pmc.get("gather_ceiling_lines_per_s")
+            if ceil:
+                out["frac_of_gather_ceiling"] = kq["fetch_bytes"] / 64.0 / (kq_ms * 1e-3) / ceil
+        tot = 0.0
+        for name, v in kern.items():  # the partition passes read wide coalesced streams: FETCH_SIZE counts those at half their bytes
+            tot += v["fetch_bytes"] * (2.0 if name.startswith(("k_bin_hist", "k_bin_scatter")) else 1.0) + v["write_bytes"]
+        out["pipeline"]["traffic"] = tot
+    return out
+
+
+def reads_leg(torch, B, ix, dev, ascii_, total, k, args, orc):
+    """the sequence / read front end on 150-nt reads: half cut from the indexed text, half foreign"""
+    import numpy as np
+    stream = torch.cuda.current_stream().cuda_stream
+    chars, roffs, nreads, nk = synth_reads(torch, dev, ascii_, total, k, args.reads, args.read_len, 0.5, args.seed * 7 + 1)
+    ids = torch.empty(nk, device=dev, dtype=torch.int64)
+    err = torch.zeros(16, device=dev, dtype=torch.int32)
+
+    def dev_call():
+        ix.query_sequences_device(chars.data_ptr(), roffs.data_ptr(), nreads, int(chars.numel()), nk, ids.data_ptr(), err.data_ptr(), stream)
+
+    for _ in range(2):
+        dev_call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        dev_call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out = {"workload": "%d reads x %d nt (50 %% windows of the indexed text, 50 %% random), %d k-mers per pass" % (nreads, args.read_len, nk),
+           "device_resident": {"kmers_per_s": nk / (ms * 1e-3), "ms": ms, "stages_ms": {a: round(v, 4) for a, v in stage_profile(ix, dev_call).items()}},
+           "found_fraction": float((ids >= 0).float().mean().item()), "invalid_char_flag": int(err[0].item())}
+    ids_dev = ids.cpu().numpy()
+    if orc is not None:  # a sample of the reads against the CPU oracle, element-wise
+        ns = 3000
+        raw = chars[: ns * args.read_len].cpu().numpy().tobytes()
+        want = np.concatenate([orc.query_sequence(raw[i * args.read_len:(i + 1) * args.read_len]) for i in range(ns)])
+        out["oracle_sample_equal"] = bool(np.array_equal(want, ids_dev[: want.size]))
+    if args.no_host_legs:
+        return out
+    # ---- host buffers through blmx_query_sequences (PCIe + host copies included)
+    h_chars = chars.cpu().numpy()
+    h_offs = roffs.cpu().numpy().astype(np.uint64)
+    h_ids = np.empty(nk, dtype=np.int64)
+    u64p, i64p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int64)
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        rc = ix._lib.blmx_query_sequences(ix._h, h_chars.ctypes.data_as(ctypes.c_char_p), h_offs.ctypes.data_as(u64p), nreads, h_ids.ctypes.data_as(i64p))
+        dt = time.perf_counter() - t
+        assert rc == 0
+        best = dt if best is None else min(best, dt)
+    out["host_buffers"] = {"entry": "blmx_query_sequences", "kmers_per_s": nk / best, "seconds": best, "ids_equal_to_device": bool(np.array_equal(h_ids, ids_dev))}
+    # ---- file_query on a FASTA file of the same reads
+    tmpdir = tempfile.mkdtemp(prefix="blight_bench_", dir=os.environ.get("TMPDIR") or None)
+    path = os.path.join(tmpdir, "reads.fa")
+    rec = np.empty((nreads, 11 + args.read_len + 1), dtype=np.uint8)  # ">%09d\n<read>\n"
+    digits = (np.arange(nreads, dtype=np.int64)[:, None] // (10 ** np.arange(8, -1, -1, dtype=np.int64))[None, :]) % 10
+    rec[:, 0] = ord(">")
+    rec[:, 1:10] = digits.astype(np.uint8) + ord("0")
+    rec[:, 10] = ord("\n")
+    rec[:, 11:11 + args.read_len] = h_chars.reshape(nreads, args.read_len)
+    rec[:, -1] = ord("\n")
+    rec.tofile(path)
+    fsize = os.path.getsize(path)
+    good = ctypes.c_uint64()
+    bad = ctypes.c_uint64()
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        rc = ix._lib.blmx_query_file(ix._h, path.encode(), ctypes.byref(good), ctypes.byref(bad))
+        dt = time.perf_counter() - t
+        assert rc == 0
+        best = dt if best is None else min(best, dt)
+    out["file_query"] = {"entry": "blmx_query_file", "file_bytes": fsize, "kmers_per_s": nk / best, "seconds": best,
+                         "counts_equal_to_device": (good.value, bad.value) == (int((ids_dev >= 0).sum()), int((ids_dev < 0).sum()))}
+    os.unlink(path)
+    os.rmdir(tmpdir)
+    # ---- one query_sequence_hash call per read from OpenMP threads through the C++ facade (the reference's calling pattern)
+    libpath = os.path.join(ROOT, "tools", "libbench_calls.so")
+    if os.path.exists(libpath):
+        lib = ctypes.CDLL(libpath)
+        lib.blight_bench_read_calls.argtypes = [ctypes.c_void_p, ctypes.c_char_p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+        ncall = min(nreads, 200_000)
+        nk_call = ncall * max(0, args.read_len - k + 1)
+        calls = {}
+        for threads in sorted({1, min(8, host_cores())}):
+            secs = ctypes.c_double()
+            r = [ctypes.c_uint64() for _ in range(4)]
+            rc = lib.blight_bench_read_calls(ix._h, h_chars.ctypes.data_as(ctypes.c_char_p), h_offs.ctypes.data_as(u64p), ncall, threads, 1,
+                                             ctypes.byref(secs), *[ctypes.byref(x) for x in r])
+            assert rc == 0
+            calls["threads_%d" % threads] = {"calls_per_s": ncall / secs.value, "kmers_per_s": r[0].value / secs.value,
+                                             "counts_equal_to_device": (r[1].value, r[2].value) == (int((ids_dev[:nk_call] >= 0).sum()), int((ids_dev[:nk_call] < 0).sum()))}
+        out["per_read_calls"] = {"entry": "kmer_Set_Light::query_sequence_hash(std::string) via include/blight.h, OpenMP callers", "reads": ncall, **calls}
+    return out
+
+
+def host_kmer_legs(torch, ix, q, ids, kw):
+    """blmx_query_kmers / blmx_query_membership on host arrays: PCIe and the host copies included"""
+    import numpy as np
+    nq = min(q.shape[0], 100_000_000)
+    h_q = q[:nq].cpu().numpy().view(np.uint64).reshape(-1)
+    want = ids[:nq].cpu().numpy()
+    out = {"queries": nq}
+    for name, call, dtype in (("blmx_query_kmers", ix.query_kmer_hash, np.int64), ("blmx_query_membership", ix.query_kmer_bool, None)):
+        best = None
+        for _ in range(3):
+            t = time.perf_counter()
+            got = call(h_q)
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        same = bool(np.array_equal(got, want)) if dtype is not None else bool(np.array_equal(got, want >= 0))
+        out[name] = {"queries_per_s": nq / best, "seconds": best, "equal_to_device_path": same}
+    return out
+
+
 def main():
     args = parse_args()
     import torch  # first: one HIP runtime for torch and the library
@@ -264,7 +495,7 @@ def main():
 
     # ---- index: seeded synthetic unitigs generated in HBM, built by the HIP pipeline
     t0 = time.time()
-    ascii_, offs, total = synth_unitigs(torch, dev, n_kmers, k, args.seed)
+    ascii_, offs, total = synth_unitigs(torch, dev, n_kmers, k, args.seed, args.skew)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     ref_sample = None
@@ -281,9 +512,9 @@ def main():
     t_build = time.time() - t0
     st = ix.stats()
     if rank == 0:
-        log("workload %s: %d k-mers, %d super-k-mers, %d unitigs, %.2f GB index, gen %.1f s, build %.1f s (%.1f M k-mers/s)" % (
-            args.workload, st["number_kmer"], st["number_super_kmer"], offs.numel() - 1, st["device_bytes"] / 1e9, t_gen, t_build,
-            st["number_kmer"] / t_build / 1e6))
+        log("workload %s%s: %d k-mers, %d super-k-mers, %d unitigs, %.2f GB index, gen %.1f s, build %.2f s (%.1f M k-mers/s)" % (
+            args.workload, " (skewed)" if args.skew else "", st["number_kmer"], st["number_super_kmer"], offs.numel() - 1, st["device_bytes"] / 1e9,
+            t_gen, t_build, st["number_kmer"] / t_build / 1e6))
 
     # ---- queries (per rank, resident in HBM)
     q, is_pos = synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank, kw, args.present)
@@ -314,7 +545,7 @@ def main():
             ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
             t_build = time.time() - t0
             st = ix.stats()
-    keep_input = querier is not None and not args.no_replicas_leg
+    keep_input = (querier is not None and not args.no_replicas_leg) or (world == 1 and args.reads > 0)
     if not keep_input:
         del ascii_
 
@@ -391,36 +622,53 @@ def main():
 
     if rank == 0:
         value = world * nq * args.steps / dt
-        algo = ALGO_BYTES.get(k, 145)
-        achieved = algo * nq / (kern_ms * 1e-3) / 1e9
+        stages = stage_profile(ix, step) if querier is None else {}
         out = {
             "metric": "kmer_id_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if kw == 1 else "u128", "data": "synthetic",
-            "config": {"workload": "%s: %d indexed %d-mers (seeded synthetic unitigs, k%d m%d n%d b%d), %d queries/step/GPU, "
-                                   "%g%% indexed / %g%% random" % (args.workload, st["number_kmer"], k, k, m, n, b, nq,
-                                                                    100 * args.present, 100 * (1 - args.present)),
+            "config": {"workload": "%s%s: %d indexed %d-mers (seeded synthetic unitigs, k%d m%d n%d b%d), %d queries/step/GPU, "
+                                   "%g%% indexed / %g%% random" % (args.workload, " skewed (every tenth unitig from {A,C})" if args.skew else "",
+                                                                    st["number_kmer"], k, k, m, n, b, nq, 100 * args.present, 100 * (1 - args.present)),
                        "parallelism": "1 GPU" if world == 1 else ("%s x%d" % (effective_mode, world)),
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
-                       "build_kmers_per_sec": st["number_kmer"] / t_build},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES.get(args.workload) if world == 1 else None, "kernel": "query pipeline: k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids (k_query = 2/3 of it)",
-                         "kernel_ms": kern_ms if world == 1 else None, "algorithmic_bytes_per_query": algo},
+                       "build_kmers_per_sec": st["number_kmer"] / t_build, "largest_mphf": st["largest_mphf"], "largest_bucket": st["largest_bucket"],
+                       "mphf_groups_lds_built": st["mphf_groups_lds_built"], "mphf_groups": st["ngroups"], "fallback_keys": st["fallback_keys"]},
+            "roofline": roofline_block(args, k, kw, b, nq, stages, kern_ms, st) if world == 1 else
+            {"bound": "hbm", "achieved": ALGO_BYTES.get(k, 145) * nq * world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+             "frac": ALGO_BYTES.get(k, 145) * nq / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+             "kernel": "whole sharded step (partition, exchange, k_query, exchange, gather) against the aggregate HBM peak"},
             "checks": {"indexed_queries_found": n_pos_found, "indexed_queries": n_pos, "random_queries_found": n_neg_found,
                        "ok": bool(ok)},
         }
-        if world == 1 and args.cpu_seconds > 0 and kw == 1:
+        orc = None
+        out["cpu_baseline"] = None
+        if world == 1 and args.cpu_seconds > 0:
             try:
-                out["cpu_baseline"] = cpu_baseline(ix, st, k, m, n, b, q.cpu().numpy().view("uint64").reshape(-1),
-                                                   ids.cpu().numpy(), args.cpu_seconds)
+                import numpy as np
+                orc, t_import = import_oracle(ix, st, k, m, n, b)
+                q_host = q.cpu().numpy().view(np.uint64)
+                q_host = q_host.reshape(-1) if kw == 1 else q_host.reshape(-1, 2)
+                out["cpu_baseline"] = cpu_baseline(orc, t_import, q_host, ids.cpu().numpy(), args.cpu_seconds)
             except Exception as e:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+            if kw == 1:
+                try:
+                    out["cpu_reference"] = cpu_reference_calibration(ref_sample[0], ref_sample[1], k, m, n, b) if ref_sample else None
+                except Exception as e:
+                    out["cpu_reference"] = {"value": None, "kind": "reference", "sample": "failed: %r" % (e,)}
+        if world == 1 and args.reads > 0:
             try:
-                out["cpu_reference"] = cpu_reference_calibration(ref_sample[0], ref_sample[1], k, m, n, b) if ref_sample else None
+                out["reads"] = reads_leg(torch, blight_amd, ix, dev, ascii_, total, k, args, orc)
             except Exception as e:
-                out["cpu_reference"] = {"value": None, "kind": "reference", "sample": "failed: %r" % (e,)}
-        else:
-            out["cpu_baseline"] = None
+                out["reads"] = {"failed": repr(e)}
+            if not args.no_host_legs:
+                try:
+                    out["host_buffers"] = host_kmer_legs(torch, ix, q, ids, kw)
+                except Exception as e:
+                    out["host_buffers"] = {"failed": repr(e)}
+        if orc is not None:
+            orc.close()
         if replicas is not None:
             out["replicas"] = replicas
         print(json.dumps(out), flush=True)

@@ -78,7 +78,23 @@ public:
 	}
 	kmer_Set_Light(const kmer_Set_Light&) = delete;
 	kmer_Set_Light& operator=(const kmer_Set_Light&) = delete;
-	~kmer_Set_Light() { blmx_destroy(_h); }
+	~kmer_Set_Light()
+	{
+		if (_owned)
+			blmx_destroy(_h);
+	}
+	// Facade over an index that was created (and stays owned) by a caller of the C ABI, e.g. another language binding.
+	static kmer_Set_Light* attach(blmx_index* h)
+	{
+		blmx_stats_t st;
+		if (blmx_abi_version() != BLMX_ABI_VERSION || blmx_stats(h, &st) != BLMX_OK)
+			throw std::runtime_error("cannot attach to this index handle");
+		if (st.kmer_bytes != sizeof(kmer_t))
+			throw std::invalid_argument("index was created with another kmer_t width (BLIGHT_KMER_128)");
+		kmer_Set_Light* f = new kmer_Set_Light(h, st);
+		f->refresh();
+		return f;
+	}
 
 	// blight.cpp:108-125 (prints the reference's timing lines and index recap, blight.cpp:361-378)
 	void construct_index(const std::string& input_file)
@@ -241,6 +257,12 @@ public:
 private:
 	blmx_index* _h = nullptr;
 	blmx_stats_t _st{};
+	bool _owned = true;
+
+	kmer_Set_Light(blmx_index* h, const blmx_stats_t& st)
+	    : _k((ksize_t)st.k), _minimizer_length((ksize_t)st.m), _core_number(1), bit_saved_sub((bitsize_t)st.bits_saved), _h(h), _owned(false)
+	{
+	}
 
 	void check(int rc)
 	{

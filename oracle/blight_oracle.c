@@ -209,14 +209,8 @@ void orc_free(orc_handle *h)
 	if (!h)
 		return;
 	if (h->borrowed) {
-		orc_index_64 *ix = h->i64;
-		for (uint32_t g = 0; g < ix->ngroups; g++) {
-			free(ix->mphf[g].ranks);
-			free(ix->mphf[g].fallback);
-		}
-		free(ix->mphf);
-		free(ix->g_nbits);
-		free(ix);
+		orc_free_imported_64(h->i64);
+		orc_free_imported_128(h->i128);
 		free(h);
 		return;
 	}
@@ -337,68 +331,23 @@ int64_t orc_query_sequence(const orc_handle *h, const char *s, uint64_t len, int
  * alive); only the rank samples (bitVector::build_ranks, bbhash.h:447-465) and the per-group fallback tables are built
  * here.  seq must be padded with zero words (>= (2^b + k)/32 + 4) past total_nt.  64-bit k-mers only.
  */
-int orc_import(orc_handle **out, int k, int m, int n, int b, uint64_t total_nt, uint64_t number_kmer, const uint32_t *bucket_nt,
+int orc_import(orc_handle **out, int k, int m, int n, int b, int kmer_bytes, uint64_t total_nt, uint64_t number_kmer, const uint32_t *bucket_nt,
                const uint64_t *bucket_start, const uint64_t *seq, const uint64_t *positions, uint64_t positions_bits,
                const uint64_t *g_nkeys, const uint64_t *g_prefix, const uint64_t *g_posstart, const uint32_t *g_nbits,
                const uint64_t *level_sizes, const uint64_t *wbase, const uint64_t *bits, const uint64_t *fb_keys,
                const uint64_t *fb_ranks, const uint32_t *fb_group, uint64_t nfb)
 {
+	if (kmer_bytes != 8 && kmer_bytes != 16)
+		return ORC_EINVAL;
 	orc_handle *h = (orc_handle *)calloc(1, sizeof(*h));
-	orc_index_64 *ix = (orc_index_64 *)calloc(1, sizeof(*ix));
-	h->kmer_bytes = 8;
-	h->i64 = ix;
+	h->kmer_bytes = kmer_bytes;
 	h->borrowed = 1;
-	ix->k = k;
-	ix->m = m;
-	ix->n = n;
-	ix->b = b;
-	ix->gshift = 2 * m - 1 - n;
-	ix->nbuckets = 1u << (2 * m - 1);
-	ix->ngroups = 1u << n;
-	ix->total_nt = total_nt;
-	ix->number_kmer = number_kmer;
-	ix->bucket_nt = (uint32_t *)bucket_nt;
-	ix->bucket_start = (uint64_t *)bucket_start;
-	ix->seq = (uint64_t *)seq;
-	ix->positions = (uint64_t *)positions;
-	ix->positions_bits = positions_bits;
-	ix->g_nkeys = (uint64_t *)g_nkeys;
-	ix->g_prefix = (uint64_t *)g_prefix;
-	ix->g_posstart = (uint64_t *)g_posstart;
-	ix->g_nbits = (uint8_t *)malloc(ix->ngroups);
-	ix->mphf = (orc_mphf_64 *)calloc(ix->ngroups, sizeof(orc_mphf_64));
-	uint64_t f = 0;
-#pragma omp parallel for schedule(dynamic, 64)
-	for (int64_t g = 0; g < (int64_t)ix->ngroups; g++) {
-		orc_mphf_64 *mp = &ix->mphf[g];
-		ix->g_nbits[g] = (uint8_t)g_nbits[g];
-		mp->nelem = g_nkeys[g];
-		if (!mp->nelem)
-			continue;
-		memcpy(mp->sizes, level_sizes + (uint64_t)g * ORC_NLEVELS, sizeof(mp->sizes));
-		mp->nwords = wbase[g + 1] - wbase[g];
-		mp->bits = (uint64_t *)bits + wbase[g];
-		orc_build_ranks_64(mp, mp->nwords * 64);
-	}
-	/* fallback: the device table keeps every occurrence sorted by (group, key, input order); winner = last of a run */
-	while (f < nfb) {
-		uint32_t g = fb_group[f];
-		uint64_t e = f;
-		while (e < nfb && fb_group[e] == g)
-			e++;
-		orc_mphf_64 *mp = &ix->mphf[g];
-		mp->fallback = (orc_fb_entry_64 *)malloc((e - f) * sizeof(orc_fb_entry_64));
-		uint64_t o = 0;
-		for (uint64_t i = f; i < e; i++) {
-			if (i + 1 < e && fb_keys[i + 1] == fb_keys[i])
-				continue;
-			mp->fallback[o].key = fb_keys[i];
-			mp->fallback[o].rank = fb_ranks[i];
-			o++;
-		}
-		mp->nfallback = o;
-		f = e;
-	}
+	if (kmer_bytes == 8)
+		h->i64 = orc_import_64(k, m, n, b, total_nt, number_kmer, bucket_nt, bucket_start, seq, positions, positions_bits, g_nkeys, g_prefix,
+		                       g_posstart, g_nbits, level_sizes, wbase, bits, fb_keys, fb_ranks, fb_group, nfb);
+	else
+		h->i128 = orc_import_128(k, m, n, b, total_nt, number_kmer, bucket_nt, bucket_start, seq, positions, positions_bits, g_nkeys, g_prefix,
+		                         g_posstart, g_nbits, level_sizes, wbase, bits, fb_keys, fb_ranks, fb_group, nfb);
 	*out = h;
 	return 0;
 }

@@ -101,7 +101,7 @@ def _orc():
         lib.orc_build.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, u64p,
                                   C.c_uint64]
         lib.orc_free.argtypes = [C.c_void_p]
-        lib.orc_import.argtypes = [C.POINTER(C.c_void_p)] + [C.c_int] * 4 + [C.c_uint64, C.c_uint64, u32p, u64p, u64p, u64p, C.c_uint64,
+        lib.orc_import.argtypes = [C.POINTER(C.c_void_p)] + [C.c_int] * 5 + [C.c_uint64, C.c_uint64, u32p, u64p, u64p, u64p, C.c_uint64,
                                    u64p, u64p, u64p, u32p, u64p, u64p, u64p, u64p, u64p, u32p, C.c_uint64]
         lib.orc_query_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, i64p, C.c_int]
         lib.orc_query_kmers_mini.argtypes = [C.c_void_p, C.c_void_p, u32p, C.c_uint64, i64p, C.c_int]
@@ -266,14 +266,14 @@ class ImportedOracle(Oracle):
     `arrays` = dict of numpy arrays named like blight_amd.EXPORT (bucket_nt, bucket_start, seq (zero-padded), positions,
     g_nkeys, g_prefix, g_posstart, g_nbits(u32), level_sizes, g_wbase, mphf_bits, fb_keys, fb_ranks, fb_group)."""
 
-    def __init__(self, k, m, n, b, total_nt, number_kmer, positions_bits, arrays):
+    def __init__(self, k, m, n, b, total_nt, number_kmer, positions_bits, arrays, kmer_bytes=8):
         self.lib = _orc()
-        self.kmer_bytes = 8
+        self.kmer_bytes = kmer_bytes
         self.k, self.m, self.n, self.b = k, m, n, b
         self._keep = {key: np.ascontiguousarray(v) for key, v in arrays.items()}
         a = self._keep
         h = C.c_void_p()
-        rc = self.lib.orc_import(C.byref(h), k, m, n, b, total_nt, number_kmer, _ptr(a["bucket_nt"], u32p),
+        rc = self.lib.orc_import(C.byref(h), k, m, n, b, kmer_bytes, total_nt, number_kmer, _ptr(a["bucket_nt"], u32p),
                                  _ptr(a["bucket_start"], u64p), _ptr(a["seq"], u64p), _ptr(a["positions"], u64p), positions_bits,
                                  _ptr(a["g_nkeys"], u64p), _ptr(a["g_prefix"], u64p), _ptr(a["g_posstart"], u64p),
                                  _ptr(a["g_nbits"], u32p), _ptr(a["level_sizes"], u64p), _ptr(a["g_wbase"], u64p),

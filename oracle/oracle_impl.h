@@ -440,6 +440,87 @@ static void SUF(orc_free_index)(SUF(orc_index) *ix)
 	free(ix);
 }
 
+/* An index image exported from elsewhere (bench.py: the HIP build's arrays copied back from HBM): the big arrays stay the
+ * caller's; ranks are rebuilt here (bitVector::build_ranks, bbhash.h:447-465), the fallback table keeps the LAST entry of every
+ * run of equal keys (the map's last assignment wins, bbhash.h:724).  fb_keys: KMER_BITS / 64 little-endian words per key. */
+static SUF(orc_index) *SUF(orc_import)(int k, int m, int n, int b, uint64_t total_nt, uint64_t number_kmer, const uint32_t *bucket_nt,
+                                       const uint64_t *bucket_start, const uint64_t *seq, const uint64_t *positions, uint64_t positions_bits,
+                                       const uint64_t *g_nkeys, const uint64_t *g_prefix, const uint64_t *g_posstart, const uint32_t *g_nbits,
+                                       const uint64_t *level_sizes, const uint64_t *wbase, const uint64_t *bits, const uint64_t *fb_keys,
+                                       const uint64_t *fb_ranks, const uint32_t *fb_group, uint64_t nfb)
+{
+	SUF(orc_index) *ix = (SUF(orc_index) *)calloc(1, sizeof(*ix));
+	ix->k = k;
+	ix->m = m;
+	ix->n = n;
+	ix->b = b;
+	ix->gshift = 2 * m - 1 - n;
+	ix->nbuckets = 1u << (2 * m - 1);
+	ix->ngroups = 1u << n;
+	ix->total_nt = total_nt;
+	ix->number_kmer = number_kmer;
+	ix->bucket_nt = (uint32_t *)bucket_nt;
+	ix->bucket_start = (uint64_t *)bucket_start;
+	ix->seq = (uint64_t *)seq;
+	ix->positions = (uint64_t *)positions;
+	ix->positions_bits = positions_bits;
+	ix->g_nkeys = (uint64_t *)g_nkeys;
+	ix->g_prefix = (uint64_t *)g_prefix;
+	ix->g_posstart = (uint64_t *)g_posstart;
+	ix->g_nbits = (uint8_t *)malloc(ix->ngroups);
+	ix->mphf = (SUF(orc_mphf) *)calloc(ix->ngroups, sizeof(SUF(orc_mphf)));
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int64_t g = 0; g < (int64_t)ix->ngroups; g++) {
+		SUF(orc_mphf) *mp = &ix->mphf[g];
+		ix->g_nbits[g] = (uint8_t)g_nbits[g];
+		mp->nelem = g_nkeys[g];
+		if (!mp->nelem)
+			continue;
+		memcpy(mp->sizes, level_sizes + (uint64_t)g * ORC_NLEVELS, sizeof(mp->sizes));
+		mp->nwords = wbase[g + 1] - wbase[g];
+		mp->bits = (uint64_t *)bits + wbase[g];
+		SUF(orc_build_ranks)(mp, mp->nwords * 64);
+	}
+	const unsigned kw = KMER_BITS / 64;
+	uint64_t f = 0;
+	while (f < nfb) {
+		const uint32_t g = fb_group[f];
+		uint64_t e = f;
+		while (e < nfb && fb_group[e] == g)
+			e++;
+		SUF(orc_mphf) *mp = &ix->mphf[g];
+		mp->fallback = (SUF(orc_fb_entry) *)malloc((e - f) * sizeof(SUF(orc_fb_entry)));
+		uint64_t o = 0;
+		for (uint64_t i = f; i < e; i++) {
+			if (i + 1 < e && memcmp(fb_keys + (i + 1) * kw, fb_keys + i * kw, 8 * kw) == 0)
+				continue;
+			KMER_T key = (KMER_T)fb_keys[i * kw];
+#if KMER_BITS == 128
+			key |= (KMER_T)fb_keys[i * kw + 1] << 64;
+#endif
+			mp->fallback[o].key = key;
+			mp->fallback[o].rank = fb_ranks[i];
+			o++;
+		}
+		mp->nfallback = o;
+		f = e;
+	}
+	return ix;
+}
+
+static void SUF(orc_free_imported)(SUF(orc_index) *ix)
+{
+	if (!ix)
+		return;
+	for (uint32_t g = 0; g < ix->ngroups; g++) {
+		free(ix->mphf[g].ranks);
+		free(ix->mphf[g].fallback);
+	}
+	free(ix->mphf);
+	free(ix->g_nbits);
+	free(ix);
+}
+
 /*
  * construct_index (blight.cpp:108-125) = create_super_buckets_regular (:185-307) + read_super_buckets (:328-383),
  * at t = 1, without the gzip temp files (their only effect is the order in which super-k-mers reach str2bool:
