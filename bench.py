@@ -422,7 +422,7 @@ def reads_leg(torch, B, ix, dev, ascii_, total, k, args, orc):
     os.unlink(path)
     os.rmdir(tmpdir)
     # ---- one query_sequence_hash call per read from OpenMP threads through the C++ facade (the reference's calling pattern)
-    libpath = os.path.join(ROOT, "tools", "libbench_calls.so")
+    libpath = os.path.join(ROOT, "tools", "libbench_calls.so" if k <= 32 else "libbench_calls128.so")  # kmer_t = uint64_t / __uint128_t
     if os.path.exists(libpath):
         lib = ctypes.CDLL(libpath)
         lib.blight_bench_read_calls.argtypes = [ctypes.c_void_p, ctypes.c_char_p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5

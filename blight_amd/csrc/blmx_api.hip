@@ -569,6 +569,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_query_heads = value;
 	else if (k == "reads_mode")
 		ix.tune_reads_mode = value;
+	else if (k == "narrow_ids")
+		ix.tune_narrow_ids = value;
 	else if (k == "window_kb")
 		ix.tune_window_kb = value;
 	else if (k == "query_binning")

@@ -13,11 +13,13 @@
 //     the reference's record rule and k-mer starts are found on the device (blmx_reads.hip).  Only the two recap counters
 //     come back.
 #include <fcntl.h>
+#include <immintrin.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +34,8 @@ namespace blmx {
 namespace {
 
 // ---- persistent host threads for parallel copies and reads -------------------------------------------------------------------
+class WorkerPool;
+using WorkerPoolRef = WorkerPool&;
 class WorkerPool {
 public:
 	explicit WorkerPool(unsigned nthreads)
@@ -115,29 +119,109 @@ private:
 
 constexpr size_t kCopyPiece = 4u << 20;
 
+// BLIGHT_TRACE=1: wall time of the host phases of the window pipelines on stderr
+struct Trace {
+	bool on;
+	std::chrono::steady_clock::time_point t;
+	Trace() : on(getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) != 0), t(std::chrono::steady_clock::now()) {}
+	void lap(const char* what, uint64_t window)
+	{
+		if (!on)
+			return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[blmx front] window %3llu %-18s %8.3f ms\n", (unsigned long long)window, what, std::chrono::duration<double, std::milli>(now - t).count());
+		t = now;
+	}
+};
+
+// Large staging copies write memory that the CPU does not read again (a pinned buffer on its way to the GPU, or the caller's
+// result array): non-temporal stores skip the read-for-ownership of the destination lines.
+__attribute__((target("avx2"))) void stream_copy_avx2(char* dst, const char* src, size_t n)
+{
+	while (n && ((uintptr_t)dst & 31)) {
+		*dst++ = *src++;
+		n--;
+	}
+	for (; n >= 128; n -= 128, dst += 128, src += 128) {
+		const __m256i a = _mm256_loadu_si256((const __m256i*)src), b = _mm256_loadu_si256((const __m256i*)(src + 32)),
+		              c = _mm256_loadu_si256((const __m256i*)(src + 64)), d = _mm256_loadu_si256((const __m256i*)(src + 96));
+		_mm256_stream_si256((__m256i*)dst, a);
+		_mm256_stream_si256((__m256i*)(dst + 32), b);
+		_mm256_stream_si256((__m256i*)(dst + 64), c);
+		_mm256_stream_si256((__m256i*)(dst + 96), d);
+	}
+	_mm_sfence();
+	if (n)
+		memcpy(dst, src, n);
+}
+
+// IDs cross PCIe as 32-bit words when the index holds fewer than 2^32 - 1 k-mers (0xffffffff = absent): widen on the way out
+__attribute__((target("avx2"))) void widen_ids_avx2(int64_t* dst, const uint32_t* src, size_t n)
+{
+	const __m256i absent = _mm256_set1_epi64x(0xffffffffll);
+	size_t i = 0;
+	if (((uintptr_t)dst & 31) == 0)
+		for (; i + 8 <= n; i += 8) {
+			const __m256i a = _mm256_cvtepu32_epi64(_mm_loadu_si128((const __m128i*)(src + i)));
+			const __m256i b = _mm256_cvtepu32_epi64(_mm_loadu_si128((const __m128i*)(src + i + 4)));
+			_mm256_stream_si256((__m256i*)(dst + i), _mm256_or_si256(a, _mm256_cmpeq_epi64(a, absent)));
+			_mm256_stream_si256((__m256i*)(dst + i + 4), _mm256_or_si256(b, _mm256_cmpeq_epi64(b, absent)));
+		}
+	_mm_sfence();
+	for (; i < n; i++)
+		dst[i] = src[i] == 0xffffffffu ? -1 : (int64_t)src[i];
+}
+
+void widen_ids(WorkerPoolRef pool, int64_t* dst, const uint32_t* src, size_t n);
+
+void copy_piece(char* dst, const char* src, size_t n)
+{
+	static const bool nt = __builtin_cpu_supports("avx2") && !(getenv("BLIGHT_NT_COPY") && atoi(getenv("BLIGHT_NT_COPY")) == 0);
+	if (nt && n >= (256u << 10))
+		stream_copy_avx2(dst, src, n);
+	else
+		memcpy(dst, src, n);
+}
+
 void parallel_copy(WorkerPool& pool, void* dst, const void* src, size_t n)
 {
 	if (n <= kCopyPiece) {
-		memcpy(dst, src, n);
+		copy_piece((char*)dst, (const char*)src, n);
 		return;
 	}
 	const size_t pieces = (n + kCopyPiece - 1) / kCopyPiece;
 	pool.run(pieces, [&](size_t i) {
 		const size_t a = i * kCopyPiece, z = std::min(n, a + kCopyPiece);
-		memcpy((char*)dst + a, (const char*)src + a, z - a);
+		copy_piece((char*)dst + a, (const char*)src + a, z - a);
+	});
+}
+
+void widen_ids(WorkerPoolRef pool, int64_t* dst, const uint32_t* src, size_t n)
+{
+	static const bool avx2 = __builtin_cpu_supports("avx2");
+	const size_t piece = 1u << 20;
+	pool.run((n + piece - 1) / piece, [&](size_t i) {
+		const size_t a = i * piece, z = std::min(n, a + piece);
+		if (avx2) {
+			widen_ids_avx2(dst + a, src + a, z - a);
+		} else {
+			for (size_t j = a; j < z; j++)
+				dst[j] = src[j] == 0xffffffffu ? -1 : (int64_t)src[j];
+		}
 	});
 }
 
 // ---- slots -----------------------------------------------------------------------------------------------------------------------
 struct WindowSlot {
 	Pinned h_in, h_aux, h_out, h_flags;
-	DevBuf d_in, d_aux, d_kmers, d_minis, d_ids, d_flags;
+	DevBuf d_in, d_aux, d_aux2, d_kmers, d_minis, d_ids, d_flags;
 	FrontScratch fs;
 	hipStream_t s = nullptr;
 	hipEvent_t done = nullptr;
 	bool in_flight = false;
 	uint64_t nk = 0, out_index = 0;  // results of the window in flight: count and where they go in the caller's array
 	size_t out_elem = 8;
+	bool narrow = false;  // the IDs in h_out are 32-bit words
 	~WindowSlot()
 	{
 		if (done)
@@ -171,8 +255,10 @@ void grow(DevBuf& b, size_t bytes, hipStream_t s)
 
 }  // namespace
 
+constexpr int kWindowSlots = 3;  // copy-in | H2D + kernels + D2H | copy-out of three windows overlap
+
 struct HostFront {
-	WindowSlot win[2];
+	WindowSlot win[kWindowSlots];
 	std::vector<std::unique_ptr<SmallSlot>> small_all;
 	std::vector<SmallSlot*> small_free;
 	std::mutex small_mu;
@@ -260,6 +346,9 @@ struct SmallLease {
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// every ID (and -1 as 0xffffffff) fits 32 bits: results cross PCIe as 4-byte words
+bool ids_fit_32(const Index& ix) { return ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull; }
 
 uint64_t window_positions(const Index& ix)
 {
@@ -356,7 +445,10 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 		w.in_flight = false;
 		if (w.h_flags.as<int>()[0])
 			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
-		parallel_copy(*hf.pool, ids_out + w.out_index, w.h_out.p, w.nk * 8);
+		if (w.narrow)
+			widen_ids(*hf.pool, ids_out + w.out_index, w.h_out.as<uint32_t>(), w.nk);
+		else
+			parallel_copy(*hf.pool, ids_out + w.out_index, w.h_out.p, w.nk * 8);
 	};
 	struct Drain {  // an exception must not leave copies into the caller's buffers in flight
 		HostFront& hf;
@@ -376,7 +468,7 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 		if (nk == 0)
 			continue;
 		WindowSlot& w = hf.win[cur];
-		cur ^= 1;
+		cur = (cur + 1) % kWindowSlots;
 		prepare_window_slot(w);
 		finish(w);
 		// sequences that overlap the window's characters: their starts break k-mers
@@ -394,16 +486,24 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 		BLMX_HIP(hipMemsetAsync(w.d_flags.p, 0, 16, w.s));
 		front_valid_concat(ix, w.fs, w.d_aux.as<uint64_t>(), ns + 1, A, npos, nbytes, w.s);
 		query_window(ix, w, nbytes, npos, nk, true, nullptr);
-		w.h_out.ensure(nk * 8);
-		BLMX_HIP(hipMemcpyAsync(w.h_out.p, w.d_ids.p, nk * 8, hipMemcpyDeviceToHost, w.s));
+		w.narrow = ids_fit_32(ix);
+		if (w.narrow) {
+			grow(w.d_aux2, nk * 4, w.s);
+			launch_narrow_ids(w.d_ids.as<int64_t>(), nk, w.d_aux2.as<uint32_t>(), w.s);
+		}
+		const size_t ob = w.narrow ? 4 : 8;
+		w.h_out.ensure(nk * ob);
+		BLMX_HIP(hipMemcpyAsync(w.h_out.p, w.narrow ? w.d_aux2.p : w.d_ids.p, nk * ob, hipMemcpyDeviceToHost, w.s));
 		BLMX_HIP(hipMemcpyAsync(w.h_flags.p, w.d_flags.p, 4, hipMemcpyDeviceToHost, w.s));
 		BLMX_HIP(hipEventRecord(w.done, w.s));
 		w.in_flight = true;
 		w.nk = nk;
 		w.out_index = nk0;
 	}
-	finish(hf.win[0]);
-	finish(hf.win[1]);
+	for (int i = 0; i < kWindowSlots; i++) {  // oldest first
+		finish(hf.win[cur]);
+		cur = (cur + 1) % kWindowSlots;
+	}
 	ix.number_query.fetch_add(nk_all, std::memory_order_relaxed);
 }
 
@@ -479,13 +579,16 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 	}
 	// chunks through the two window slots: copy-in (host threads) | H2D | kernels | D2H | copy-out overlap
 	std::lock_guard<std::mutex> lock(ix.mu);
-	const uint64_t C = std::max<uint64_t>(1u << 16, window_positions(ix) / 2);  // k-mers per chunk
+	const uint64_t C = std::max<uint64_t>(1u << 16, window_positions(ix) / 4);  // k-mers per chunk
 	auto finish = [&](WindowSlot& w) {
 		if (!w.in_flight)
 			return;
 		BLMX_HIP(hipEventSynchronize(w.done));
 		w.in_flight = false;
-		parallel_copy(*hf.pool, (char*)out + w.out_index * w.out_elem, w.h_out.p, w.nk * w.out_elem);
+		if (w.narrow)
+			widen_ids(*hf.pool, (int64_t*)out + w.out_index, w.h_out.as<uint32_t>(), w.nk);
+		else
+			parallel_copy(*hf.pool, (char*)out + w.out_index * w.out_elem, w.h_out.p, w.nk * w.out_elem);
 	};
 	struct Drain {
 		HostFront& hf;
@@ -499,14 +602,17 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 		}
 	} drain{hf};
 	int cur = 0;
+	Trace tr;
 	for (uint64_t a = 0; a < nq; a += C) {
 		const uint64_t n = std::min(C, nq - a);
 		WindowSlot& w = hf.win[cur];
-		cur ^= 1;
+		cur = (cur + 1) % kWindowSlots;
 		prepare_window_slot(w);
 		finish(w);
+		tr.lap("wait+copy out", a / C);
 		w.h_in.ensure(n * kb);
 		parallel_copy(*hf.pool, w.h_in.p, (const char*)kmers + a * kb, n * kb);
+		tr.lap("copy in", a / C);
 		grow(w.d_kmers, n * kb, w.s);
 		grow(w.d_ids, n * 8, w.s);
 		BLMX_HIP(hipMemcpyAsync(w.d_kmers.p, w.h_in.p, n * kb, hipMemcpyHostToDevice, w.s));
@@ -522,16 +628,25 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 			launch_query_ids_auto(ix, w.d_kmers.p, n, w.d_ids.as<int64_t>(), w.s);
 		else
 			launch_query(ix, w.d_kmers.p, d_minis, n, w.d_ids.p, mode, w.s);
-		w.h_out.ensure(n * ob);
-		BLMX_HIP(hipMemcpyAsync(w.h_out.p, w.d_ids.p, n * ob, hipMemcpyDeviceToHost, w.s));
+		w.narrow = mode == kQueryIds && ids_fit_32(ix);
+		if (w.narrow) {
+			grow(w.d_aux2, n * 4, w.s);
+			launch_narrow_ids(w.d_ids.as<int64_t>(), n, w.d_aux2.as<uint32_t>(), w.s);
+		}
+		const size_t wire = w.narrow ? 4 : ob;
+		w.h_out.ensure(n * wire);
+		BLMX_HIP(hipMemcpyAsync(w.h_out.p, w.narrow ? w.d_aux2.p : w.d_ids.p, n * wire, hipMemcpyDeviceToHost, w.s));
 		BLMX_HIP(hipEventRecord(w.done, w.s));
 		w.in_flight = true;
 		w.nk = n;
 		w.out_index = a;
 		w.out_elem = ob;
+		tr.lap("enqueue", a / C);
 	}
-	finish(hf.win[0]);
-	finish(hf.win[1]);
+	for (int i = 0; i < kWindowSlots; i++) {
+		finish(hf.win[cur]);
+		cur = (cur + 1) % kWindowSlots;
+	}
 	ix.number_query.fetch_add(nq, std::memory_order_relaxed);
 }
 
@@ -665,10 +780,10 @@ void stream_file(Index& ix, const char* path, int mode, Payload* payload, uint32
 		prepare_window_slot(w);
 	hipStream_t s0 = hf.win[0].s;
 	if (!hf.d_counts.p)
-		BLMX_HIP(hf.d_counts.alloc(16, false, s0));
+		BLMX_HIP(hf.d_counts.alloc(16 * kCountStripes, false, s0));
 	if (!hf.d_carry.p)
 		BLMX_HIP(hf.d_carry.alloc(32, false, s0));
-	BLMX_HIP(hipMemsetAsync(hf.d_counts.p, 0, 16, s0));
+	BLMX_HIP(hipMemsetAsync(hf.d_counts.p, 0, 16 * kCountStripes, s0));
 	BLMX_HIP(hipMemsetAsync(hf.d_carry.p, 0, 32, s0));
 	BLMX_HIP(hipStreamSynchronize(s0));
 	auto finish = [&](WindowSlot& w) {
@@ -693,10 +808,13 @@ void stream_file(Index& ix, const char* path, int mode, Payload* payload, uint32
 	const uint64_t W = window_positions(ix);
 	uint64_t queries = 0;
 	unsigned long long* d_counts = hf.d_counts.as<unsigned long long>();
+	Trace tr;
 	for (uint64_t i = 0;; i++) {
-		WindowSlot& w = hf.win[i & 1];
+		WindowSlot& w = hf.win[i % kWindowSlots];
 		finish(w);
+		tr.lap("wait slot", i);
 		const uint64_t nbytes = rf.next(w.h_in, W, *hf.pool);
+		tr.lap("read", i);
 		if (nbytes == 0)
 			break;
 		if (nbytes >= 0xffffffc0ull)
@@ -708,7 +826,9 @@ void stream_file(Index& ix, const char* path, int mode, Payload* payload, uint32
 		front_valid_raw(ix, w.fs, w.d_in.as<uint8_t>(), nbytes, mode, carry + 2 * (i & 1), carry + 2 * ((i + 1) & 1), nullptr, w.s);
 		const uint64_t nwords = (nbytes + 63) / 64;
 		BLMX_HIP(hipMemcpyAsync(w.h_flags.p, w.fs.vpre.as<uint32_t>() + nwords, 4, hipMemcpyDeviceToHost, w.s));
+		tr.lap("enqueue prep", i);
 		BLMX_HIP(hipStreamSynchronize(w.s));  // the number of k-mers sizes the rest of the window's work
+		tr.lap("sync prep", i);
 		const uint64_t nk = w.h_flags.as<uint32_t>()[0];
 		if (nk) {
 			query_window(ix, w, nbytes, nbytes, nk, payload != nullptr, d_counts);
@@ -719,13 +839,17 @@ void stream_file(Index& ix, const char* path, int mode, Payload* payload, uint32
 		BLMX_HIP(hipEventRecord(w.done, w.s));
 		w.in_flight = true;
 		queries += nk;
+		tr.lap("enqueue query", i);
 	}
-	finish(hf.win[0]);
-	finish(hf.win[1]);
-	uint64_t h_counts[2] = {0, 0};
-	BLMX_HIP(hipMemcpy(h_counts, hf.d_counts.p, 16, hipMemcpyDeviceToHost));
-	good = h_counts[0];
-	erroneous = h_counts[1];
+	for (auto& w : hf.win)
+		finish(w);
+	uint64_t h_counts[2 * kCountStripes];
+	BLMX_HIP(hipMemcpy(h_counts, hf.d_counts.p, sizeof h_counts, hipMemcpyDeviceToHost));
+	good = erroneous = 0;
+	for (int i = 0; i < kCountStripes; i++) {
+		good += h_counts[2 * i];
+		erroneous += h_counts[2 * i + 1];
+	}
 	ix.number_query.fetch_add(queries, std::memory_order_relaxed);
 }
 

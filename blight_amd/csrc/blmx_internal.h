@@ -245,6 +245,7 @@ struct Index {
 	int tune_mini_handoff = -1;  // partition pass hands the minimizers to the query kernel: 1 / 0 / -1 = automatic
 	int tune_query_heads = 1;    // 0 = query kernels read the full group descriptor instead of the compact 32-B head
 	int tune_reads_mode = 0;     // sequence / file queries: 0 = automatic, 1 = always fused front end + query, 2 = always front end -> binned pipeline
+	int tune_narrow_ids = 1;     // host-buffer results cross PCIe as 32-bit words when every ID fits (0 = always 64-bit)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
 
 	Index()
@@ -329,7 +330,10 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode);
 void query_sequences_device(Index& ix, const uint8_t* d_chars, const uint64_t* d_offs, uint64_t nseq, uint64_t total, uint64_t nk, int64_t* d_ids,
                             int* d_err, hipStream_t s);
+// found / not-found counters are kCountStripes (found, not found) pairs that the caller sums (one hot counter serialises)
+constexpr int kCountStripes = 64;
 void launch_count_found(const int64_t* d_ids, uint64_t n, unsigned long long* d_counts, hipStream_t s);
+void launch_narrow_ids(const int64_t* d_ids, uint64_t n, uint32_t* d_out, hipStream_t s);
 void launch_kmers_at(const Index& ix, const uint8_t* d_ascii, const uint64_t* d_pos, uint64_t nq, void* d_out, int* d_err, hipStream_t s);
 void launch_canonicalize(const Index& ix, void* d_kmers, uint64_t nq, hipStream_t s);
 void launch_route_count(const Index& ix, const void* d_kmers, uint64_t nq, const uint32_t* d_bounds, uint32_t world, uint8_t* d_dest,

@@ -6,9 +6,8 @@
 //
 // Here a workgroup owns 512 consecutive character positions of a window that is resident in HBM (or in pinned host
 // memory for a single short read) and works on them cooperatively:
-//   * every lane reads ONE character; three wave ballots give the two code bit-planes and the invalid-character mask of 64
-//     positions, the 2-bit packed words are interleaved from the ballots on the scalar unit and kept in LDS
-//     (nuc2int / str2num, kmer.h:56-98);
+//   * a lane encodes FOUR characters (one dword load) into one byte of the 2-bit packed words that the block keeps in LDS
+//     (nuc2int / str2num, kmer.h:56-98); invalid characters set bits of an LDS bitmap;
 //   * every lane hashes ONE m-mer (ParityCanonical kmer.h:475-487, signed revhash kmer.h:102-108) and the minimum over the
 //     w = k-m+1 m-mers of each k-mer is assembled from power-of-two prefix minima in ceil(log2 w)+1 LDS rounds -- the data
 //     parallel form of the chopper's monotone deque (SuperKChopper::update_mini, kmer.h:734-781); consecutive k-mers
@@ -36,22 +35,6 @@ constexpr int kFrontBlock = 512;  // positions per workgroup (8 waves)
 constexpr int kFrontHalo = 64;    // k - 1 <= 62 trailing characters / w - 1 <= 62 trailing m-mers
 constexpr int kFrontWords = (kFrontBlock + 2 * kFrontHalo) / 32 + 2;
 
-// bit i of x -> bit 2i (32 -> 64 bits)
-__device__ __forceinline__ uint64_t spread_bits(uint64_t x)
-{
-	x = (x | (x << 16)) & 0x0000ffff0000ffffull;
-	x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
-	x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
-	x = (x | (x << 2)) & 0x3333333333333333ull;
-	x = (x | (x << 1)) & 0x5555555555555555ull;
-	return x;
-}
-// 32 lanes' code bit-planes (lane j = bit j) -> packed word, nucleotide j in bits 63-2j .. 62-2j
-__device__ __forceinline__ uint64_t pack_planes(uint32_t b1, uint32_t b0)
-{
-	return (spread_bits((uint64_t)__brev(b1)) << 1) | spread_bits((uint64_t)__brev(b0));
-}
-
 template <int KW> struct FrontLane {
 	Kmer<KW> x, xr;  // canonical k-mer and its reverse complement (x <= xr)
 	uint32_t mini;
@@ -67,34 +50,35 @@ __device__ __forceinline__ void front_block(const uint8_t* __restrict__ bytes, u
 	__shared__ uint64_t s_bad[kFrontWords / 2 + 2];
 	__shared__ int32_t s_pow[2][kFrontBlock + kFrontHalo + 2];
 	const int tid = (int)threadIdx.x;
-	const uint32_t lane = (uint32_t)tid & 63u;
 	const int w = k - m + 1;
-	// ---- characters -> 2-bit words + invalid-character bitmap, 64 positions per wave and round
-	const int need = kFrontBlock + k - 1;          // characters that the block's k-mers cover
-	const int rounds = (need + 63) / 64;           // 64-character groups; group g is handled by wave g % 8
-	for (int g = tid >> 6; g < rounds + 1; g += kFrontBlock / 64) {  // group `rounds` = zero words behind the last group (funnel shifts read them)
-		uint64_t w0 = 0, w1 = 0, bd = 0;
-		if (g < rounds) {
-			const uint64_t p = base + (uint64_t)g * 64 + lane;
-			uint32_t c = 0;
-			bool isbad = false;
-			if (p < total) {
-				c = nuc_code(bytes[p]);
-				isbad = c > 3;
-			}
-			const uint64_t b0 = __ballot(c & 1u), b1 = __ballot(c & 2u);
-			bd = __ballot(isbad);
-			w0 = pack_planes((uint32_t)b1, (uint32_t)b0);
-			w1 = pack_planes((uint32_t)(b1 >> 32), (uint32_t)(b0 >> 32));
+	// ---- characters -> 2-bit words + invalid-character bitmap: a lane encodes FOUR characters (one dword load) into one byte
+	// of the packed words in LDS (nucleotide j of a word in bits 63-2j .. 62-2j: byte 7 - (j / 4) of the little-endian word).
+	// (Assembling the words from wave ballots on the scalar unit was measured first: ~60 scalar instructions per 64 characters
+	// made the kernel scalar-issue bound.)
+	const int need = kFrontBlock + k - 1;  // characters that the block's k-mers cover
+	const int nquads = (need + 3) / 4;
+	uint8_t* s_src8 = reinterpret_cast<uint8_t*>(s_src);
+	if (tid < (int)(sizeof(s_bad) / 8))
+		s_bad[tid] = 0;
+	for (int q = nquads + tid; q < kFrontWords * 8; q += kFrontBlock)  // bytes behind the last character (funnel shifts read them)
+		s_src8[(q & ~7) | (7 - (q & 7))] = 0;
+	__syncthreads();
+	if (tid < nquads) {
+		const uint64_t p = base + 4 * (uint64_t)tid;
+		uint32_t v = 0x41414141u;  // 'A': positions at or beyond `total`
+		if (p + 4 <= total) {
+			v = *reinterpret_cast<const uint32_t*>(bytes + p);
+		} else {
+			for (int j = 0; j < 4; j++)
+				if (p + j < total)
+					v = (v & ~(0xffu << (8 * j))) | ((uint32_t)bytes[p + j] << (8 * j));
 		}
-		if (lane == 0) {
-			s_src[2 * g] = w0;
-			s_src[2 * g + 1] = w1;
-			s_bad[g] = bd;
-		}
+		const uint32_t c0 = nuc_code((uint8_t)v), c1 = nuc_code((uint8_t)(v >> 8)), c2 = nuc_code((uint8_t)(v >> 16)), c3 = nuc_code((uint8_t)(v >> 24));
+		s_src8[((tid >> 3) << 3) | (7 - (tid & 7))] = (uint8_t)(((c0 & 3u) << 6) | ((c1 & 3u) << 4) | ((c2 & 3u) << 2) | (c3 & 3u));
+		const uint32_t bad4 = (c0 > 3 ? 1u : 0u) | (c1 > 3 ? 2u : 0u) | (c2 > 3 ? 4u : 0u) | (c3 > 3 ? 8u : 0u);
+		if (bad4)  // rare: the bitmap starts zeroed
+			atomicOr(reinterpret_cast<unsigned long long*>(&s_bad[tid >> 4]), (unsigned long long)bad4 << (4 * (tid & 15)));
 	}
-	if (tid == 0)
-		s_bad[rounds + 1] = 0;
 	__syncthreads();
 	// ---- one m-mer hash per position (entries e = 0 .. kFrontBlock + w - 2)
 	for (int e = tid; e < kFrontBlock + w - 1; e += kFrontBlock) {
@@ -221,7 +205,7 @@ __global__ __launch_bounds__(kFrontBlock) void k_read_front(const uint8_t* __res
 }
 
 // front end + query body in one launch, IDs in position order (query_sequence_hash, blight.cpp:575-591).
-// counts (may be null): [0] += k-mers found, [1] += k-mers not found (query_sequence_bool, blight.cpp:554-571).
+// counts (may be null): kCountStripes pairs (found, not found); a block adds to ONE pair (query_sequence_bool, blight.cpp:554-571).
 template <int KW, int LOGP>
 __global__ __launch_bounds__(kFrontBlock) void k_read_query(DeviceIndexView v, const uint8_t* __restrict__ bytes, uint64_t total, FrontWhere fw,
                                                             int64_t* __restrict__ ids, unsigned long long* __restrict__ counts,
@@ -244,12 +228,24 @@ __global__ __launch_bounds__(kFrontBlock) void k_read_query(DeviceIndexView v, c
 			ids[o] = id;
 	}
 	if (counts) {
+		__shared__ unsigned int s_found, s_absent;
+		if (threadIdx.x == 0)
+			s_found = s_absent = 0;
+		__syncthreads();
 		const unsigned long long bv = __ballot(valid), bf = __ballot(valid && id >= 0);
 		if ((threadIdx.x & 63) == 0) {
 			if (bf)
-				atomicAdd(&counts[0], (unsigned long long)__popcll(bf));
+				atomicAdd(&s_found, (unsigned int)__popcll(bf));
 			if (bv != bf)
-				atomicAdd(&counts[1], (unsigned long long)(__popcll(bv) - __popcll(bf)));
+				atomicAdd(&s_absent, (unsigned int)(__popcll(bv) - __popcll(bf)));
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const unsigned stripe = blockIdx.x % kCountStripes;
+			if (s_found)
+				atomicAdd(&counts[2 * stripe], (unsigned long long)s_found);
+			if (s_absent)
+				atomicAdd(&counts[2 * stripe + 1], (unsigned long long)s_absent);
 		}
 	}
 }
@@ -286,12 +282,33 @@ __global__ __launch_bounds__(256) void k_valid_from_starts(const unsigned long l
 }
 
 // ---- raw FASTA bytes: newline bitmap, line table, record rule, VALID ----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_raw_newlines(const uint8_t* __restrict__ bytes, uint64_t total, unsigned long long* __restrict__ nl)
+// exact per-byte test "byte == c" of the four bytes of x -> bits 0..3
+__device__ __forceinline__ uint32_t bytes_equal_mask(uint32_t x, uint32_t c4)
 {
-	const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const unsigned long long bal = __ballot(q < total && bytes[q] == (uint8_t)'\n');
-	if ((threadIdx.x & 63) == 0)
-		nl[q >> 6] = bal;
+	const uint32_t t = x ^ c4;
+	const uint32_t z = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);  // 0x80 in every byte of t that is zero
+	return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+}
+
+// one lane per 16 bytes (one dwordx4 load), four lanes assemble one 64-position word of the bitmap
+__global__ __launch_bounds__(256) void k_raw_newlines(const uint8_t* __restrict__ bytes, uint64_t total, uint64_t nwords,
+                                                      unsigned long long* __restrict__ nl)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t p = i * 16;
+	uint32_t m = 0;
+	if (p + 16 <= total && (reinterpret_cast<uintptr_t>(bytes) & 15) == 0) {
+		const uint4 v = *reinterpret_cast<const uint4*>(bytes + p);
+		const uint32_t c4 = 0x0a0a0a0au;
+		m = bytes_equal_mask(v.x, c4) | (bytes_equal_mask(v.y, c4) << 4) | (bytes_equal_mask(v.z, c4) << 8) | (bytes_equal_mask(v.w, c4) << 12);
+	} else {
+		for (int j = 0; j < 16; j++)
+			if (p + j < total && bytes[p + j] == (uint8_t)'\n')
+				m |= 1u << j;
+	}
+	const uint32_t m1 = __shfl_down(m, 1), m2 = __shfl_down(m, 2), m3 = __shfl_down(m, 3);
+	if ((threadIdx.x & 3) == 0 && (i >> 2) < nwords)
+		nl[i >> 2] = (unsigned long long)m | ((unsigned long long)m1 << 16) | ((unsigned long long)m2 << 32) | ((unsigned long long)m3 << 48);
 }
 
 // nlpos[j] = position of the j-th newline of the window; nlpos[number of newlines] = total (end of the unterminated last line)
@@ -438,7 +455,7 @@ void front_valid_raw(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, 
 	ensure_scratch(fs.ok, nbytes + 2, s);
 	BLMX_HIP(hipMemsetAsync((char*)fs.marks.p + nwords * 8, 0, 16, s));
 	BLMX_HIP(hipMemsetAsync((char*)fs.valid.p + nwords * 8, 0, kBitmapPad * 8, s));
-	hipLaunchKernelGGL(k_raw_newlines, dim3(grid_for(nwords * 64, 256)), dim3(256), 0, s, d_bytes, nbytes, fs.marks.as<unsigned long long>());
+	hipLaunchKernelGGL(k_raw_newlines, dim3(grid_for(nwords * 4, 256)), dim3(256), 0, s, d_bytes, nbytes, nwords, fs.marks.as<unsigned long long>());
 	BLMX_HIP(hipGetLastError());
 	popcount_prefix(fs, fs.marks.as<unsigned long long>(), nwords, fs.mpre.as<uint32_t>(), s);
 	hipLaunchKernelGGL(k_line_table, dim3(grid_for(nwords + 1, 256)), dim3(256), 0, s, fs.marks.as<unsigned long long>(), fs.mpre.as<uint32_t>(), nwords,

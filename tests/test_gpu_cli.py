@@ -42,3 +42,45 @@ def test_bench_blight_cli_dump_then_load(tmp_path):
     wrong = subprocess.run([exe, "-q", G.LAMBDA, "-l", img, "-k", "31", "-m", "7", "-n", "6", "-s", "3", "-b", "6"],
                            capture_output=True, text=True, timeout=60)
     assert wrong.returncode != 0 and "differ" in wrong.stderr
+
+
+def test_per_read_calls_from_openmp_threads(tmp_path):
+    """tools/bench_reads: one kmer_Set_Light::query_sequence_hash call per read from 8 OpenMP threads through the C++ facade --
+    the calling pattern of the reference's applications (Colored_De_Bruijn_graph_snippet.cpp:122-157) -- against the oracle:
+    found / absent counts, an order-independent checksum over (read, k-mer, ID), and the atomic number_query counter."""
+    import json
+
+    import numpy as np
+    from oracle import oracle as O
+    exe = os.path.join(ROOT, "tools", "bench_reads")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "bench_reads"])
+    c = G.Case("lambda_k31_m7_n5_b6")
+    rng = np.random.default_rng(11)
+    genome = c.seqs[3]
+    reads = []
+    for i in range(4000):
+        if i % 3 == 2:
+            reads.append("".join("ACGT"[j] for j in rng.integers(0, 4, 150)))
+        else:
+            a = int(rng.integers(0, len(genome) - 150))
+            reads.append(genome[a:a + int(rng.integers(31, 150))])
+    reads.append("ACGT")  # shorter than k: a call that returns nothing
+    rf = tmp_path / "reads.txt"
+    rf.write_text("\n".join(reads) + "\n")
+    orc = O.Oracle(c.k, c.m, c.n, c.b, c.seqs)
+    found = absent = checksum = kmers = 0
+    for i, r in enumerate(reads):
+        ids = orc.query_sequence(r) if len(r) >= c.k else np.zeros(0, np.int64)
+        kmers += ids.size
+        found += int((ids >= 0).sum())
+        absent += int((ids < 0).sum())
+        for j, v in enumerate(ids.tolist()):
+            checksum = (checksum + (i * 1000003 + j + 1) * ((v + 2) % (1 << 64))) % (1 << 64)
+    for threads in ("8", "1"):
+        out = subprocess.run([exe, "-g", G.LAMBDA, "-q", str(rf), "-k", "31", "-m", "7", "-n", "5", "-s", "3", "-b", "6", "-t", threads],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert (res["reads"], res["kmers"], res["found"], res["absent"], res["checksum"]) == (len(reads), kmers, found, absent, checksum)
+        assert res["number_query"] == kmers + max(0, len(reads[0]) - 31 + 1)  # + the warm-up call

@@ -90,6 +90,7 @@ def test_sequence_queries_every_path(B, O, k, m, n, b, kb):
         for wkb in (0, 64, 1):
             ix.set_tuning("reads_mode", mode)
             ix.set_tuning("window_kb", wkb)
+            ix.set_tuning("narrow_ids", 0 if (mode, wkb) == (1, 64) else 1)
             got = ix.query_sequences_hash(many)
             assert np.array_equal(got, want), (mode, wkb)
     ix.set_tuning("reads_mode", 0)
@@ -271,8 +272,9 @@ def test_host_batches_in_chunks(B, O, k, kb, b):
     want = orc.query_kmers(q.reshape(-1) if kb == 8 else q)
     ix.set_tuning("window_kb", 128)  # 2^16 k-mers per chunk
     assert len(q) > 5 * (1 << 16)
-    for binning in (-1, 1):
+    for binning, narrow in ((-1, 1), (1, 1), (1, 0)):
         ix.set_query_binning(binning)
+        ix.set_tuning("narrow_ids", narrow)  # IDs cross PCIe as 32-bit words (widened on the host) or as 64-bit words
         assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want)
     assert np.array_equal(ix.query_kmer_bool(q.reshape(-1)), want >= 0)
     # caller-supplied minimizers: the right ones for the first 20000 k-mers, then the same values tiled (mostly wrong: defined too)
