@@ -153,6 +153,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.tune_mini_handoff = env_int("BLIGHT_MINI_HANDOFF", -1);
 	h->ix.tune_query_heads = env_int("BLIGHT_QUERY_HEADS", 1);
 	h->ix.tune_reads_mode = env_int("BLIGHT_READS_MODE", 0);
+	h->ix.tune_partition = env_int("BLIGHT_PARTITION", 0);
 	h->ix.tune_window_kb = env_int("BLIGHT_WINDOW_KB", 0);
 	if (hipSetDevice(prm.device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
 		g_create_err = "hipStreamCreate failed";
@@ -569,6 +570,10 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_query_heads = value;
 	else if (k == "reads_mode")
 		ix.tune_reads_mode = value;
+	else if (k == "partition")
+		ix.tune_partition = value;
+	else if (k == "slot_slack_pct")
+		ix.tune_slot_slack_pct = value;
 	else if (k == "narrow_ids")
 		ix.tune_narrow_ids = value;
 	else if (k == "window_kb")

@@ -245,6 +245,8 @@ struct Index {
 	int tune_mini_handoff = -1;  // partition pass hands the minimizers to the query kernel: 1 / 0 / -1 = automatic
 	int tune_query_heads = 1;    // 0 = query kernels read the full group descriptor instead of the compact 32-B head
 	int tune_reads_mode = 0;     // sequence / file queries: 0 = automatic, 1 = always fused front end + query, 2 = always front end -> binned pipeline
+	int tune_partition = 0;      // batch partition: 0 / 2 = exact (histogram, scan, scatter), 1 = one pass into fixed-capacity bins
+	int tune_slot_slack_pct = 0; // one-pass partition: slots per bin = mean occupancy + this many percent (0 = default 12)
 	int tune_narrow_ids = 1;     // host-buffer results cross PCIe as 32-bit words when every ID fits (0 = always 64-bit)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
 

@@ -5,12 +5,14 @@
 //   (bbhash.h:561-577, 617-663; one 16-B line [u32 rank | 96 level bits] per probed level) -> position field
 //   (blight.cpp:473-482) -> 2^b window of the packed sequence (blight.cpp:729-739) compared in registers.
 // The path is a chain of ~5 dependent random accesses per k-mer (query_device.h): latency / line-rate bound, no MFMA.
+#include <cstdio>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "blmx_internal.h"
@@ -503,6 +505,168 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 	}
 }
 
+// ---- one-pass partition into fixed-capacity bins ----------------------------------------------------------------------------
+// The exact partition above costs two passes over the batch (histogram, scan, scatter) because every (tile, bin) run needs its
+// final offset before anything is written.  A batch that is only going to be QUERIED does not need a dense order: bin b owns the
+// slots [b * cap, (b + 1) * cap) (cap = mean occupancy + slack, a multiple of the query block), a tile reserves the slot range
+// of each of its runs with ONE global atomic per (tile, bin) on the bin's cursor, and whatever does not fit a bin goes to an
+// overflow region behind the bins (reserved with one more atomic per overflowing run).  One kernel computes the minimizers,
+// sorts the tile in LDS and writes the runs; the query kernel walks the slots and skips the unused tail of every bin.
+// Skewed batches (all k-mers in a few bins) only lose locality for the overflowing part; results never depend on the layout.
+// MEASURED (C4, 1e8 random / indexed 31-mers): the pass itself takes 1.41 ms instead of 0.87 + 0.04 + 0.88 ms, but minimizer-prefix
+// bins are far from equally loaded (99 k .. 328 k k-mers around a mean of 195 k; 54 k .. 399 k for 63-mers), so with one capacity
+// for every bin 4-8 % of the batch overflows and the slot walk of the query kernel is 0.3 ms (k = 63: 0.9 ms) slower than on
+// the dense order: 7.28 vs 7.31 ms per step -- no gain without per-bin capacities learnt from earlier batches.  The exact
+// partition stays the default; this path is selected with blmx_set_tuning("partition", 1).
+struct SlotPlan {
+	uint32_t nbins, cap;     // slots per bin (multiple of 256)
+	uint32_t ovf_cap;        // slots of the overflow region
+	uint32_t main_blocks;    // nbins * cap / 256, a multiple of 8
+	uint32_t ovf_blocks;     // looping blocks that answer the overflow region
+	__host__ __device__ uint64_t ovf_base() const { return (uint64_t)nbins * cap; }
+	__host__ __device__ uint64_t total_slots() const { return (uint64_t)nbins * cap + ovf_cap; }
+};
+
+template <int KW>
+__global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, SlotPlan sp, const uint64_t* __restrict__ kmers,
+                                                             const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
+                                                             uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint32_t* __restrict__ inv)
+{
+	constexpr int kTile = BinTile<KW>::value;
+	constexpr int kPer = kTile / kBinThreads;
+	constexpr int kNB = 1 << kBinBitsMax;
+	__shared__ uint64_t s_keys[kTile * KW];
+	__shared__ uint32_t s_mini[kTile];
+	__shared__ uint32_t s_cnt[kNB];     // k-mers of this tile per bin, then the tile-local start of the bin
+	__shared__ uint32_t s_gbase[kNB];   // first slot (inside the bin) of this tile's run
+	__shared__ uint32_t s_obase[kNB];   // first overflow slot of the part of the run that does not fit the bin
+	__shared__ uint32_t s_wsum[kBinThreads / 64];
+	static_assert(kBinThreads == kNB, "one bin per thread");
+	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	s_cnt[t] = 0;
+	__syncthreads();
+	const uint64_t base = (uint64_t)blockIdx.x * kTile;
+	Kmer<KW> x[kPer];
+	uint32_t mini[kPer], rank[kPer];
+#pragma unroll
+	for (int e = 0; e < kPer; e++) {
+		const uint64_t i = base + (uint64_t)e * kBinThreads + t;
+		mini[e] = 0;
+		rank[e] = 0;
+		if (i < nq) {
+			x[e] = load_kmer<KW>(kmers, i);
+			mini[e] = minis_in ? minis_in[i] : kmer_minimizer<KW>(x[e], kmer_rc<KW>(x[e], k), k, m);
+			rank[e] = atomicAdd(&s_cnt[bm.bin_of(mini[e])], 1u);
+		}
+	}
+	__syncthreads();
+	// one thread per bin: tile-local exclusive scan of the counts, slot reservation in the bin and in the overflow region
+	{
+		const uint32_t c = s_cnt[t];
+		uint32_t v = c;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t u = __shfl_up(v, o);
+			if ((int)lane >= o)
+				v += u;
+		}
+		if (lane == 63)
+			s_wsum[wave] = v;
+		uint32_t g = 0, ob = 0;
+		if (c) {
+			g = atomicAdd(&cursors[t], c);
+			const uint32_t over = g + c > sp.cap ? g + c - max(g, sp.cap) : 0u;
+			if (over)
+				ob = atomicAdd(&cursors[sp.nbins], over);
+		}
+		s_gbase[t] = g;
+		s_obase[t] = ob;
+		__syncthreads();
+		uint32_t wbase = 0;
+		for (uint32_t w = 0; w < wave; w++)
+			wbase += s_wsum[w];
+		s_cnt[t] = wbase + v - c;  // tile-local start of bin t
+	}
+	__syncthreads();
+	const uint64_t ovf_base = sp.ovf_base();
+	auto slot_of = [&](uint32_t b, uint32_t r) -> uint64_t {  // r-th k-mer of this tile's run of bin b
+		const uint32_t g = s_gbase[b], gs = g + r;
+		return gs < sp.cap ? (uint64_t)b * sp.cap + gs : ovf_base + s_obase[b] + (gs - max(g, sp.cap));
+	};
+#pragma unroll
+	for (int e = 0; e < kPer; e++) {
+		const uint64_t i = base + (uint64_t)e * kBinThreads + t;
+		if (i < nq) {
+			const uint32_t b = bm.bin_of(mini[e]);
+			const uint32_t ls = s_cnt[b] + rank[e];
+			if constexpr (KW == 1) {
+				s_keys[ls] = x[e].lo;
+			} else {
+				s_keys[2 * ls] = x[e].lo;
+				s_keys[2 * ls + 1] = x[e].hi;
+			}
+			s_mini[ls] = mini[e];
+			const uint64_t dst = slot_of(b, rank[e]);
+			inv[i] = dst < sp.total_slots() ? (uint32_t)dst : 0xffffffffu;
+		}
+	}
+	__syncthreads();
+	const uint32_t count = (uint32_t)min((uint64_t)kTile, nq - base);
+	for (uint32_t sidx = t; sidx < count; sidx += kBinThreads) {
+		const uint32_t mi = s_mini[sidx];
+		const uint32_t b = bm.bin_of(mi);
+		const uint64_t dst = slot_of(b, sidx - s_cnt[b]);
+		if (dst >= sp.total_slots())
+			continue;  // cannot happen: the overflow region holds a whole batch
+		if (slot_minis)
+			slot_minis[dst] = mi;
+		if constexpr (KW == 1) {
+			slots[dst] = s_keys[sidx];
+		} else {
+			slots[2 * dst] = s_keys[2 * sidx];
+			slots[2 * dst + 1] = s_keys[2 * sidx + 1];
+		}
+	}
+}
+
+// The query kernel over slots: blocks [0, main_blocks) answer 256 slots of a bin each (XCD-major like k_query), the blocks
+// behind them loop over the overflow region.  IDs go to ids[slot].
+template <int KW, int LOGP>
+__device__ __forceinline__ void query_slot(const DeviceIndexView& v, const uint64_t* __restrict__ slots, const uint32_t* __restrict__ slot_minis,
+                                           int64_t* __restrict__ ids, uint64_t slot)
+{
+	const Kmer<KW> x = load_kmer<KW>(slots, slot);
+	const Kmer<KW> xr = kmer_rc<KW>(x, v.k);
+	const uint32_t mini = slot_minis ? slot_minis[slot] : kmer_minimizer<KW>(x, xr, v.k, v.m);
+	int64_t id;
+	int32_t posj;
+	query_one<KW, LOGP, false>(v, x, xr, mini, id, posj);
+	ids[slot] = id;
+}
+template <int KW, int LOGP>
+__global__ __launch_bounds__(256) void k_query_slots(DeviceIndexView v, SlotPlan sp, const uint32_t* __restrict__ cursors, const uint64_t* __restrict__ slots,
+                                                     const uint32_t* __restrict__ slot_minis, int64_t* __restrict__ ids)
+{
+	const uint32_t blk = (blockIdx.x & 7u) * (sp.main_blocks >> 3) + (blockIdx.x >> 3);
+	const uint32_t per_bin = sp.cap >> 8, b = blk / per_bin;
+	const uint32_t used = min(cursors[b], sp.cap);
+	const uint64_t slot = (uint64_t)blk * 256 + threadIdx.x;
+	if (slot < (uint64_t)b * sp.cap + used)
+		query_slot<KW, LOGP>(v, slots, slot_minis, ids, slot);
+}
+
+// The overflow region (usually empty) in its own launch: a fixed number of blocks loop over it.  (Looping blocks inside
+// k_query_slots made the register allocator keep 256 VGPRs for 128-bit k-mers, a call 70-98: the common path stays loop-free.)
+template <int KW, int LOGP>
+__global__ __launch_bounds__(256) void k_query_slots_overflow(DeviceIndexView v, SlotPlan sp, const uint32_t* __restrict__ cursors,
+                                                              const uint64_t* __restrict__ slots, const uint32_t* __restrict__ slot_minis,
+                                                              int64_t* __restrict__ ids)
+{
+	const uint64_t end = sp.ovf_base() + min(cursors[sp.nbins], sp.ovf_cap);
+#pragma nounroll
+	for (uint64_t slot = sp.ovf_base() + (uint64_t)blockIdx.x * 256 + threadIdx.x; slot < end; slot += (uint64_t)sp.ovf_blocks * 256)
+		query_slot<KW, LOGP>(v, slots, slot_minis, ids, slot);
+}
+
 // out[i] = ids_sorted[inv[i]].  One block per partition TILE: the (tile, bin) runs written by k_bin_scatter are consumed by
 // the block that covers the same tile, so each 64-B line of ids_sorted is fetched once by one CU instead of by many.
 template <int TILE>
@@ -643,6 +807,98 @@ bool query_batch_worth_binning(const Index& ix, uint64_t nq)
 	return nq >= (1ull << 20) && ix.st.device_bytes >= (64ull << 20) && mbits >= 4;
 }
 
+template <int KW>
+static void launch_query_slots_kw(const Index& ix, const SlotPlan& sp, const uint32_t* d_cursors, const void* d_slots, const uint32_t* d_slot_minis,
+                                  int64_t* d_ids, hipStream_t s)
+{
+	const DeviceIndexView v = ix.view();
+	const uint64_t* sl = reinterpret_cast<const uint64_t*>(d_slots);
+#define BLMX_QS(LP)                                                                                                                                    \
+	case LP:                                                                                                                                           \
+		hipLaunchKernelGGL((k_query_slots<KW, LP>), dim3(sp.main_blocks), dim3(256), 0, s, v, sp, d_cursors, sl, d_slot_minis, d_ids);                 \
+		hipLaunchKernelGGL((k_query_slots_overflow<KW, LP>), dim3(sp.ovf_blocks), dim3(256), 0, s, v, sp, d_cursors, sl, d_slot_minis, d_ids);        \
+		break;
+	switch (v.b) {
+		BLMX_QS(0)
+		BLMX_QS(1)
+		BLMX_QS(2)
+		BLMX_QS(3)
+		BLMX_QS(4)
+		BLMX_QS(5)
+		BLMX_QS(6)
+		BLMX_QS(7)
+		BLMX_QS(8)
+	default:
+		throw StatusError{BLMX_EINVAL, "internal: the slot pipeline needs bits_to_save <= 8"};
+	}
+#undef BLMX_QS
+}
+
+// partition into fixed-capacity bins (one pass) -> query the slots -> gather the IDs into the caller's order
+static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, bool handoff, hipStream_t s)
+{
+	const int mbits = 2 * (int)ix.prm.m - 1;
+	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsDefault;
+	const int tbits = std::max(3, std::min(mbits, want_bits));  // main_blocks must be a multiple of 8
+	BinMap bm;
+	bm.shift = mbits - tbits;
+	bm.nbound = 0;
+	SlotPlan sp;
+	sp.nbins = 1u << tbits;
+	const uint64_t mean = (nq + sp.nbins - 1) / sp.nbins;
+	const uint64_t pct = ix.tune_slot_slack_pct > 0 ? (uint64_t)ix.tune_slot_slack_pct : 12;
+	const uint64_t slack = std::max<uint64_t>(mean * pct / 100, (uint64_t)(6.0 * std::sqrt((double)mean)) + 64);
+	sp.cap = (uint32_t)(((mean + slack + 255) / 256) * 256);
+	sp.ovf_cap = (uint32_t)nq;
+	sp.main_blocks = sp.nbins * (sp.cap >> 8);
+	sp.ovf_blocks = 1024;
+	const uint64_t slots = sp.total_slots();
+	if (slots >= 0xffffffffull)
+		throw StatusError{BLMX_ELIMIT, "a partitioned batch holds fewer than 2^31 k-mers"};
+	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
+	const uint32_t nblk = (uint32_t)((nq + tile - 1) / tile);
+	ensure_buf(ix.b_sorted, slots * 8 * (size_t)ix.KW, s);
+	ensure_buf(ix.b_inv, nq * 4, s);
+	ensure_buf(ix.b_ids, slots * 8, s);
+	ensure_buf(ix.b_offs, ((size_t)sp.nbins + 1) * 4, s);
+	if (handoff)
+		ensure_buf(ix.b_minis, slots * 4, s);
+	uint32_t* d_slot_minis = handoff ? ix.b_minis.as<uint32_t>() : nullptr;
+	uint32_t* d_cursors = ix.b_offs.as<uint32_t>();
+	BLMX_HIP(hipMemsetAsync(d_cursors, 0, ((size_t)sp.nbins + 1) * 4, s));
+	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	ix.prof_mark(2, s);
+	ix.prof_mark(3, s);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp, km, d_minis, nq, d_cursors,
+		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, ix.b_inv.as<uint32_t>());
+	else
+		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp, km, d_minis, nq, d_cursors,
+		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, ix.b_inv.as<uint32_t>());
+	BLMX_HIP(hipGetLastError());
+	ix.prof_mark(4, s);
+	if (ix.KW == 1)
+		launch_query_slots_kw<1>(ix, sp, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.as<int64_t>(), s);
+	else
+		launch_query_slots_kw<2>(ix, sp, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.as<int64_t>(), s);
+	BLMX_HIP(hipGetLastError());
+	ix.prof_mark(5, s);
+	gather_ids(ix, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out, s);
+	ix.prof_mark(6, s);
+	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 2) {  // bin occupancy of this batch (synchronises)
+		std::vector<uint32_t> h(sp.nbins + 1);
+		BLMX_HIP(hipMemcpyAsync(h.data(), d_cursors, h.size() * 4, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+		uint32_t mx = 0, mn = ~0u;
+		for (uint32_t b2 = 0; b2 < sp.nbins; b2++) {
+			mx = std::max(mx, h[b2]);
+			mn = std::min(mn, h[b2]);
+		}
+		fprintf(stderr, "[blmx partition] nq %llu bins %u cap %u mean %llu min %u max %u overflow %u\n", (unsigned long long)nq, sp.nbins, sp.cap,
+		        (unsigned long long)mean, mn, mx, h[sp.nbins]);
+	}
+}
+
 // d_minis: minimizers of the k-mers when the caller already has them (read front end), else nullptr
 static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, hipStream_t s)
 {
@@ -664,6 +920,11 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	// hand the minimizers over to the query kernel?  Known minimizers always travel; computed ones only for 128-bit k-mers
 	// (55 m-mers hashed once instead of twice; for 64-bit k-mers the extra 8 B/query of traffic ate the gain) unless tuned.
 	const bool handoff = ix.tune_mini_handoff >= 0 ? ix.tune_mini_handoff != 0 : (d_minis != nullptr || ix.KW == 2);
+	if (ix.tune_partition == 1 && ix.prm.bits_saved <= 8 && nq < (1ull << 31) && 2 * (int)ix.prm.m - 1 >= 3) {
+		query_ids_onepass(ix, d_kmers, d_minis, nq, d_out, handoff, s);
+		partition_end(ix, s);
+		return;
+	}
 	if (handoff)
 		ensure_buf(ix.b_minis, nq * 4, s);
 	uint32_t* d_sorted_minis = handoff ? ix.b_minis.as<uint32_t>() : nullptr;

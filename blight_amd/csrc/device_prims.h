@@ -105,19 +105,77 @@ __device__ __forceinline__ uint32_t kmer_shr32(Kmer<2> x, int s)
 // kmer.h:791-810; ParityCanonical kmer.h:475-487).  The reverse-complement m-mers are read from the reverse-complement
 // k-mer (m-mer i of x pairs with m-mer k-m-i of rc(x)), so no per-window rcb is needed.  Ties imply equal values
 // (revhash is a bijection), so the scan order is irrelevant.
+//
+// Only the smallest hash is tracked (one v_min_i32 per m-mer); revhash is a bijection on 32 bits, so the m-mer it belongs to
+// is recovered once at the end with the inverse permutation instead of being carried through the loop.  The loop is fully
+// unrolled over the window index with a wave-uniform early exit: the k-mers live in 32-bit words, the reverse complement is
+// shifted ONCE so that its window for index i starts at the compile-time bit 2 (WMAX - 1 - i), and every window is then one
+// v_alignbit with immediate operands (the runtime-offset version paid 64-bit shifts -- and branches for 128-bit k-mers --
+// per window: 19 instructions per m-mer instead of 14; the minimizer is what bounds the partition pass).
 template <int KW> __device__ __forceinline__ uint32_t kmer_minimizer(Kmer<KW> x, Kmer<KW> xr, int k, int m)
 {
-	// Only the smallest hash is tracked (one v_min_i32 per m-mer); revhash is a bijection on 32 bits, so the m-mer it
-	// belongs to is recovered once at the end with the inverse permutation instead of being carried through the loop.
+	constexpr int NW = 2 * KW;     // 32-bit words of a k-mer
+	constexpr int WMAX = 32 * KW;  // k - m + 1 <= 32 KW windows
 	const uint32_t mask = (m >= 16) ? 0xffffffffu : ((1u << (2 * m)) - 1u);
-	const uint32_t cmask = mask >> 1;
-	const int w = k - m;
-	int32_t best_h = 0x7fffffff;
-	for (int i = 0; i <= w; i++) {
-		const uint32_t f = kmer_shr32(x, 2 * i), r = kmer_shr32(xr, 2 * (w - i));
-		const uint32_t c = (((__popc(f & mask) & 1) ? f : r) >> 1) & cmask;
-		best_h = min(best_h, revhash32(c));
+	const int w = k - m;  // last window index
+	uint32_t X[NW + 1], R[NW + 1];
+	X[0] = (uint32_t)x.lo;
+	X[1] = (uint32_t)(x.lo >> 32);
+	// xs = xr << 2 (WMAX - 1 - w): at most 2 (WMAX - 1 + m) <= 64 KW + 30 bits
+	const int s = 2 * (WMAX - 1 - w);
+	if constexpr (KW == 1) {
+		X[2] = 0;
+		const uint64_t lo = xr.lo << s, hi = s ? (xr.lo >> (64 - s)) : 0ull;
+		R[0] = (uint32_t)lo;
+		R[1] = (uint32_t)(lo >> 32);
+		R[2] = (uint32_t)hi;
+	} else {
+		X[2] = (uint32_t)x.hi;
+		X[3] = (uint32_t)(x.hi >> 32);
+		X[4] = 0;
+		// 128-bit value shifted left by s in [0, 126] into 160 bits (the top word only ever receives m-mer bits)
+		uint64_t a0, a1, a2;  // bits 0-63, 64-127, 128-191
+		if (s >= 64) {
+			const int t = s - 64;
+			a0 = 0;
+			a1 = xr.lo << t;
+			a2 = (xr.hi << t) | (t ? (xr.lo >> (64 - t)) : 0ull);
+		} else {
+			a0 = xr.lo << s;
+			a1 = (xr.hi << s) | (s ? (xr.lo >> (64 - s)) : 0ull);
+			a2 = s ? (xr.hi >> (64 - s)) : 0ull;
+		}
+		R[0] = (uint32_t)a0;
+		R[1] = (uint32_t)(a0 >> 32);
+		R[2] = (uint32_t)a1;
+		R[3] = (uint32_t)(a1 >> 32);
+		R[4] = (uint32_t)a2;
 	}
+	int32_t best_h = 0x7fffffff;
+	auto window = [&](uint32_t f, uint32_t r) {
+		// pick = all ones when the forward strand has odd parity (v_bfe_i32 of the popcount's bit 0), then one v_bfi_b32
+		// selects the strand and one v_bfe_u32 masks and drops the low bit: no v_cmp / v_cndmask pair, no VCC hazard
+		const uint32_t pick = (uint32_t)__builtin_amdgcn_sbfe(__popc(f & mask), 0u, 1u);
+		uint32_t sel;
+		asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(pick), "v"(f), "v"(r));
+		best_h = min(best_h, revhash32(__builtin_amdgcn_ubfe(sel, 1u, (uint32_t)(2 * m - 1))));
+	};
+	// Groups of four windows whose word indices and shifts are immediates, behind ONE wave-uniform branch per group (a branch
+	// per window cost more than it saved: taken branches stall the wave's instruction stream) ...
+#pragma unroll
+	for (int g = 0; g < WMAX / 4; g++) {
+		if (4 * g + 3 <= w) {
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int of = 2 * (4 * g + j), orr = 2 * (WMAX - 1 - (4 * g + j));
+				window((of & 31) ? __builtin_amdgcn_alignbit(X[(of >> 5) + 1], X[of >> 5], of & 31) : X[of >> 5],
+				       (orr & 31) ? __builtin_amdgcn_alignbit(R[(orr >> 5) + 1], R[orr >> 5], orr & 31) : R[orr >> 5]);
+			}
+		}
+	}
+	// ... and the last (w + 1) mod 4 windows with runtime offsets
+	for (int i = (w + 1) & ~3; i <= w; i++)
+		window(kmer_shr32(x, 2 * i), kmer_shr32(xr, 2 * (w - i)));
 	return unrevhash32((uint32_t)best_h);
 }
 

@@ -216,7 +216,7 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
  * created.  Keys: "bin_bits" (partition bins = 2^value, 0 = default), "mini_handoff" (1/0/-1: the partition pass hands the
  * minimizers to the query kernel / it recomputes them / automatic), "query_heads" (0: query kernels read the full group
  * descriptor instead of the compact head), "reads_mode" (sequence / file queries: 0 automatic, 1 front end fused with the query
- * body, 2 front end -> binned pipeline), "window_kb" (KiB of characters per front-end window), "narrow_ids" (0: host-buffer results cross PCIe as 64-bit words even when every ID fits 32 bits), "query_binning" (as blmx_set_query_binning). */
+ * body, 2 front end -> binned pipeline), "window_kb" (KiB of characters per front-end window), "partition" (1: one-pass partition into fixed-capacity bins instead of the exact one -- histogram, scan, scatter), "slot_slack_pct" (its slack), "narrow_ids" (0: host-buffer results cross PCIe as 64-bit words even when every ID fits 32 bits), "query_binning" (as blmx_set_query_binning). */
 int blmx_set_tuning(blmx_index* ix, const char* key, int value);
 
 int blmx_stats(const blmx_index* ix, blmx_stats_t* out);

@@ -314,3 +314,31 @@ def test_tuning_knobs_do_not_change_results(B, O, k, kb, b):
         assert np.array_equal(ix.query_sequences_hash(reads), want_reads)
     with pytest.raises(ValueError):
         ix.set_tuning("no_such_knob", 1)
+
+
+@pytest.mark.parametrize("k,kb,b", [(31, 8, 6), (63, 16, 8)])
+def test_partition_paths_and_skewed_batches(B, O, k, kb, b):
+    """The batch partition in front of the query kernel: one pass into fixed-capacity bins (default) and the exact partition
+    give the direct kernel's answers -- also when nearly the whole batch falls into a few bins and spills into the overflow
+    region (a few k-mers repeated a thousand times), and for batches that are not a multiple of anything."""
+    ix, orc, seqs, rng = _index(B, O, k, 9, 7, b, kb, 1300 + k, nseq=2500)
+    pos = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
+    neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(30000)]
+    neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
+    uniform = np.concatenate([pos, neg])
+    uniform = np.ascontiguousarray(uniform[rng.permutation(len(uniform))])
+    few = uniform[:700]
+    skewed = np.ascontiguousarray(np.concatenate([np.tile(few, (1500, 1)), uniform[:12345]])[rng.permutation(700 * 1500 + 12345)])
+    one = np.ascontiguousarray(np.tile(uniform[5:6], (300001, 1)))
+    for name, q in (("uniform", uniform), ("skewed", skewed), ("one k-mer", one)):
+        want = orc.query_kmers(q.reshape(-1) if kb == 8 else q)
+        ix.set_query_binning(-1)
+        assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), name
+        ix.set_query_binning(1)
+        for part in (0, 1):  # exact partition / one pass into fixed-capacity bins
+            for bits in (0, 4, 10):
+                ix.set_tuning("partition", part)
+                ix.set_tuning("bin_bits", bits)
+                assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), (name, part, bits)
+    ix.set_tuning("partition", 0)
+    ix.set_tuning("bin_bits", 0)

@@ -172,3 +172,89 @@ def test_streaming_file_query_multi_batch(tmp_path):
     assert (good2, bad2) == ((n_idx + n_other + 1) * per, 0)
     sample = [bytes(s_) for s_ in seqs[n_idx:n_idx + 50]]
     assert (ix2.query_sequences_hash(sample) >= 0).all() and (ix.query_sequences_hash(sample) < 0).all()
+
+
+# ---- k = 63 (128-bit k-mers, b = 8) at BASELINE scale: C5 = 5e8 63-mers --------------------------------------------------------
+@pytest.fixture(scope="module")
+def big63():
+    import torch
+    import blight_amd as B
+    import bench
+    k, m, n, b = 63, 9, 14, 8
+    dev = torch.device("cuda", 0)
+    ascii_, offs, total = bench.synth_unitigs(torch, dev, 500_000_000, k, 5)
+    torch.cuda.synchronize()
+    ix = B.kmer_Set_Light(k, m, n, 6, 1, b)
+    ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+    return dict(torch=torch, B=B, bench=bench, dev=dev, ascii=ascii_, offs=offs, total=total, ix=ix, k=k, m=m, n=n, b=b)
+
+
+def test_k63_self_query_negatives_and_fallback(big63):
+    """Every indexed 63-mer is found, the IDs are a permutation of [0, N) up to duplicated k-mers, random 63-mers are absent,
+    and the fallback table -- populated for real at this scale by k-mers that agree in their low 64 bits (SURVEY C-7: the MPHF
+    hashes 128-bit keys by their low half, bbhash.h:160-170) -- answers like the oracle on the exported index image."""
+    torch, ix, dev, k = big63["torch"], big63["ix"], big63["dev"], big63["k"]
+    st = ix.stats()
+    N = st["number_kmer"]
+    assert N == 500_000_000 and st["kmer_bytes"] == 16
+    assert st["fallback_keys"] > 0
+    pos = _all_kmer_positions(torch, big63["offs"], k)
+    s = torch.cuda.current_stream().cuda_stream
+    kmers = torch.empty((N, 2), device=dev, dtype=torch.int64)
+    err = torch.zeros(1, device=dev, dtype=torch.int32)
+    ix.kmers_at_device(big63["ascii"].data_ptr(), pos.data_ptr(), N, kmers.data_ptr(), err.data_ptr(), s)
+    del pos
+    ids = torch.empty(N, device=dev, dtype=torch.int64)
+    ix.query_kmers_device(kmers.data_ptr(), N, ids.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    assert int(ids.min().item()) >= 0 and int(ids.max().item()) == N - 1
+    counts = torch.bincount(ids, minlength=N)
+    dup_ids = int((counts > 1).sum().item())
+    assert int((counts == 0).sum().item()) == dup_ids and dup_ids <= 2
+    del counts
+    # random 63-mers: absent; membership == (ID >= 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(63)
+    nq = 20_000_000
+    q = torch.randint(-(1 << 63), (1 << 63) - 1, (nq, 2), device=dev, dtype=torch.int64, generator=g)
+    ix.canonicalize_device(q.data_ptr(), nq, s)
+    nids = torch.empty(nq, device=dev, dtype=torch.int64)
+    ix.query_kmers_device(q.data_ptr(), nq, nids.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int((nids >= 0).sum().item()) == 0
+    sample = q[:100000].cpu().numpy().view(np.uint64)
+    assert not ix.query_kmer_bool(sample.reshape(-1)).any()
+    # the oracle's query path on the exported image: indexed sample, fallback keys, near misses of fallback keys
+    from oracle import oracle as O
+    orc, _ = big63["bench"].import_oracle(ix, st, k, big63["m"], big63["n"], big63["b"])
+    hs = kmers[:300000].cpu().numpy().view(np.uint64)
+    assert np.array_equal(ids[:300000].cpu().numpy(), orc.query_kmers(hs))
+    fb = ix.export("fb_keys").reshape(-1, 2)
+    got = ix.query_kmer_hash(fb.reshape(-1))
+    assert np.array_equal(got, orc.query_kmers(fb)) and (got >= 0).all()
+    flipped = fb.copy()
+    flipped[:, 1] ^= np.uint64(1)  # same low 64 bits (same MPHF hashes), another k-mer: must be absent or answered like the oracle
+    ints = [min(x, O.p_rc(x, k, 16)) for x in O.array_to_kmers(flipped, 16)]
+    fa = O.kmers_to_array(ints, 16)
+    assert np.array_equal(ix.query_kmer_hash(fa.reshape(-1)), orc.query_kmers(fa))
+    orc.close()
+    big63["kmers"], big63["ids"] = kmers, ids
+
+
+def test_k63_strand_symmetry_and_reads(big63):
+    torch, ix, k = big63["torch"], big63["ix"], big63["k"]
+    offs = big63["offs"][:1501].cpu().numpy()
+    raw = bytes(big63["ascii"][: int(offs[-1])].cpu().numpy())
+    seqs = [raw[offs[i]:offs[i + 1]].decode() for i in range(1500)]
+    fwd = ix.query_sequences_hash(seqs)
+    comp = str.maketrans("ACGT", "TGCA")
+    rc = ix.query_sequences_hash([s[::-1].translate(comp) for s in seqs])
+    o = 0
+    for s_ in seqs:
+        nk = len(s_) - k + 1
+        assert np.array_equal(rc[o:o + nk], fwd[o:o + nk][::-1])
+        o += nk
+    assert (fwd >= 0).all()
+    if "ids" in big63:  # the sequence front end and the k-mer batch path agree
+        assert np.array_equal(fwd, big63["ids"][: fwd.size].cpu().numpy())
