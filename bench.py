@@ -521,38 +521,66 @@ def main():
     ids = torch.empty(nq, device=dev, dtype=torch.int64)
     torch.cuda.synchronize()
 
-    querier = None
+    querier = None   # torch.distributed exchange (blight_amd/dist.py): fallback of the native one
+    comm = None      # native exchange: RCCL behind the C ABI (blmx_comm_*, blmx_query_kmers_sharded_device)
     if effective_mode == "sharded":
-        from blight_amd.dist import DeviceOps, ShardedQuerier
-        bounds = torch.from_numpy(ix.shard_bounds().astype("int32")).to(dev)
-        querier = ShardedQuerier(DeviceOps(ix, dev), bounds)
-        # Probe the exchange once on a small slice.  The 8-GPU RCCL path cannot be exercised on the 1-GPU development
-        # boxes, so if the all-to-all fails on any rank every rank falls back to full replicas (reported in `parallelism`).
-        failed = torch.zeros(1, device=("cpu" if rehearsal else dev), dtype=torch.int32)
-        try:
-            querier.query(q[:4096].contiguous())
-            torch.cuda.synchronize()
-        except Exception as e:  # pragma: no cover - only on a broken collective
-            log("rank %d: sharded exchange failed (%r); falling back to replicas" % (rank, e))
-            failed += 1
-        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-        if int(failed.item()):
-            effective_mode = "replicas (sharded exchange failed)"
-            querier = None
-            ix.close()
-            ix = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
-            t0 = time.time()
-            ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
-            t_build = time.time() - t0
-            st = ix.stats()
-    keep_input = (querier is not None and not args.no_replicas_leg) or (world == 1 and args.reads > 0)
+        def all_failed(flag):
+            t = torch.tensor([1 if flag else 0], device=("cpu" if rehearsal else dev), dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return bool(t.item())
+        # 1. the library's own RCCL communicator (rank 0's unique id travels through the launcher's process group)
+        failed = rehearsal  # several ranks on ONE GPU: RCCL refuses duplicate devices
+        if not failed:
+            try:
+                uid = torch.zeros(blight_amd.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(blight_amd.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                comm = blight_amd.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world, device=local_rank)
+                probe = torch.empty(4096, device=dev, dtype=torch.int64)
+                comm.query_kmers_sharded_device(ix, q[:4096].contiguous().data_ptr(), 4096, probe.data_ptr(), stream)
+                torch.cuda.synchronize()
+            except Exception as e:  # pragma: no cover - only on a broken collective
+                log("rank %d: native sharded exchange failed (%r)" % (rank, e))
+                failed = True
+        if all_failed(failed):
+            comm = None
+            # 2. the same choreography over torch.distributed
+            from blight_amd.dist import DeviceOps, ShardedQuerier
+            bounds = torch.from_numpy(ix.shard_bounds().astype("int32")).to(dev)
+            querier = ShardedQuerier(DeviceOps(ix, dev), bounds)
+            failed = False
+            try:
+                querier.query(q[:4096].contiguous())
+                torch.cuda.synchronize()
+            except Exception as e:  # pragma: no cover
+                log("rank %d: torch.distributed sharded exchange failed (%r); falling back to replicas" % (rank, e))
+                failed = True
+            if all_failed(failed):  # 3. full replicas, no data-path collective
+                effective_mode = "replicas (sharded exchange failed)"
+                querier = None
+                ix.close()
+                ix = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
+                t0 = time.time()
+                ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+                t_build = time.time() - t0
+                st = ix.stats()
+            else:
+                effective_mode = "sharded (torch.distributed exchange)"
+        else:
+            effective_mode = "sharded (native RCCL exchange behind the C ABI)"
+    sharded = comm is not None or querier is not None
+    keep_input = (sharded and not args.no_replicas_leg) or (world == 1 and args.reads > 0)
     if not keep_input:
         del ascii_
 
-    if querier is not None:
+    if comm is not None:
+        def step():  # partition -> all-to-all-v (RCCL/xGMI) -> owner's k_query -> all-to-all-v back -> gather
+            comm.query_kmers_sharded_device(ix, q.data_ptr(), nq, ids.data_ptr(), stream)
+    elif querier is not None:
         def step():
             nonlocal ids
-            ids = querier.query(q)  # route -> all-to-all-v (RCCL/xGMI) -> owner's k_query -> all-to-all-v back -> un-permute
+            ids = querier.query(q)
     else:
         def step():
             ix.query_kmers_device(q.data_ptr(), nq, ids.data_ptr(), stream)
@@ -583,7 +611,7 @@ def main():
     # ---- N > 1, sharded: also report the communication-free alternative (full index on every GPU, queries split), measured the
     # same way right after the sharded run ("report both").  `value` stays the sharded number.
     replicas = None
-    if querier is not None and keep_input:
+    if sharded and keep_input:
         ids_sharded = ids
         full = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
         full.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
@@ -622,7 +650,7 @@ def main():
 
     if rank == 0:
         value = world * nq * args.steps / dt
-        stages = stage_profile(ix, step) if querier is None else {}
+        stages = stage_profile(ix, step) if not sharded else {}
         out = {
             "metric": "kmer_id_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
 ABI_VERSION = 8  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
-BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT = 0, -1, -2, -3, -4, -5, -6, -7, -8
+BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT, BLMX_ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+COMM_ID_BYTES = 128
 
 _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
@@ -99,6 +100,11 @@ def load_library():
                                               C.c_void_p, C.c_void_p]
     lib.blmx_unpermute_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_set_query_binning.argtypes = [C.c_void_p, C.c_int]
+    lib.blmx_comm_unique_id.argtypes = [C.c_void_p]
+    lib.blmx_comm_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    lib.blmx_comm_destroy.argtypes = [C.c_void_p]
+    lib.blmx_comm_destroy.restype = None
+    lib.blmx_query_kmers_sharded_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
@@ -392,6 +398,44 @@ class kmer_Set_Light:
             if r < 0:
                 _raise(int(r), self._lib.blmx_last_error(self._h).decode())
         return out
+
+
+def comm_unique_id():
+    """rank 0: the 128-byte id every rank passes to Comm() (ncclGetUniqueId)"""
+    lib = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.blmx_comm_unique_id(buf)
+    if rc:
+        _raise(rc, lib.blmx_last_error(None).decode() or "blmx_comm_unique_id failed")
+    return buf.raw
+
+
+class Comm:
+    """Native RCCL communicator of the library (one process per GPU); collective construction like ncclCommInitRank."""
+
+    def __init__(self, unique_id, rank, world, device=0):
+        self._lib = load_library()
+        self._c = C.c_void_p()
+        self.rank, self.world = rank, world
+        rc = self._lib.blmx_comm_create(unique_id, rank, world, device, C.byref(self._c))
+        if rc:
+            self._c = None
+            _raise(rc, self._lib.blmx_last_error(None).decode() or "blmx_comm_create failed")
+
+    def query_kmers_sharded_device(self, index, d_kmers_ptr, nq, d_ids_ptr, stream=None):
+        """collective: every rank calls it with its own batch; IDs in the caller's order"""
+        index._check(self._lib.blmx_query_kmers_sharded_device(index._h, self._c, d_kmers_ptr, nq, d_ids_ptr, stream))
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._lib.blmx_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def primitive(op, data, arg=0, arg2=0, kmer_bytes=8):

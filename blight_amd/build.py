@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libblight_mi355x.so")
-SOURCES = ["blmx_api.hip", "blmx_build.hip", "blmx_query.hip", "blmx_reads.hip", "blmx_front.hip", "blmx_stream.hip"]
+SOURCES = ["blmx_api.hip", "blmx_build.hip", "blmx_query.hip", "blmx_reads.hip", "blmx_front.hip", "blmx_stream.hip", "blmx_comm.hip"]
 HEADERS = ["blmx_internal.h", "device_prims.h", "index_device.h", "query_device.h", os.path.join(ROOT, "include", "blight_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-DNDEBUG",
@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
     if force or procs or _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -29,9 +29,11 @@ namespace {
 thread_local std::string g_create_err;
 thread_local std::string g_last_err;
 
-int fail(blmx_index*, int code, const std::string& msg)
+int fail(blmx_index* h, int code, const std::string& msg)
 {
 	g_last_err = msg;
+	if (!h)  // calls without an index (communicator, primitives): blmx_last_error(NULL) reports them
+		g_create_err = msg;
 	return code;
 }
 
@@ -546,6 +548,31 @@ int blmx_gather_ids_device(blmx_index* h, const int64_t* d_ids_sorted, const uin
 		BLMX_HIP(hipSetDevice(h->ix.prm.device));
 		launch_gather_ids(h->ix, d_ids_sorted, d_inv, nq, d_ids_out, reinterpret_cast<hipStream_t>(stream));
 	});
+}
+
+int blmx_comm_unique_id(void* id_out)
+{
+	if (!id_out)
+		return BLMX_EINVAL;
+	return guarded(nullptr, [&] { comm_unique_id(id_out); });
+}
+
+int blmx_comm_create(const void* id, uint32_t rank, uint32_t world, int device, blmx_comm** out)
+{
+	if (out)
+		*out = nullptr;
+	if (!id || !out)
+		return BLMX_EINVAL;
+	return guarded(nullptr, [&] { *out = reinterpret_cast<blmx_comm*>(comm_create(id, rank, world, device)); });
+}
+
+void blmx_comm_destroy(blmx_comm* c) { comm_destroy(reinterpret_cast<Comm*>(c)); }
+
+int blmx_query_kmers_sharded_device(blmx_index* h, blmx_comm* c, const void* d_kmers, uint64_t nq, int64_t* d_ids, void* stream)
+{
+	if (!h || !c || (nq && (!d_kmers || !d_ids)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { query_kmers_sharded(h->ix, *reinterpret_cast<Comm*>(c), d_kmers, nq, d_ids, reinterpret_cast<hipStream_t>(stream)); });
 }
 
 int blmx_set_query_binning(blmx_index* h, int policy)

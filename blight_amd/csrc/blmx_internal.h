@@ -343,6 +343,12 @@ void launch_route_count(const Index& ix, const void* d_kmers, uint64_t nq, const
 void launch_route_scatter(const Index& ix, const void* d_kmers, const uint8_t* d_dest, uint64_t nq, const uint64_t* d_offsets, uint32_t world,
                           void* d_sorted, uint32_t* d_order, uint64_t* d_cursor, hipStream_t s);
 void launch_unpermute(const int64_t* d_vals, const uint32_t* d_order, uint64_t nq, int64_t* d_out, hipStream_t s);
+// native multi-GPU exchange (blmx_comm.hip)
+struct Comm;
+void comm_unique_id(void* id_out);
+Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int device);
+void comm_destroy(Comm* c);
+void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s);
 // streaming front end (blmx_stream.hip)
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);
 void build_from_fasta_streamed(Index& ix, const char* path);

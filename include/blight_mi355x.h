@@ -33,6 +33,7 @@ extern "C" {
 #define BLMX_EHIP (-5)    /* HIP runtime error / no usable GPU                                                     */
 #define BLMX_ENOMEM (-6)  /* host or device allocation failed                                                      */
 #define BLMX_ESTATE (-7)  /* call order: query before build, build twice                                           */
+#define BLMX_ERCCL (-9)   /* RCCL cannot be loaded or a collective failed (multi-GPU entry points only)                 */
 #define BLMX_ELIMIT (-8)  /* input exceeds an implementation limit (e.g. a bucket of >= 2^32 nt, as in the reference) */
 
 typedef struct blmx_index blmx_index;
@@ -206,6 +207,22 @@ int blmx_partition_device(blmx_index* ix, const void* d_kmers, uint64_t nq, void
 int blmx_query_partitioned_device(blmx_index* ix, const void* d_ordered_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
 int blmx_gather_ids_device(blmx_index* ix, const int64_t* d_ids_ordered, const uint32_t* d_inv, uint64_t nq, int64_t* d_ids_out,
                            void* stream);
+/* ---- native multi-GPU queries: RCCL over xGMI behind this ABI, no Python / torch involved.  One process per GPU.  Rank 0 makes
+ * a unique id (blmx_comm_unique_id, BLMX_COMM_ID_BYTES bytes) and hands it to the other ranks by any means (a file, MPI, a
+ * socket); every rank then calls blmx_comm_create(id, rank, world, device) -- collective, like ncclCommInitRank.
+ * blmx_query_kmers_sharded_device is the whole exchange step for one batch per rank: partition by owner (bins split at the shard
+ * boundaries), all-to-all-v of the k-mers (grouped ncclSend / ncclRecv), the owner's query kernel, all-to-all-v of the IDs back,
+ * gather into the caller's order; pieces of the batch are pipelined so that the exchange of one piece hides behind the queries
+ * of another.  It is a collective: every rank of the communicator calls it, in the same order, each with its own batch (nq may
+ * differ and may be 0).  The index must have been built with blmx_set_shard(rank, world) of the same rank / world.
+ * librccl.so.1 is loaded at run time (BLMX_ERCCL when absent); single-GPU callers never need it. */
+typedef struct blmx_comm blmx_comm;
+#define BLMX_COMM_ID_BYTES 128
+int blmx_comm_unique_id(void* id_out);
+int blmx_comm_create(const void* id, uint32_t rank, uint32_t world, int device, blmx_comm** out);
+void blmx_comm_destroy(blmx_comm* c);
+int blmx_query_kmers_sharded_device(blmx_index* ix, blmx_comm* c, const void* d_canon_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
+
 /* Batch-query strategy of blmx_query_kmers / blmx_query_kmers_device: 0 = automatic (large batches on large indexes are first
  * partitioned by the top bits of their minimizer so that concurrently running blocks share a slice of the index in
  * L2 / Infinity Cache; results are identical and in the caller's order), 1 = always partition, -1 = never.

@@ -182,3 +182,69 @@ def test_sharded_querier_on_rccl_world1(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "NCCL-WORLD1-OK" in r.stdout, r.stderr[-2000:]
+
+
+_NATIVE_WORLD1 = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["BLIGHT_ROOT"])
+os.environ["BLIGHT_NO_TORCH"] = "1"      # no torch in this process: the library loads librccl.so.1 itself
+import ctypes as C
+import blight_amd as B
+rng = np.random.default_rng(5)
+k, m, n, b = int(sys.argv[1]), 9, 7, int(sys.argv[2])
+kb = 8 if k <= 32 else 16
+seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, k - 1 + int(rng.geometric(1 / 80)))) for _ in range(4000)]
+ix = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ix.set_shard(0, 1)
+ix.construct_index_from_sequences(seqs)
+comm = B.Comm(B.comm_unique_id(), 0, 1, device=0)
+# queries: the k-mers of the index (through the sequence entry point they are canonical) + random ones, shuffled
+hip_path = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0]  # the HIP runtime the library itself loaded
+hip = C.CDLL(hip_path)
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+def dmalloc(nbytes):
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 16))) == 0
+    return p
+want_pos = ix.query_sequences_hash(seqs)
+from oracle import oracle as O
+orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+pos = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
+neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(50000)]
+neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
+q = np.concatenate([pos, neg])
+q = np.ascontiguousarray(q[rng.permutation(len(q))])
+want = ix.query_kmer_hash(q.reshape(-1))
+assert np.array_equal(want, orc.query_kmers(q.reshape(-1) if kb == 8 else q))
+nq = len(q)
+d_q, d_ids = dmalloc(q.nbytes), dmalloc(nq * 8)
+assert hip.hipMemcpy(d_q, C.c_void_p(q.ctypes.data), C.c_size_t(q.nbytes), 1) == 0
+for pieces in ("1", "2", "3"):
+    os.environ["BLIGHT_DIST_CHUNKS"] = pieces
+    for n_ in (nq, 12345, 0):
+        comm.query_kmers_sharded_device(ix, d_q, n_, d_ids, None)
+        assert hip.hipDeviceSynchronize() == 0
+        got = np.full(max(n_, 1), -7, dtype=np.int64)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), d_ids, C.c_size_t(n_ * 8), 2) == 0
+        assert np.array_equal(got[:n_], want[:n_]), (pieces, n_)
+comm.close()
+print("NATIVE-WORLD1-OK")
+"""
+
+
+@pytest.mark.parametrize("k,b", [(31, 6), (63, 8)])
+def test_native_rccl_exchange_world1(tmp_path, k, b):
+    """blmx_comm_* + blmx_query_kmers_sharded_device: the native exchange (RCCL loaded by the library itself, grouped
+    ncclSend / ncclRecv all-to-all-v on the communicator's stream, pieces pipelined against the query kernel) with a world of
+    one rank on the test box's GPU, in a process WITHOUT torch: IDs equal the unsharded path and the oracle, for 1, 2 and 3
+    pieces, partial and empty batches."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "native_world1.py"
+    script.write_text(_NATIVE_WORLD1)
+    env = dict(os.environ, BLIGHT_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), str(k), str(b)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "NATIVE-WORLD1-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
