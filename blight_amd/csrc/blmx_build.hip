@@ -127,7 +127,10 @@ __global__ __launch_bounds__(kBlock) void k_superkmer_flags(const uint64_t* __re
 	__shared__ uint8_t s_valid[kBlock + 1];
 	const int w = k - m + 1;
 	const int L = (int)kBlock + w;  // m-mer entries e = 0 .. L-1  <->  positions base-1 .. base+kBlock-1+w-1
-	const uint64_t base = (uint64_t)blockIdx.x * kBlock;
+	// (an AQL dispatch counts work-items in 32 bits per dimension: more than 2^32 positions need the second grid dimension)
+	const uint64_t base = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBlock;
+	if (base > total_len)
+		return;
 	const int tid = (int)threadIdx.x;
 	auto mmer_hash = [&](int e) -> int32_t {
 		const int64_t p = (int64_t)base - 1 + e;
@@ -636,6 +639,157 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 	}
 }
 
+// ---- K7 (LDS-staged, one level of one SLICE per workgroup): groups above the single-workgroup budget ----------------------------
+// A group of more than ~1.18 M keys (low-complexity sequence puts millions of k-mers under a few minimizers) would leave LDS for
+// memory-side atomics (~2e10 scattered atomics/s chip-wide: 340 ms for the 2.5e8 keys of the skewed human-scale input).  Here a
+// level of such a group is cut into slices of kLdsLevelBits bits and every (group, slice) pair of the level gets its own
+// workgroup: it walks the group's current key list, marks the keys that hash into its slice in LDS, reserves room for its
+// survivors in the group's next list with ONE global atomic (their number = keys in the slice - bits finally set, no extra
+// walk), walks the list again to write them, and stores the finished slice.  Keys are hashed once per walk and slice, which
+// is cheap next to atomics; one launch per level, workgroups of finished groups exit at once.
+// lvcnt[level * ngroups + g] = keys of group g alive at `level` (level 0: all keys, implicit list).
+template <int KW>
+__global__ __launch_bounds__(kGroupBlock) void k_mphf_level_sliced(BuildGroups bg, const uint64_t* __restrict__ keys, int level,
+                                                                   const uint2* __restrict__ items, uint32_t* __restrict__ listA,
+                                                                   uint32_t* __restrict__ listB, uint32_t* __restrict__ lvcnt,
+                                                                   uint32_t* __restrict__ gbits32)
+{
+	__shared__ uint32_t s_bits[kLdsLevelWords];
+	__shared__ uint32_t s_coll[kLdsLevelWords];
+	__shared__ uint32_t s_in, s_set, s_base, s_cnt;
+	const uint32_t g = items[blockIdx.x].x, sl = items[blockIdx.x].y;
+	const GroupDesc* gd = &bg.groups[g];
+	const uint64_t kb = bg.g_prefix[g];
+	const uint32_t count = level == 0 ? (uint32_t)gd->nkeys : lvcnt[(uint64_t)level * bg.ngroups + g];
+	if (count == 0)
+		return;
+	const uint64_t size = gd->size[level];
+	const uint32_t words = (uint32_t)(size >> 5), w0 = sl * kLdsLevelWords;
+	if (w0 >= words)
+		return;
+	const uint32_t wn = min(kLdsLevelWords, words - w0);
+	const uint32_t* cur = ((level & 1) ? listB : listA) + kb;  // survivors of level - 1 (level 0: implicit)
+	uint32_t* nxt = ((level & 1) ? listA : listB) + kb;
+	for (uint32_t w = threadIdx.x; w < wn; w += kGroupBlock) {
+		s_bits[w] = 0;
+		s_coll[w] = 0;
+	}
+	if (threadIdx.x == 0)
+		s_in = s_set = s_cnt = 0;
+	__syncthreads();
+	// mark (processLevel_, bbhash.h:677-709) + count the keys that fall into this slice; four keys in flight per thread (the walk
+	// is a stream of dependent-free loads: one per iteration left the CU at a few GB/s)
+	constexpr uint32_t kIlp = 4;
+	auto load_key = [&](uint32_t i) -> uint64_t {
+		const uint32_t j = level == 0 ? i : cur[i];
+		return KW == 1 ? keys[kb + j] : keys[2 * (kb + j)];
+	};
+	auto bit_of_key = [&](uint64_t key) -> uint32_t {
+		LevelHasher hs(key);
+		uint64_t h = 0;
+		for (int l = 0; l <= level; l++)
+			h = hs.next(l);
+		return (uint32_t)reduce_level(h, size);
+	};
+	const uint32_t rounds = (count + kGroupBlock * kIlp - 1) / (kGroupBlock * kIlp);
+	uint32_t mine = 0;
+	for (uint32_t r = 0; r < rounds; r++) {
+		uint64_t key[kIlp];
+		bool in[kIlp];
+#pragma unroll
+		for (uint32_t u = 0; u < kIlp; u++) {
+			const uint32_t i = (r * kIlp + u) * kGroupBlock + threadIdx.x;
+			in[u] = i < count;
+			key[u] = in[u] ? load_key(i) : 0;
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < kIlp; u++) {
+			if (!in[u])
+				continue;
+			const uint32_t b = bit_of_key(key[u]);
+			const uint32_t lw = (b >> 5) - w0;
+			if (lw < wn) {
+				const uint32_t m = 1u << (b & 31);
+				if (atomicOr(&s_bits[lw], m) & m)
+					atomicOr(&s_coll[lw], m);
+				mine++;
+			}
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1)
+		mine += __shfl_xor(mine, o);
+	if ((threadIdx.x & 63) == 0 && mine)
+		atomicAdd(&s_in, mine);
+	__syncthreads();
+	// the finished slice (clearCollisions, bbhash.h:358-368) and the number of bits it keeps
+	uint32_t* out = gbits32 + 2 * gd->wbase + (uint32_t)(bg.loff[(uint64_t)g * kLevels + level] >> 5) + w0;
+	uint32_t kept = 0;
+	for (uint32_t w = threadIdx.x; w < wn; w += kGroupBlock) {
+		const uint32_t v = s_bits[w] & ~s_coll[w];
+		out[w] = v;
+		kept += __popc(v);
+	}
+	for (int o = 32; o > 0; o >>= 1)
+		kept += __shfl_xor(kept, o);
+	if ((threadIdx.x & 63) == 0 && kept)
+		atomicAdd(&s_set, kept);
+	__syncthreads();
+	const uint32_t nsurv = s_in - s_set;  // every key of the slice either keeps its bit for itself or goes on
+	if (nsurv == 0)
+		return;
+	if (threadIdx.x == 0)
+		s_base = atomicAdd(&lvcnt[(uint64_t)(level + 1) * bg.ngroups + g], nsurv);
+	__syncthreads();
+	for (uint32_t r = 0; r < rounds; r++) {
+		uint64_t key[kIlp];
+		uint32_t jj[kIlp];
+		bool in[kIlp];
+#pragma unroll
+		for (uint32_t u = 0; u < kIlp; u++) {
+			const uint32_t i = (r * kIlp + u) * kGroupBlock + threadIdx.x;
+			in[u] = i < count;
+			jj[u] = in[u] ? (level == 0 ? i : cur[i]) : 0;
+			key[u] = in[u] ? (KW == 1 ? keys[kb + jj[u]] : keys[2 * (kb + jj[u])]) : 0;
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < kIlp; u++) {
+			bool surv = false;
+			if (in[u]) {
+				const uint32_t b = bit_of_key(key[u]);
+				const uint32_t lw = (b >> 5) - w0;
+				surv = lw < wn && ((s_coll[lw] >> (b & 31)) & 1u);
+			}
+			const unsigned long long bal = __ballot(surv);
+			if (bal) {
+				const uint32_t lane = threadIdx.x & 63;
+				uint32_t base = 0;
+				const int leader = __ffsll(bal) - 1;
+				if ((int)lane == leader)
+					base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
+				base = __shfl(base, leader);
+				if (surv)
+					nxt[s_base + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = jj[u];
+			}
+		}
+	}
+}
+
+// after the last level: survivors of every sliced group -> fb_count (they sit in listA like those of k_mphf_group_lds), levels used
+__global__ void k_sliced_finish(const uint32_t* __restrict__ glist, uint32_t nlarge, uint32_t ngroups, const uint32_t* __restrict__ lvcnt,
+                                uint32_t* __restrict__ fb_count, int* __restrict__ levels_max)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nlarge)
+		return;
+	const uint32_t g = glist[t];
+	int used = 1;
+	for (int l = 1; l < kLevels; l++)
+		if (lvcnt[(uint64_t)l * ngroups + g])
+			used = l + 1;
+	fb_count[g] = lvcnt[(uint64_t)kLevels * ngroups + g];
+	atomicMax(levels_max, used);
+}
+
 // first work list of the global level kernels: the key indices of the groups that do NOT fit the LDS path
 __global__ void k_seed_large_list(const uint64_t* __restrict__ g_prefix, const uint8_t* __restrict__ small, const uint64_t* __restrict__ seed_off,
                                   uint32_t ngroups, uint32_t* __restrict__ list)
@@ -648,9 +802,16 @@ __global__ void k_seed_large_list(const uint64_t* __restrict__ g_prefix, const u
 		list[o + i] = (uint32_t)(kb + i);
 }
 
+__global__ void k_widen_u32(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		out[i] = in[i];
+}
+
 // fallback keys of the LDS-built groups -> global key indices appended to the fallback list
 __global__ void k_fb_collect(const uint64_t* __restrict__ g_prefix, const uint32_t* __restrict__ fb_count, const uint64_t* __restrict__ fb_off,
-                             const uint32_t* __restrict__ listA, uint32_t ngroups, uint32_t* __restrict__ fb_list)
+                             const uint32_t* __restrict__ listA, uint32_t ngroups, uint64_t* __restrict__ fb_list)
 {
 	const uint32_t g = blockIdx.x;
 	if (g >= ngroups)
@@ -658,7 +819,7 @@ __global__ void k_fb_collect(const uint64_t* __restrict__ g_prefix, const uint32
 	const uint32_t c = fb_count[g];
 	const uint64_t kb = g_prefix[g];
 	for (uint32_t i = threadIdx.x; i < c; i += blockDim.x)
-		fb_list[fb_off[g] + i] = (uint32_t)(kb + listA[kb + i]);
+		fb_list[fb_off[g] + i] = kb + listA[kb + i];  // absolute key index: 64 bits (an index may hold 2^32 k-mers or more)
 }
 
 // ---- K8 ----------------------------------------------------------------------------------------------------------------
@@ -738,7 +899,7 @@ __global__ void k_group_popc(const uint64_t* __restrict__ line_base, const uint6
 // ---- K9: fallback -----------------------------------------------------------------------------------------------------
 // processFallbackLevel (bbhash.h:711-728): keys left after 16 levels, in input (key index) order, get ranks R, R+1, ...
 template <int KW>
-__global__ void k_fb_prepare(BuildGroups bg, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ fb_sorted, uint64_t F,
+__global__ void k_fb_prepare(BuildGroups bg, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ fb_sorted, uint64_t F,
                              const uint64_t* __restrict__ g_popc, uint64_t* __restrict__ fk, uint64_t* __restrict__ frank,
                              uint32_t* __restrict__ fgrp)
 {
@@ -752,7 +913,7 @@ __global__ void k_fb_prepare(BuildGroups bg, const uint64_t* __restrict__ keys, 
 	const uint64_t first_key = bg.g_prefix[g];
 	while (lo < hi) {
 		const uint64_t mid = (lo + hi) >> 1;
-		if ((uint64_t)fb_sorted[mid] < first_key)
+		if (fb_sorted[mid] < first_key)
 			lo = mid + 1;
 		else
 			hi = mid;
@@ -767,21 +928,19 @@ __global__ void k_fb_prepare(BuildGroups bg, const uint64_t* __restrict__ keys, 
 	}
 }
 
-template <int KW> struct FbLess {
-	const uint64_t* fk;
-	const uint32_t* fgrp;
-	__host__ __device__ bool operator()(uint32_t a, uint32_t b) const
-	{
-		if (fgrp[a] != fgrp[b])
-			return fgrp[a] < fgrp[b];
-		if (KW == 2 && fk[2 * a + 1] != fk[2 * b + 1])
-			return fk[2 * a + 1] < fk[2 * b + 1];
-		const uint64_t ka = KW == 1 ? fk[a] : fk[2 * a], kb = KW == 1 ? fk[b] : fk[2 * b];
-		if (ka != kb)
-			return ka < kb;
-		return a < b;  // input order: the last occurrence of a duplicated key ends its run
-	}
-};
+// sort key of fallback entry perm[e] (perm == nullptr: identity, and the identity is written to iota_out):
+// which = 0 low key word, 1 high key word (128-bit k-mers), 2 group
+__global__ void k_fb_sortkey(const uint64_t* __restrict__ fk, const uint32_t* __restrict__ fgrp, const uint32_t* __restrict__ perm, uint64_t F, int KW,
+                             int which, uint64_t* __restrict__ key_out, uint32_t* __restrict__ iota_out)
+{
+	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= F)
+		return;
+	const uint32_t t = perm ? perm[e] : (uint32_t)e;
+	if (iota_out)
+		iota_out[e] = (uint32_t)e;
+	key_out[e] = which == 2 ? (uint64_t)fgrp[t] : fk[(uint64_t)KW * t + (which == 1 ? 1 : 0)];
+}
 
 template <int KW>
 __global__ void k_fb_table(const uint32_t* __restrict__ perm, uint64_t F, const uint64_t* __restrict__ fk, const uint64_t* __restrict__ frank,
@@ -803,7 +962,8 @@ __global__ void k_fb_table(const uint32_t* __restrict__ perm, uint64_t F, const 
 	tgrp[e] = g;
 	if (e == 0 || fgrp[perm[e - 1]] != g)
 		g_fb_start[g] = e;
-	atomicAdd(&g_fb_count[g], 1u);
+	if (e + 1 == F || fgrp[perm[e + 1]] != g)
+		g_fb_count[g] = (uint32_t)(e + 1);  // END of the group's run (the host subtracts the start): no per-entry atomics on a few hot counters
 }
 
 // ---- positions -----------------------------------------------------------------------------------------------------------
@@ -847,7 +1007,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, co
 }
 
 template <int KW>
-__global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ fb_sorted, uint64_t F,
+__global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ fb_sorted, uint64_t F,
                                const uint64_t* __restrict__ tk, const uint64_t* __restrict__ trank, const uint32_t* __restrict__ tgrp,
                                const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
                                const uint64_t* __restrict__ key_start, uint64_t nsk, uint64_t id_base, uint32_t* __restrict__ field_of_rank)
@@ -1021,7 +1181,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 
 	// ---- K1: packed source + unitig-start bitmap
 	const uint64_t npos = total_len + 1;                      // positions 0 .. total_len
-	const uint64_t nbw = (uint64_t)grid_for(npos) * (kBlock / 64);  // bitmap words written by K2
+	const uint64_t nbw = ((npos + kBlock - 1) / kBlock) * (kBlock / 64);  // bitmap words written by K2
 	const uint64_t src_words = (total_len + 31) / 32;
 	DevBuf d_src, d_ustart, d_Hb, d_Eb;
 	BLMX_HIP(d_src.alloc((src_words + 4) * 8, true, s));
@@ -1048,7 +1208,9 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	BLMX_HIP(d_Hpre.alloc((nbw + 1) * 8, false, s));
 	BLMX_HIP(d_Epre.alloc((nbw + 1) * 8, false, s));
 	if (nseq) {
-		hipLaunchKernelGGL((k_superkmer_flags<KW>), dim3(grid_for(npos)), dim3(kBlock), 0, s, d_src.as<uint64_t>(),
+		const uint64_t k2_blocks = (npos + kBlock - 1) / kBlock;
+		const unsigned k2_gx = (unsigned)std::min<uint64_t>(k2_blocks, 1u << 22), k2_gy = (unsigned)((k2_blocks + k2_gx - 1) / k2_gx);
+		hipLaunchKernelGGL((k_superkmer_flags<KW>), dim3(k2_gx, k2_gy), dim3(kBlock), 0, s, d_src.as<uint64_t>(),
 		                   d_ustart.as<unsigned long long>(), total_len, k, m, d_Hb.as<unsigned long long>(),
 		                   d_Eb.as<unsigned long long>());
 		BLMX_HIP(hipGetLastError());
@@ -1177,8 +1339,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_lennt.release();
 	d_lenk.release();
 	d_sklast.release();
-	if (N >= 0xffffffffull)
-		throw StatusError{BLMX_ELIMIT, "more than 2^32 - 1 k-mers on one device"};
+	// k-mer counts are 64-bit throughout; 32-bit quantities are per MPHF group (key lists, ranks) and per batch
 
 	DevBuf d_bnb, d_bne, d_bkb, d_bke, d_bnt, d_bkeys, d_bstart, d_bkpre;
 	const size_t bb = ((size_t)nbuckets + 1) * 8;
@@ -1308,15 +1469,19 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	BLMX_HIP(d_bits.alloc((total_words + 1) * 8, true, s));
 	BLMX_HIP(d_coll.alloc((total_words + 1) * 8, true, s));
 	BLMX_HIP(d_cnt.alloc(8, true, s));
-	std::vector<uint8_t> h_small(ngroups, 0);
+	std::vector<uint8_t> h_small(ngroups, 0);  // 1 = one workgroup builds all levels in LDS, 2 = one workgroup per (level, slice), 0 = global kernels
 	uint64_t n_small = 0, keys_large = 0;
-	const char* lds_env = getenv("BLIGHT_BUILD_NO_LDS");  // test hook: force the global level kernels for every group
-	const bool lds_off = lds_env && atoi(lds_env) != 0;
+	std::vector<uint32_t> h_sliced;
+	const char* lds_env = getenv("BLIGHT_BUILD_NO_LDS");  // test hook: 1 = global level kernels for every group, 2 = for the groups above the
+	const int lds_off = lds_env ? atoi(lds_env) : 0;      //            single-workgroup budget only (no sliced path)
 	for (uint32_t g = 0; g < ngroups; g++) {
 		const GroupDesc& gd = ix.h_groups[g];
-		if (gd.nkeys && !lds_off && gd.size[0] <= kLdsLevelBits * kLdsMaxSlices) {
+		if (gd.nkeys && lds_off != 1 && gd.size[0] <= kLdsLevelBits * kLdsMaxSlices) {
 			h_small[g] = 1;
 			n_small++;
+		} else if (gd.nkeys && lds_off == 0 && gd.nkeys < 0xffffffffull) {
+			h_small[g] = 2;
+			h_sliced.push_back(g);
 		} else {
 			keys_large += gd.nkeys;
 		}
@@ -1327,27 +1492,68 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	int levels_used = 0;
 	uint64_t F_lds = 0;
 	std::vector<uint64_t> h_fboff;
-	if (n_small) {
+	if (n_small || !h_sliced.empty()) {
 		DevBuf d_lA, d_lB;
 		BLMX_HIP(d_lA.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_lB.alloc((N + 1) * 4, false, s));
 		BLMX_HIP(d_fbcnt.alloc((size_t)ngroups * 4, true, s));
 		BLMX_HIP(d_lvmax.alloc(4, true, s));
+		if (!h_sliced.empty()) {
+			// work items (group, slice) of every level, largest groups first inside a level
+			std::sort(h_sliced.begin(), h_sliced.end(), [&](uint32_t a, uint32_t b2) {
+				return ix.h_groups[a].nkeys != ix.h_groups[b2].nkeys ? ix.h_groups[a].nkeys > ix.h_groups[b2].nkeys : a < b2;
+			});
+			std::vector<uint2> h_items;
+			size_t level_off[kLevels + 1];
+			for (int l = 0; l < kLevels; l++) {
+				level_off[l] = h_items.size();
+				for (uint32_t g : h_sliced) {
+					const uint32_t words = (uint32_t)(ix.h_groups[g].size[l] >> 5);
+					for (uint32_t sl = 0; sl * kLdsLevelWords < words; sl++)
+						h_items.push_back(make_uint2(g, sl));
+				}
+			}
+			level_off[kLevels] = h_items.size();
+			DevBuf d_items, d_lvcnt, d_glist;
+			BLMX_HIP(d_items.alloc(h_items.size() * sizeof(uint2), false, s));
+			BLMX_HIP(d_lvcnt.alloc((size_t)(kLevels + 1) * ngroups * 4, true, s));
+			BLMX_HIP(d_glist.alloc(h_sliced.size() * 4, false, s));
+			BLMX_HIP(hipMemcpyAsync(d_items.p, h_items.data(), h_items.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+			BLMX_HIP(hipMemcpyAsync(d_glist.p, h_sliced.data(), h_sliced.size() * 4, hipMemcpyHostToDevice, s));
+			for (int l = 0; l < kLevels; l++) {
+				const size_t ni = level_off[l + 1] - level_off[l];
+				if (ni)
+					hipLaunchKernelGGL((k_mphf_level_sliced<KW>), dim3((unsigned)ni), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(), l,
+					                   d_items.as<uint2>() + level_off[l], d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_lvcnt.as<uint32_t>(),
+					                   d_bits.as<uint32_t>());
+				if (trace) {
+					char what[64];
+					snprintf(what, sizeof what, "  K7 sliced level %d (%zu wg)", l, ni);
+					mark(what);
+				}
+			}
+			hipLaunchKernelGGL(k_sliced_finish, dim3(grid_for(h_sliced.size())), dim3(kBlock), 0, s, d_glist.as<uint32_t>(), (uint32_t)h_sliced.size(),
+			                   ngroups, d_lvcnt.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>());
+			BLMX_HIP(hipGetLastError());
+			BLMX_HIP(hipStreamSynchronize(s));  // the host vectors and the item buffers go out of scope
+		}
 		std::vector<uint32_t> h_order;
 		h_order.reserve(n_small);
 		for (uint32_t g = 0; g < ngroups; g++)
-			if (h_small[g])
+			if (h_small[g] == 1)
 				h_order.push_back(g);
 		std::sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b2) {
 			return ix.h_groups[a].nkeys != ix.h_groups[b2].nkeys ? ix.h_groups[a].nkeys > ix.h_groups[b2].nkeys : a < b2;
 		});
 		DevBuf d_gorder;
-		BLMX_HIP(d_gorder.alloc(h_order.size() * 4, false, s));
-		BLMX_HIP(hipMemcpyAsync(d_gorder.p, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, s));
-		hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3((unsigned)h_order.size()), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(),
-		                   d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>(),
-		                   d_gorder.as<uint32_t>());
-		BLMX_HIP(hipGetLastError());
+		if (!h_order.empty()) {
+			BLMX_HIP(d_gorder.alloc(h_order.size() * 4, false, s));
+			BLMX_HIP(hipMemcpyAsync(d_gorder.p, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, s));
+			hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3((unsigned)h_order.size()), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(),
+			                   d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>(),
+			                   d_gorder.as<uint32_t>());
+			BLMX_HIP(hipGetLastError());
+		}
 		std::vector<uint32_t> h_fbcnt(ngroups);
 		BLMX_HIP(hipMemcpyAsync(h_fbcnt.data(), d_fbcnt.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
 		levels_used = read_scalar(d_lvmax.as<int>(), s);
@@ -1359,20 +1565,22 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		if (F_lds) {
 			BLMX_HIP(d_fboff.alloc((size_t)ngroups * 8, false, s));
 			BLMX_HIP(hipMemcpyAsync(d_fboff.p, h_fboff.data(), (size_t)ngroups * 8, hipMemcpyHostToDevice, s));
-			BLMX_HIP(d_fball.alloc((F_lds + 1) * 4, false, s));
+			BLMX_HIP(d_fball.alloc((F_lds + 1) * 8, false, s));
 			hipLaunchKernelGGL(k_fb_collect, dim3(ngroups), dim3(256), 0, s, d_gpre.as<uint64_t>(), d_fbcnt.as<uint32_t>(), d_fboff.as<uint64_t>(),
-			                   d_lA.as<uint32_t>(), ngroups, d_fball.as<uint32_t>());
+			                   d_lA.as<uint32_t>(), ngroups, d_fball.as<uint64_t>());
 			BLMX_HIP(hipGetLastError());
 		}
 		BLMX_HIP(hipStreamSynchronize(s));
 	}
 	// global path: seeded with the keys of the large groups only (all keys when the LDS path is unused)
+	if (keys_large && N >= 0xffffffffull)
+		throw StatusError{BLMX_ELIMIT, "the global MPHF level kernels index keys with 32 bits (an MPHF group of 2^32 keys or more, or BLIGHT_BUILD_NO_LDS)"};
 	uint64_t count = keys_large;
 	const uint32_t* cur = nullptr;
 	uint32_t* nxt = nullptr;
 	uint64_t F = 0;
 	DevBuf d_seed, d_seedoff;
-	if (keys_large && n_small) {
+	if (keys_large && (n_small || !h_sliced.empty())) {
 		std::vector<uint64_t> h_seedoff(ngroups, 0);
 		uint64_t o = 0;
 		for (uint32_t g = 0; g < ngroups; g++) {
@@ -1406,18 +1614,24 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		if (level == kLevels - 1)
 			F = count;
 	}
-	// one fallback list: the global path's survivors followed by those of the LDS-built groups (sorted by key index below)
-	if (F_lds) {
+	// one fallback list of absolute key indices: the global path's survivors followed by those of the LDS-built groups
+	// (sorted by key index below)
+	const uint64_t* fb_all = nullptr;
+	{
 		DevBuf d_merge;
-		BLMX_HIP(d_merge.alloc((F + F_lds + 1) * 4, false, s));
+		BLMX_HIP(d_merge.alloc((F + F_lds + 1) * 8, false, s));
 		if (F)
-			BLMX_HIP(hipMemcpyAsync(d_merge.p, cur, F * 4, hipMemcpyDeviceToDevice, s));
-		BLMX_HIP(hipMemcpyAsync(d_merge.as<uint32_t>() + F, d_fball.p, F_lds * 4, hipMemcpyDeviceToDevice, s));
+			hipLaunchKernelGGL(k_widen_u32, dim3(grid_for(F)), dim3(kBlock), 0, s, cur, F, d_merge.as<uint64_t>());
+		if (F_lds)
+			BLMX_HIP(hipMemcpyAsync(d_merge.as<uint64_t>() + F, d_fball.p, F_lds * 8, hipMemcpyDeviceToDevice, s));
+		BLMX_HIP(hipGetLastError());
 		BLMX_HIP(hipStreamSynchronize(s));
 		std::swap(d_fball.p, d_merge.p);
 		std::swap(d_fball.bytes, d_merge.bytes);
-		cur = d_fball.as<uint32_t>();
+		fb_all = d_fball.as<uint64_t>();
 		F += F_lds;
+		if (F >= 0xffffffffull)
+			throw StatusError{BLMX_ELIMIT, "2^32 - 1 or more fallback keys"};
 	}
 
 	mark("K7 mphf levels");
@@ -1450,24 +1664,53 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	BLMX_HIP(ix.fb_ranks.alloc((F + 1) * 8, true, s));
 	ix.h_fb_group.clear();
 	if (F) {
-		BLMX_HIP(d_fbsorted.alloc(F * 4, false, s));
+		BLMX_HIP(d_fbsorted.alloc(F * 8, false, s));
 		size_t bytes = 0;
-		BLMX_HIP(rocprim::radix_sort_keys(nullptr, bytes, cur, d_fbsorted.as<uint32_t>(), (size_t)F, 0u, 32u, s));
+		unsigned idx_bits = 1;
+		while (idx_bits < 64 && (N >> idx_bits))
+			idx_bits++;
+		BLMX_HIP(rocprim::radix_sort_keys(nullptr, bytes, fb_all, d_fbsorted.as<uint64_t>(), (size_t)F, 0u, idx_bits, s));
 		void* tmp = sc.get(bytes);
-		BLMX_HIP(rocprim::radix_sort_keys(tmp, bytes, cur, d_fbsorted.as<uint32_t>(), (size_t)F, 0u, 32u, s));
+		BLMX_HIP(rocprim::radix_sort_keys(tmp, bytes, fb_all, d_fbsorted.as<uint64_t>(), (size_t)F, 0u, idx_bits, s));
 		BLMX_HIP(d_fk.alloc(F * 8 * KW, false, s));
 		BLMX_HIP(d_frank.alloc(F * 8, false, s));
 		BLMX_HIP(d_fgrp.alloc(F * 4, false, s));
-		hipLaunchKernelGGL((k_fb_prepare<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), d_fbsorted.as<uint32_t>(), F,
+		hipLaunchKernelGGL((k_fb_prepare<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), d_fbsorted.as<uint64_t>(), F,
 		                   d_gpopc.as<uint64_t>(), d_fk.as<uint64_t>(), d_frank.as<uint64_t>(), d_fgrp.as<uint32_t>());
 		BLMX_HIP(hipGetLastError());
+		// table order = (group, key, input order).  The entries arrive in input order (= group, position), so two or three
+		// STABLE radix sorts do it: by the key (low word, then high word), then by the group -- a comparison sort through an
+		// indirect comparator took 100 ms for the 3.7e7 fallback keys of the skewed human-scale input.
 		BLMX_HIP(d_perm.alloc(F * 4, false, s));
-		rocprim::counting_iterator<uint32_t> iota(0);
-		FbLess<KW> less{d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>()};
-		bytes = 0;
-		BLMX_HIP(rocprim::merge_sort(nullptr, bytes, iota, d_perm.as<uint32_t>(), (size_t)F, less, s));
-		tmp = sc.get(bytes);
-		BLMX_HIP(rocprim::merge_sort(tmp, bytes, iota, d_perm.as<uint32_t>(), (size_t)F, less, s));
+		{
+			DevBuf d_k0, d_k1, d_p0, d_p1;
+			BLMX_HIP(d_k0.alloc(F * 8, false, s));
+			BLMX_HIP(d_k1.alloc(F * 8, false, s));
+			BLMX_HIP(d_p0.alloc(F * 4, false, s));
+			BLMX_HIP(d_p1.alloc(F * 4, false, s));
+			auto sort_by = [&](const uint64_t* kin, const uint32_t* pin, uint32_t* pout, unsigned bits) {
+				size_t nb = 0;
+				BLMX_HIP(rocprim::radix_sort_pairs(nullptr, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)F, 0u, bits, s));
+				void* t2 = sc.get(nb);
+				BLMX_HIP(rocprim::radix_sort_pairs(t2, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)F, 0u, bits, s));
+			};
+			hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(F)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), (const uint32_t*)nullptr, F,
+			                   KW, 0, d_k0.as<uint64_t>(), d_p0.as<uint32_t>());
+			sort_by(d_k0.as<uint64_t>(), d_p0.as<uint32_t>(), d_p1.as<uint32_t>(), 64u);
+			uint32_t* cur_p = d_p1.as<uint32_t>();
+			uint32_t* other_p = d_p0.as<uint32_t>();
+			if (KW == 2) {
+				hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(F)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), cur_p, F, KW, 1,
+				                   d_k0.as<uint64_t>(), (uint32_t*)nullptr);
+				sort_by(d_k0.as<uint64_t>(), cur_p, other_p, 64u);
+				std::swap(cur_p, other_p);
+			}
+			hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(F)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), cur_p, F, KW, 2,
+			                   d_k0.as<uint64_t>(), (uint32_t*)nullptr);
+			sort_by(d_k0.as<uint64_t>(), cur_p, d_perm.as<uint32_t>(), 32u);
+			BLMX_HIP(hipGetLastError());
+			BLMX_HIP(hipStreamSynchronize(s));
+		}
 		BLMX_HIP(d_tgrp.alloc(F * 4, false, s));
 		BLMX_HIP(d_gfbstart.alloc((size_t)ngroups * 8, true, s));
 		BLMX_HIP(d_gfbcount.alloc((size_t)ngroups * 4, true, s));
@@ -1484,7 +1727,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		BLMX_HIP(hipStreamSynchronize(s));
 		for (uint32_t g = 0; g < ngroups; g++) {
 			ix.h_groups[g].fb_start = h_fs[g];
-			ix.h_groups[g].fb_count = h_fc[g];
+			ix.h_groups[g].fb_count = h_fc[g] ? h_fc[g] - (uint32_t)h_fs[g] : 0;
 		}
 	}
 	// final group table (with fallback ranges); a shard's IDs are global: add the key count of all lower groups
@@ -1508,7 +1751,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			hipLaunchKernelGGL((k_fill_positions<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
 			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>());
 		if (F)
-			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint32_t>(), F,
+			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint64_t>(), F,
 			                   ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(),
 			                   d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, id_base, d_field.as<uint32_t>());
 		if (N)
@@ -1530,7 +1773,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	st.shard_world = world;
 	st.shard_group_lo = glo;
 	st.shard_group_hi = ghi;
-	st.mphf_groups_lds_built = (uint32_t)n_small;
+	st.mphf_groups_lds_built = (uint32_t)(n_small + h_sliced.size());
 	st.largest_mphf = largest_mphf;
 	st.positions_total_size = total_pos;
 	st.total_nt = total_nt;

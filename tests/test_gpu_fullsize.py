@@ -258,3 +258,40 @@ def test_k63_strand_symmetry_and_reads(big63):
     assert (fwd >= 0).all()
     if "ids" in big63:  # the sequence front end and the k-mer batch path agree
         assert np.array_equal(fwd, big63["ids"][: fwd.size].cpu().numpy())
+
+
+def test_more_than_2_pow_32_kmers():
+    """An index of 4.4e9 31-mers on one GPU: k-mer counts and IDs are 64-bit throughout (32-bit quantities are per MPHF group and
+    per batch).  Indexed k-mers are found with IDs in [0, N) -- some beyond 2^32 --, random ones are absent, the host-buffer path
+    (which carries such IDs as 64-bit words over PCIe) agrees with the device path, and a sample equals the CPU oracle's query
+    path on the exported image."""
+    import torch
+    import blight_amd as B
+    import bench
+    k, m, n, b = 31, 9, 14, 6
+    N = 4_400_000_000
+    dev = torch.device("cuda", 0)
+    ascii_, offs, total = bench.synth_unitigs(torch, dev, N, k, 9)
+    torch.cuda.synchronize()
+    ix = B.kmer_Set_Light(k, m, n, 6, 1, b)
+    ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+    st = ix.stats()
+    N = st["number_kmer"]  # (the generator trims to whole unitigs)
+    assert abs(N - 4_400_000_000) < 1_000_000 and N > (1 << 32)
+    nq = 20_000_000
+    q, is_pos = bench.synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, 91, 1, 0.5)
+    del ascii_
+    ids = torch.empty(nq, device=dev, dtype=torch.int64)
+    ix.query_kmers_device(q.data_ptr(), nq, ids.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    found = ids >= 0
+    assert bool((found == is_pos).all().item())
+    assert int(ids.max().item()) < N and int(ids.max().item()) >= (1 << 32)
+    h_q = q[:3_000_000].cpu().numpy().view(np.uint64).reshape(-1)
+    h_ids = ids[:3_000_000].cpu().numpy()
+    assert np.array_equal(ix.query_kmer_hash(h_q), h_ids)
+    assert np.array_equal(ix.query_kmer_bool(h_q[:100000]), h_ids[:100000] >= 0)
+    orc, _ = bench.import_oracle(ix, st, k, m, n, b)
+    assert np.array_equal(orc.query_kmers(h_q[:400000], threads=8), h_ids[:400000])
+    orc.close()
+    ix.close()

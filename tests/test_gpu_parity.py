@@ -243,9 +243,10 @@ def test_binned_batch_query_equals_direct(B, O, k, m, n, b, kb):
     assert ix.query_kmer_hash(np.zeros(0, np.uint64)).size == 0
 
 
-def test_both_mphf_build_paths(B, O, monkeypatch):
-    """BBHash levels are built either by one workgroup per group in LDS (groups of up to ~1.18 M keys, in 1-4 slices) or by
-    the global level kernels (larger groups); both must give the oracle's arrays, alone and mixed inside one index."""
+def test_all_mphf_build_paths(B, O, monkeypatch):
+    """BBHash levels are built by one workgroup per group in LDS (groups of up to ~1.18 M keys, in 1-4 slices), by one workgroup
+    per (level, slice) for larger groups, or by the global level kernels (test hook BLIGHT_BUILD_NO_LDS: 1 = every group, 2 = the
+    large groups); all must give the oracle's arrays, alone and mixed inside one index."""
     c = G.Case("dup_k31_m7_n5_b6")  # exercises 16 levels + fallback
     for no_lds in ("0", "1"):
         monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", no_lds)
@@ -253,18 +254,28 @@ def test_both_mphf_build_paths(B, O, monkeypatch):
         assert (ix.stats()["mphf_groups_lds_built"] > 0) == (no_lds == "0")
         assert np.array_equal(ix.query_sequences_hash(c.seqs), c.ids)
         _check_against_oracle_arrays(ix, O.Oracle(c.k, c.m, c.n, c.b, c.seqs))
-    monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", "0")
-    # mixed: a 3-letter source skews the minimizers, so some of the 4 groups exceed the LDS budget and some do not
+    # a 3-letter source skews the minimizers, so some of the 4 groups exceed the single-workgroup budget and some do not;
+    # duplicated unitigs push keys through all 16 levels into the fallback table of the large groups too
     rng = np.random.default_rng(21)
     seqs = [_rand_seq(rng, 31 + int(rng.integers(20, 400)), "ACG") for _ in range(20000)]
+    seqs += seqs[:300]
     k, m, n, b = 31, 9, 2, 6
-    ix = _build(B, k, m, n, b, seqs)
-    st = ix.stats()
     orc = O.Oracle(k, m, n, b, seqs)
     nk = orc.arrays()["g_nkeys"]
-    assert 0 < st["mphf_groups_lds_built"] < int((nk > 0).sum()), (st["mphf_groups_lds_built"], nk.tolist())
-    _check_against_oracle_arrays(ix, orc)
-    assert np.array_equal(ix.query_sequences_hash(seqs[:500]), np.concatenate([orc.query_sequence(s) for s in seqs[:500]]))
+    nonempty = int((nk > 0).sum())
+    want = np.concatenate([orc.query_sequence(s) for s in seqs[:500]])
+    for no_lds, lds_built in (("0", nonempty), ("2", None), ("1", 0)):
+        monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", no_lds)
+        ix = _build(B, k, m, n, b, seqs)
+        st = ix.stats()
+        if lds_built is None:
+            assert 0 < st["mphf_groups_lds_built"] < nonempty, (st["mphf_groups_lds_built"], nk.tolist())
+        else:
+            assert st["mphf_groups_lds_built"] == lds_built
+        assert st["fallback_keys"] > 0
+        _check_against_oracle_arrays(ix, orc)
+        assert np.array_equal(ix.query_sequences_hash(seqs[:500]), want)
+    monkeypatch.setenv("BLIGHT_BUILD_NO_LDS", "0")
 
 
 @pytest.mark.parametrize("k,m,n,b,kb", [(31, 9, 7, 6, 8), (63, 9, 7, 8, 16)])
