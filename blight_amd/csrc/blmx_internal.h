@@ -245,6 +245,7 @@ struct Index {
 	int tune_mini_handoff = -1;  // partition pass hands the minimizers to the query kernel: 1 / 0 / -1 = automatic
 	int tune_query_heads = 1;    // 0 = query kernels read the full group descriptor instead of the compact 32-B head
 	int tune_reads_mode = 0;     // sequence / file queries: 0 = automatic, 1 = always fused front end + query, 2 = always front end -> binned pipeline
+	uint32_t staged_tile = 0;    // tile of the last blmx_partition_device (blmx_gather_ids_device reads the order back tile by tile)
 	int tune_partition = 0;      // batch partition: 0 / 2 = exact (histogram, scan, scatter), 1 = one pass into fixed-capacity bins
 	int tune_slot_slack_pct = 0; // one-pass partition: slots per bin = mean occupancy + this many percent (0 = default 12)
 	int tune_narrow_ids = 1;     // host-buffer results cross PCIe as 32-bit words when every ID fits (0 = always 64-bit)
@@ -300,7 +301,8 @@ void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs
 
 // query (blmx_query.hip).  mode: 0 = IDs (query_kmer_hash / query_get_hash), 1 = positions (query_get_pos_unitig),
 // 2 = membership byte.  d_minis == nullptr -> minimizers are computed on the device.
-enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2, kQueryXcdMajor = 0x100 /* flag: XCD-major block order */ };
+enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2, kQueryIds32 = 3 /* IDs as 32-bit words, 0xffffffff = absent */,
+                 kQueryXcdMajor = 0x100 /* flag: XCD-major block order */ };
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
                   hipStream_t s);
 // Large batches: partition the queries by the top bits of their minimizer first (one counting pass), run the query

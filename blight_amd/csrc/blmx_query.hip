@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 	const uint64_t o = i;
 	if (mode == kQueryIds)
 		reinterpret_cast<int64_t*>(out)[o] = id;
+	else if (mode == kQueryIds32)
+		reinterpret_cast<uint32_t*>(out)[o] = (uint32_t)id;  // -1 -> 0xffffffff; the caller knows that every ID fits
 	else if (mode == kQueryPos)
 		reinterpret_cast<int32_t*>(out)[o] = posj;
 	else
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(256) void k_query_anyb(DeviceIndexView v, const uin
 	const uint64_t o = i;
 	if (mode == kQueryIds)
 		reinterpret_cast<int64_t*>(out)[o] = id;
+	else if (mode == kQueryIds32)
+		reinterpret_cast<uint32_t*>(out)[o] = (uint32_t)id;
 	else if (mode == kQueryPos)
 		reinterpret_cast<int32_t*>(out)[o] = posj;
 	else
@@ -369,6 +373,10 @@ constexpr int kBinBitsMax = 10;
 constexpr int kBinBitsDefault = 9;
 // queries per block in the partition passes: the scatter stages a whole tile (k-mers + bin ids) in LDS
 template <int KW> struct BinTile { static constexpr int value = 8192 / KW; };
+// (Tiles of 16384 k-mers -- possible when the minimizers are not staged in LDS -- with 1024 bins keep the (tile, bin) runs 16
+// k-mers long and make the query kernel 0.3 ms faster at C4 (4.66 -> 4.36 ms), but the gather then reads 1024 lines per tile
+// instead of 512, which no longer fit the CU's 32 KB L1: k_gather_ids 0.74 -> 1.05 ms, scatter +0.1 ms -- measured and dropped,
+// profiles/r02_exp_big_tile_c4.jsonl.)
 
 // minimizer -> partition bin.  Bins are minimizer prefixes; on a sharded index every bin that contains a shard boundary
 // is split there (at most 15 extra bins), so that bins stay monotone in the minimizer AND every bin belongs to exactly
@@ -386,11 +394,10 @@ struct BinMap {
 	}
 };
 
-template <int KW>
+template <int KW, int kTile>
 __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, BinMap bm, uint32_t nbins, const uint64_t* __restrict__ kmers,
                                                           uint64_t nq, uint32_t* __restrict__ minibuf, uint32_t* __restrict__ hist, uint32_t nblk)
 {
-	constexpr int kTile = BinTile<KW>::value;
 	__shared__ uint32_t s_hist[1 << kBinBitsMax];
 	for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads)
 		s_hist[b] = 0;
@@ -411,11 +418,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist(int k, int m, BinMap b
 }
 
 // the same histogram when the minimizers are already known (read front end): 4 B per k-mer instead of 23 m-mer hashes
-template <int KW>
+template <int KW, int kTile>
 __global__ __launch_bounds__(kBinThreads) void k_bin_hist_minis(BinMap bm, uint32_t nbins, const uint32_t* __restrict__ minis, uint64_t nq,
                                                                 uint32_t* __restrict__ hist, uint32_t nblk)
 {
-	constexpr int kTile = BinTile<KW>::value;
 	__shared__ uint32_t s_hist[1 << kBinBitsMax];
 	for (uint32_t b = threadIdx.x; b < nbins; b += kBinThreads)
 		s_hist[b] = 0;
@@ -434,13 +440,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_hist_minis(BinMap bm, uint3
 // Scatter with a tile-local sort in LDS: the tile's k-mers are first placed in bin order in LDS, then copied out so that
 // each (tile, bin) run is written as consecutive 8-B elements (64-128 B per run) instead of isolated 8-B stores
 // (measured: isolated stores wrote 2.8x the payload to HBM).  inv[i] = final position of query i (coalesced by i).
-template <int KW>
+template <int KW, int kTile>
 __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __restrict__ kmers, uint64_t nq, const uint32_t* __restrict__ minibuf,
                                                              BinMap bm, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
                                                              uint32_t nblk, uint32_t nbins, uint64_t* __restrict__ sorted,
                                                              uint32_t* __restrict__ sorted_minis, uint32_t* __restrict__ inv)
 {
-	constexpr int kTile = BinTile<KW>::value;
 	constexpr int kNB = 1 << kBinBitsMax;
 	__shared__ uint64_t s_keys[kTile * KW];
 	__shared__ uint32_t s_mini[kTile];
@@ -669,15 +674,22 @@ __global__ __launch_bounds__(256) void k_query_slots_overflow(DeviceIndexView v,
 
 // out[i] = ids_sorted[inv[i]].  One block per partition TILE: the (tile, bin) runs written by k_bin_scatter are consumed by
 // the block that covers the same tile, so each 64-B line of ids_sorted is fetched once by one CU instead of by many.
-template <int TILE>
-__global__ __launch_bounds__(kBinThreads) void k_gather_ids(const int64_t* __restrict__ ids_sorted, const uint32_t* __restrict__ inv, uint64_t nq,
+// NARROW: the ordered IDs are 32-bit words (0xffffffff = absent), written so by the query kernel when every ID fits
+template <int TILE, bool NARROW>
+__global__ __launch_bounds__(kBinThreads) void k_gather_ids(const void* __restrict__ ids_sorted, const uint32_t* __restrict__ inv, uint64_t nq,
                                                             int64_t* __restrict__ out)
 {
 	const uint64_t base = (uint64_t)blockIdx.x * TILE;
 	for (int it = 0; it < TILE / kBinThreads; it++) {
 		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
-		if (i < nq)
-			out[i] = ids_sorted[inv[i]];
+		if (i < nq) {
+			if constexpr (NARROW) {
+				const uint32_t v = reinterpret_cast<const uint32_t*>(ids_sorted)[inv[i]];
+				out[i] = v == 0xffffffffu ? -1 : (int64_t)v;
+			} else {
+				out[i] = reinterpret_cast<const int64_t*>(ids_sorted)[inv[i]];
+			}
+		}
 	}
 }
 
@@ -703,7 +715,7 @@ namespace {
 
 struct PartitionPlan {
 	BinMap bm;
-	uint32_t nbins, nblk;
+	uint32_t nbins, nblk, tile;
 	bool handoff;
 };
 
@@ -724,16 +736,42 @@ void partition_end(Index& ix, hipStream_t s)
 }
 
 // k_bin_hist -> scan -> k_bin_scatter.  d_sorted / d_inv are the outputs; d_sorted_minis may be null.
+template <int KW, int TILE>
+void partition_launch(Index& ix, const PartitionPlan& pl, const uint64_t* km, const uint32_t* d_minis_in, uint64_t nq, void* d_sorted, uint32_t* d_sorted_minis,
+                      uint32_t* d_inv, hipStream_t s)
+{
+	const uint32_t nblk = pl.nblk, nbins = pl.nbins;
+	const size_t nh = (size_t)nbins * nblk;
+	const uint32_t* minibuf = d_minis_in ? d_minis_in : ix.b_bins.as<uint32_t>();
+	if (d_minis_in)
+		hipLaunchKernelGGL((k_bin_hist_minis<KW, TILE>), dim3(nblk), dim3(kBinThreads), 0, s, pl.bm, nbins, d_minis_in, nq, ix.b_hist.as<uint32_t>(), nblk);
+	else
+		hipLaunchKernelGGL((k_bin_hist<KW, TILE>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, pl.bm, nbins, km, nq,
+		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
+	BLMX_HIP(hipGetLastError());
+	ix.prof_mark(2, s);
+	size_t bytes = 0;
+	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
+	ensure_buf(ix.b_tmp, bytes, s);
+	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
+	ix.prof_mark(3, s);
+	hipLaunchKernelGGL((k_bin_scatter<KW, TILE>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm, ix.b_hist.as<uint32_t>(),
+	                   ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
+	BLMX_HIP(hipGetLastError());
+	ix.prof_mark(4, s);
+}
+
 PartitionPlan partition_batch(Index& ix, const void* d_kmers, const uint32_t* d_minis_in, uint64_t nq, bool owner_bins, void* d_sorted,
                               uint32_t* d_sorted_minis, uint32_t* d_inv, hipStream_t s)
 {
 	const int mbits = 2 * (int)ix.prm.m - 1;
+	PartitionPlan pl;
+	pl.handoff = d_sorted_minis != nullptr;
 	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsDefault;
 	int tbits = mbits < want_bits ? mbits : want_bits;
 	const uint32_t nbound = (owner_bins && ix.shard_world > 1) ? ix.shard_world - 1 : 0;
 	while (tbits > 1 && (1u << tbits) + nbound > (1u << kBinBitsMax))  // the kernels hold at most 2^kBinBitsMax bins
 		tbits--;
-	PartitionPlan pl;
 	pl.bm.shift = mbits - tbits;
 	pl.bm.nbound = 0;
 	if (owner_bins && ix.shard_world > 1) {  // split the bins at the shard boundaries (first minimizer of each owner)
@@ -743,54 +781,37 @@ PartitionPlan partition_batch(Index& ix, const void* d_kmers, const uint32_t* d_
 			pl.bm.bound[pl.bm.nbound++] = ix.shard_bounds[r] << ix.gshift;
 	}
 	pl.nbins = (1u << tbits) + pl.bm.nbound;
-	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
-	pl.nblk = (uint32_t)((nq + tile - 1) / tile);
-	pl.handoff = d_sorted_minis != nullptr;
-	const uint32_t nblk = pl.nblk, nbins = pl.nbins;
-	const size_t nh = (size_t)nbins * nblk;
+	pl.tile = (uint32_t)(BinTile<1>::value / ix.KW);
+	pl.nblk = (uint32_t)((nq + pl.tile - 1) / pl.tile);
+	const size_t nh = (size_t)pl.nbins * pl.nblk;
 	if (!d_minis_in)
 		ensure_buf(ix.b_bins, nq * 4, s);
 	ensure_buf(ix.b_hist, nh * 4, s);
 	ensure_buf(ix.b_offs, nh * 4, s);
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
-	const uint32_t* minibuf = d_minis_in ? d_minis_in : ix.b_bins.as<uint32_t>();
-	if (d_minis_in) {
-		if (ix.KW == 1)
-			hipLaunchKernelGGL((k_bin_hist_minis<1>), dim3(nblk), dim3(kBinThreads), 0, s, pl.bm, nbins, d_minis_in, nq, ix.b_hist.as<uint32_t>(), nblk);
-		else
-			hipLaunchKernelGGL((k_bin_hist_minis<2>), dim3(nblk), dim3(kBinThreads), 0, s, pl.bm, nbins, d_minis_in, nq, ix.b_hist.as<uint32_t>(), nblk);
-	} else if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_hist<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, pl.bm, nbins, km, nq,
-		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
-	else
-		hipLaunchKernelGGL((k_bin_hist<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, pl.bm, nbins, km, nq,
-		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
-	BLMX_HIP(hipGetLastError());
-	ix.prof_mark(2, s);
-	size_t bytes = 0;
-	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
-	ensure_buf(ix.b_tmp, bytes, s);
-	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
-	ix.prof_mark(3, s);
 	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_scatter<1>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm,
-		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
+		partition_launch<1, BinTile<1>::value>(ix, pl, km, d_minis_in, nq, d_sorted, d_sorted_minis, d_inv, s);
 	else
-		hipLaunchKernelGGL((k_bin_scatter<2>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm,
-		                   ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);
-	BLMX_HIP(hipGetLastError());
-	ix.prof_mark(4, s);
+		partition_launch<2, BinTile<2>::value>(ix, pl, km, d_minis_in, nq, d_sorted, d_sorted_minis, d_inv, s);
 	return pl;
 }
 
-void gather_ids(const Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s)
+// out[i] = ids_ordered[inv[i]]; `tile` = the partition tile the order was made with (a gather block covers one tile, so the runs
+// a scatter block wrote are read back by one CU); narrow = the ordered IDs are 32-bit words
+void gather_ids(const Index& ix, const void* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, uint32_t tile, bool narrow, hipStream_t s)
 {
-	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
 	const uint32_t nblk = (uint32_t)((nq + tile - 1) / tile);
-	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_gather_ids<BinTile<1>::value>), dim3(nblk), dim3(kBinThreads), 0, s, d_ids_sorted, d_inv, nq, d_out);
-	else
-		hipLaunchKernelGGL((k_gather_ids<BinTile<2>::value>), dim3(nblk), dim3(kBinThreads), 0, s, d_ids_sorted, d_inv, nq, d_out);
+#define BLMX_G(T)                                                                                                                                  \
+	if (tile == (uint32_t)(T)) {                                                                                                                   \
+		if (narrow)                                                                                                                                \
+			hipLaunchKernelGGL((k_gather_ids<T, true>), dim3(nblk), dim3(kBinThreads), 0, s, d_ids_sorted, d_inv, nq, d_out);                    \
+		else                                                                                                                                       \
+			hipLaunchKernelGGL((k_gather_ids<T, false>), dim3(nblk), dim3(kBinThreads), 0, s, d_ids_sorted, d_inv, nq, d_out);                   \
+	}
+	BLMX_G(BinTile<1>::value)
+	else BLMX_G(BinTile<2>::value)
+	else throw StatusError{BLMX_EINVAL, "internal: unknown partition tile"};
+#undef BLMX_G
 	BLMX_HIP(hipGetLastError());
 }
 
@@ -883,7 +904,7 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 		launch_query_slots_kw<2>(ix, sp, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.as<int64_t>(), s);
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(5, s);
-	gather_ids(ix, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out, s);
+	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, tile, false, s);
 	ix.prof_mark(6, s);
 	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 2) {  // bin occupancy of this batch (synchronises)
 		std::vector<uint32_t> h(sp.nbins + 1);
@@ -931,12 +952,14 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	ensure_buf(ix.b_sorted, nq * 8 * (size_t)ix.KW, s);
 	ensure_buf(ix.b_inv, nq * 4, s);
 	ensure_buf(ix.b_ids, nq * 8, s);
-	partition_batch(ix, d_kmers, d_minis, nq, false, ix.b_sorted.p, d_sorted_minis, ix.b_inv.as<uint32_t>(), s);
+	const PartitionPlan pl = partition_batch(ix, d_kmers, d_minis, nq, false, ix.b_sorted.p, d_sorted_minis, ix.b_inv.as<uint32_t>(), s);
 	// (storing each ID straight into the caller's slot from k_query was measured 2.8 ms SLOWER per 1e8 queries than this
 	// separate gather: 1e8 scattered 8-B stores cost more than reading the IDs back through the inverse permutation)
-	launch_query(ix, ix.b_sorted.p, d_sorted_minis, nq, ix.b_ids.p, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
+	// The ordered IDs are 32-bit words when every ID fits: half the bytes written by the query kernel and gathered at random.
+	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull && ix.prm.bits_saved <= 8;
+	launch_query(ix, ix.b_sorted.p, d_sorted_minis, nq, ix.b_ids.p, (QueryMode)((narrow ? kQueryIds32 : kQueryIds) | kQueryXcdMajor), s);
 	ix.prof_mark(5, s);
-	gather_ids(ix, ix.b_ids.as<int64_t>(), ix.b_inv.as<uint32_t>(), nq, d_out, s);
+	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, pl.tile, narrow, s);
 	ix.prof_mark(6, s);
 	partition_end(ix, s);
 }
@@ -964,6 +987,7 @@ void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorte
 	std::lock_guard<std::mutex> lock(ix.bin_mu);
 	partition_begin(ix, s);
 	const PartitionPlan pl = partition_batch(ix, d_kmers, nullptr, nq, true, d_sorted, nullptr, d_inv, s);
+	ix.staged_tile = pl.tile;
 	if (d_rank_counts) {
 		uint32_t first_bin[18];
 		first_bin[0] = 0;
@@ -992,7 +1016,7 @@ void launch_gather_ids(Index& ix, const int64_t* d_ids_sorted, const uint32_t* d
 {
 	if (nq == 0)
 		return;
-	gather_ids(ix, d_ids_sorted, d_inv, nq, d_out, s);
+	gather_ids(ix, d_ids_sorted, d_inv, nq, d_out, ix.staged_tile ? ix.staged_tile : (uint32_t)(BinTile<1>::value / ix.KW), false, s);
 }
 
 void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s)

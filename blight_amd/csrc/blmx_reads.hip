@@ -48,7 +48,7 @@ __device__ __forceinline__ void front_block(const uint8_t* __restrict__ bytes, u
 {
 	__shared__ uint64_t s_src[kFrontWords];
 	__shared__ uint64_t s_bad[kFrontWords / 2 + 2];
-	__shared__ int32_t s_pow[2][kFrontBlock + kFrontHalo + 2];
+	__shared__ int32_t s_pow[kFrontBlock / 64][2][kFrontHalo + 64];  // per wave: two generations of prefix minima
 	const int tid = (int)threadIdx.x;
 	const int w = k - m + 1;
 	// ---- characters -> 2-bit words + invalid-character bitmap: a lane encodes FOUR characters (one dword load) into one byte
@@ -58,11 +58,13 @@ __device__ __forceinline__ void front_block(const uint8_t* __restrict__ bytes, u
 	const int need = kFrontBlock + k - 1;  // characters that the block's k-mers cover
 	const int nquads = (need + 3) / 4;
 	uint8_t* s_src8 = reinterpret_cast<uint8_t*>(s_src);
-	if (tid < (int)(sizeof(s_bad) / 8))
-		s_bad[tid] = 0;
+	// word j of the invalid-character bitmap belongs to the loader lanes 16 j .. 16 j + 15 -- one wave --, so its first lane zeroes
+	// it right before the others may OR into it (LDS operations of a wave execute in order: no barrier)
+	if ((tid & 15) == 0 && (tid >> 4) < (int)(sizeof(s_bad) / 8))
+		s_bad[tid >> 4] = 0;
 	for (int q = nquads + tid; q < kFrontWords * 8; q += kFrontBlock)  // bytes behind the last character (funnel shifts read them)
 		s_src8[(q & ~7) | (7 - (q & 7))] = 0;
-	__syncthreads();
+	__builtin_amdgcn_wave_barrier();
 	if (tid < nquads) {
 		const uint64_t p = base + 4 * (uint64_t)tid;
 		uint32_t v = 0x41414141u;  // 'A': positions at or beyond `total`
@@ -80,29 +82,35 @@ __device__ __forceinline__ void front_block(const uint8_t* __restrict__ bytes, u
 			atomicOr(reinterpret_cast<unsigned long long*>(&s_bad[tid >> 4]), (unsigned long long)bad4 << (4 * (tid & 15)));
 	}
 	__syncthreads();
-	// ---- one m-mer hash per position (entries e = 0 .. kFrontBlock + w - 2)
-	for (int e = tid; e < kFrontBlock + w - 1; e += kFrontBlock) {
+	// ---- m-mer hashes and window minima, WAVE by wave: a wave owns 64 positions and hashes the 64 + w - 1 m-mers they need
+	// itself (a third more hashes than sharing them across the block), so that the ceil(log2 w) + 1 rounds of prefix minima
+	// need no workgroup barrier at all -- LDS operations of one wave execute in order.  (The block-wide version spent its
+	// time in seven barriers per 512 positions.)
+	// M_{p+1}[e] = min(M_p[e], M_p[e + 2^p]); the window of w m-mers is the disjoint union of the blocks named by the binary
+	// digits of w.
+	const int lane = tid & 63;
+	int32_t(*pw)[kFrontHalo + 64] = s_pow[tid >> 6];
+	const int nent = 64 + w - 1;
+	for (int el = lane; el < nent; el += 64) {
+		const int e = (tid & ~63) + el;
 		const int wd = e >> 5, sh = 2 * (e & 31);
 		const uint32_t f = (uint32_t)(funnel_left(s_src[wd], s_src[wd + 1], sh) >> (64 - 2 * m));
 		const uint32_t r = (uint32_t)(rc_digits64((uint64_t)f) >> (64 - 2 * m));
-		s_pow[0][e] = revhash32(((__popc(f) & 1) ? f : r) >> 1);
+		pw[0][el] = revhash32(((__popc(f) & 1) ? f : r) >> 1);
 	}
-	__syncthreads();
-	// ---- window minimum from power-of-two prefix minima: M_{p+1}[e] = min(M_p[e], M_p[e + 2^p]); the window of w m-mers is
-	// the disjoint union of the blocks named by the binary digits of w
-	const int L = kFrontBlock + w - 1;
+	__builtin_amdgcn_wave_barrier();
 	int32_t mn = 0x7fffffff;
 	int cur = 0, off = 0;
 	for (int p2 = 0; (1 << p2) <= w; p2++) {
 		const int step = 1 << p2;
 		if (w & step) {
-			mn = min(mn, s_pow[cur][tid + off]);
+			mn = min(mn, pw[cur][lane + off]);
 			off += step;
 		}
 		if ((2 << p2) <= w) {  // another level is needed
-			for (int e = tid; e + step < L; e += kFrontBlock)
-				s_pow[cur ^ 1][e] = min(s_pow[cur][e], s_pow[cur][e + step]);
-			__syncthreads();
+			for (int el = lane; el + step < nent; el += 64)
+				pw[cur ^ 1][el] = min(pw[cur][el], pw[cur][el + step]);
+			__builtin_amdgcn_wave_barrier();
 			cur ^= 1;
 		}
 	}

@@ -303,11 +303,13 @@ def test_tuning_knobs_do_not_change_results(B, O, k, kb, b):
     ix.set_query_binning(1)
     for heads in (1, 0):
         for handoff in (-1, 0, 1):
-            for bits in (0, 3, 10):
+            for bits, narrow in ((0, 1), (3, 0), (10, 1)):
                 ix.set_tuning("query_heads", heads)
                 ix.set_tuning("mini_handoff", handoff)
                 ix.set_tuning("bin_bits", bits)
-                assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), (heads, handoff, bits)
+                ix.set_tuning("narrow_ids", narrow)   # ordered IDs as 32-bit or 64-bit words
+                assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), (heads, handoff, bits, narrow)
+        ix.set_tuning("narrow_ids", 1)
         ix.set_tuning("reads_mode", 2)
         assert np.array_equal(ix.query_sequences_hash(reads), want_reads)
         ix.set_tuning("reads_mode", 1)
