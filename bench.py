@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip every CPU leg)")
     ap.add_argument("--seed", type=int, default=4)
     ap.add_argument("--no-replicas-leg", action="store_true", help="N > 1, sharded: skip the secondary replicas measurement")
+    ap.add_argument("--no-slice-build", action="store_true", help="N > 1, native exchange: skip the construction-from-slices leg")
+    ap.add_argument("--rehearse-sharded", action="store_true",
+                    help="run the N > 1 code path (native RCCL exchange, construction from slices, replicas leg) with a world of one rank")
     ap.add_argument("--present", type=float, default=0.5, help="fraction of the queries that are indexed k-mers (headline: 0.5)")
     ap.add_argument("--skew", action="store_true", help="10 %% of the unitigs from a 2-symbol source (uneven buckets)")
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads of the sequence front-end leg (0 = skip)")
@@ -462,6 +465,11 @@ def host_kmer_legs(torch, ix, q, ids, kw):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 (RCCL prints its version banner
+    # there when a communicator is created) is sent to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch  # first: one HIP runtime for torch and the library
     import torch.distributed as dist
     import blight_amd
@@ -479,14 +487,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.rehearse_sharded  # a process group exists and the sharded code path runs
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
+        if world == 1:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        elif rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    effective_mode = args.mode if world > 1 else "single"
+    effective_mode = args.mode if multi else "single"
     k, m, n, b, n_kmers, nq = WORKLOADS[args.workload]
     n_kmers = args.kmers or n_kmers
     nq = args.queries or nq
@@ -499,7 +515,7 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     ref_sample = None
-    if world == 1 and args.cpu_seconds > 0 and kw == 1:
+    if not multi and args.cpu_seconds > 0 and kw == 1:
         # host copy of the first unitigs (~1.5e7 k-mers) for the reference calibration leg
         nu = min(offs.numel() - 1, 190_000)
         so = offs[: nu + 1].cpu().numpy()
@@ -570,7 +586,8 @@ def main():
         else:
             effective_mode = "sharded (native RCCL exchange behind the C ABI)"
     sharded = comm is not None or querier is not None
-    keep_input = (sharded and not args.no_replicas_leg) or (world == 1 and args.reads > 0)
+    slice_leg = comm is not None and not args.no_slice_build
+    keep_input = (sharded and not args.no_replicas_leg) or slice_leg or (not multi and args.reads > 0)
     if not keep_input:
         del ascii_
 
@@ -588,7 +605,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -598,20 +615,53 @@ def main():
         step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=("cpu" if rehearsal else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # ---- N > 1, sharded: also report the communication-free alternative (full index on every GPU, queries split), measured the
     # same way right after the sharded run ("report both").  `value` stays the sharded number.
+    # ---- N > 1, native exchange: the same shard built from THIS RANK'S SLICE of the unitigs only (consecutive pieces in rank order;
+    # super-k-mers travel to the owner of their MPHF group: blmx_build_sharded_from_device_sequences) must answer identically.
+    slice_build = None
+    if slice_leg:
+        cpu_or_dev = "cpu" if rehearsal else dev
+        nu = offs.numel() - 1
+        u0, u1 = nu * rank // world, nu * (rank + 1) // world
+        so = offs[u0:u1 + 1]
+        c0, c1 = int(so[0].item()), int(so[-1].item())
+        so = (so - so[0]).contiguous()
+        chars = ascii_[c0:c1]
+        ix2 = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
+        ix2.set_shard(rank, world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        comm.build_sharded_from_device(ix2, chars.data_ptr(), so.data_ptr(), u1 - u0, c1 - c0)
+        torch.cuda.synchronize()
+        ts = torch.tensor([time.perf_counter() - t0], device=cpu_or_dev, dtype=torch.float64)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        ids2 = torch.empty(nq, device=dev, dtype=torch.int64)
+        comm.query_kmers_sharded_device(ix2, q.data_ptr(), nq, ids2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        st2 = ix2.stats()
+        same = torch.tensor([1 if torch.equal(ids2, ids) and st2["local_number_kmer"] == st["local_number_kmer"] else 0], device=cpu_or_dev,
+                            dtype=torch.int32)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        slice_build = {"seconds": float(ts.item()), "whole_input_build_seconds_rank0": t_build, "unitigs_of_rank0": u1 - u0,
+                       "ids_equal_to_whole_input_build": bool(same.item()),
+                       "what": "every rank chops 1/%d of the unitigs; all-reduce of the group histograms, all-to-all-v of the super-k-mers" % world}
+        del ids2, chars, so
+        ix2.close()
+
     replicas = None
-    if sharded and keep_input:
+    if sharded and keep_input and not args.no_replicas_leg:
         ids_sharded = ids
         full = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
         full.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
@@ -643,7 +693,9 @@ def main():
     n_neg_found = int((found & ~is_pos).sum().item())
     n_pos = int(is_pos.sum().item())
     ok = n_pos_found == n_pos and int(ids.max().item()) < st["number_kmer"]
-    if world > 1:
+    if slice_build is not None:
+        ok = ok and slice_build["ids_equal_to_whole_input_build"]
+    if multi:
         okt = torch.tensor([1 if ok else 0], device=("cpu" if rehearsal else dev), dtype=torch.int32)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
@@ -658,11 +710,11 @@ def main():
             "config": {"workload": "%s%s: %d indexed %d-mers (seeded synthetic unitigs, k%d m%d n%d b%d), %d queries/step/GPU, "
                                    "%g%% indexed / %g%% random" % (args.workload, " skewed (every tenth unitig from {A,C})" if args.skew else "",
                                                                     st["number_kmer"], k, k, m, n, b, nq, 100 * args.present, 100 * (1 - args.present)),
-                       "parallelism": "1 GPU" if world == 1 else ("%s x%d" % (effective_mode, world)),
+                       "parallelism": "1 GPU" if not multi else ("%s x%d" % (effective_mode, world)),
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
                        "build_kmers_per_sec": st["number_kmer"] / t_build, "largest_mphf": st["largest_mphf"], "largest_bucket": st["largest_bucket"],
                        "mphf_groups_lds_built": st["mphf_groups_lds_built"], "mphf_groups": st["ngroups"], "fallback_keys": st["fallback_keys"]},
-            "roofline": roofline_block(args, k, kw, b, nq, stages, kern_ms, st) if world == 1 else
+            "roofline": roofline_block(args, k, kw, b, nq, stages, kern_ms, st) if not multi else
             {"bound": "hbm", "achieved": ALGO_BYTES.get(k, 145) * nq * world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
              "frac": ALGO_BYTES.get(k, 145) * nq / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
              "kernel": "whole sharded step (partition, exchange, k_query, exchange, gather) against the aggregate HBM peak"},
@@ -671,7 +723,7 @@ def main():
         }
         orc = None
         out["cpu_baseline"] = None
-        if world == 1 and args.cpu_seconds > 0:
+        if not multi and args.cpu_seconds > 0:
             try:
                 import numpy as np
                 orc, t_import = import_oracle(ix, st, k, m, n, b)
@@ -685,7 +737,7 @@ def main():
                     out["cpu_reference"] = cpu_reference_calibration(ref_sample[0], ref_sample[1], k, m, n, b) if ref_sample else None
                 except Exception as e:
                     out["cpu_reference"] = {"value": None, "kind": "reference", "sample": "failed: %r" % (e,)}
-        if world == 1 and args.reads > 0:
+        if not multi and args.reads > 0:
             try:
                 out["reads"] = reads_leg(torch, blight_amd, ix, dev, ascii_, total, k, args, orc)
             except Exception as e:
@@ -699,8 +751,13 @@ def main():
             orc.close()
         if replicas is not None:
             out["replicas"] = replicas
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        if slice_build is not None:
+            out["build_from_slices"] = slice_build
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if comm is not None:
+        comm.close()
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
-ABI_VERSION = 8  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
+ABI_VERSION = 9  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT, BLMX_ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 COMM_ID_BYTES = 128
 
@@ -105,6 +105,12 @@ def load_library():
     lib.blmx_comm_destroy.argtypes = [C.c_void_p]
     lib.blmx_comm_destroy.restype = None
     lib.blmx_query_kmers_sharded_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.blmx_build_sharded_from_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, _u64p, C.c_uint64]
+    lib.blmx_build_sharded_from_device_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+    lib.blmx_shard_build_begin.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _u64p]
+    lib.blmx_shard_build_begin_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, _u64p]
+    lib.blmx_shard_build_plan.argtypes = [C.c_void_p, _u64p, _u64p, _u64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.blmx_shard_build_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u64p, _u64p]
     lib.blmx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
@@ -181,6 +187,7 @@ class kmer_Set_Light:
             self._h = None
             _raise(rc, self._lib.blmx_create_error().decode())
         self._k, self._minimizer_length = k, minimizer_length
+        self.log2_mphf = log2_mphfs_number
         self.kmer_bytes = kmer_bytes or (8 if k <= 32 else 16)
 
     # -- lifetime
@@ -370,6 +377,29 @@ class kmer_Set_Light:
     def set_shard(self, rank, world):
         self._check(self._lib.blmx_set_shard(self._h, rank, world))
 
+    # -- sharded construction from this rank's own slice of the input, phase by phase (bring your own transport)
+    def shard_build_begin(self, seqs):
+        """chop the slice; returns (keys per MPHF group, super-k-mers) of it -- sum both over all ranks for shard_build_plan"""
+        buf, offs = _concat(seqs)
+        hist = np.zeros((1 << self.log2_mphf) + 1, dtype=np.uint64)
+        self._check(self._lib.blmx_shard_build_begin(self._h, buf, offs.ctypes.data_as(_u64p), len(offs) - 1, hist.ctypes.data_as(_u64p)))
+        return hist
+
+    def shard_build_plan(self, global_hist, world):
+        """-> (send_sk[world], send_words[world], device pointer of the meta words, device pointer of the packed nucleotides)"""
+        gh = np.ascontiguousarray(global_hist, dtype=np.uint64)
+        if gh.size != (1 << self.log2_mphf) + 1:
+            raise ValueError("global_hist must hold 2^log2_mphf + 1 words")
+        sk, words = np.zeros(world, np.uint64), np.zeros(world, np.uint64)
+        pm, pw = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.blmx_shard_build_plan(self._h, gh.ctypes.data_as(_u64p), sk.ctypes.data_as(_u64p), words.ctypes.data_as(_u64p),
+                                                    C.byref(pm), C.byref(pw)))
+        return sk, words, pm.value or 0, pw.value or 0
+
+    def shard_build_finish(self, d_meta_ptr, d_words_ptr, recv_sk, recv_words):
+        rs, rw = np.ascontiguousarray(recv_sk, dtype=np.uint64), np.ascontiguousarray(recv_words, dtype=np.uint64)
+        self._check(self._lib.blmx_shard_build_finish(self._h, d_meta_ptr, d_words_ptr, rs.ctypes.data_as(_u64p), rw.ctypes.data_as(_u64p)))
+
     def shard_bounds(self):
         world = self.stats()["shard_world"]
         b = np.zeros(world + 1, dtype=np.uint32)
@@ -425,6 +455,14 @@ class Comm:
     def query_kmers_sharded_device(self, index, d_kmers_ptr, nq, d_ids_ptr, stream=None):
         """collective: every rank calls it with its own batch; IDs in the caller's order"""
         index._check(self._lib.blmx_query_kmers_sharded_device(index._h, self._c, d_kmers_ptr, nq, d_ids_ptr, stream))
+
+    def build_sharded_from_sequences(self, index, seqs):
+        """collective: every rank passes ITS OWN consecutive slice of the input (rank order = input order)"""
+        buf, offs = _concat(seqs)
+        index._check(self._lib.blmx_build_sharded_from_sequences(index._h, self._c, buf, offs.ctypes.data_as(_u64p), len(offs) - 1))
+
+    def build_sharded_from_device(self, index, d_concat_ptr, d_offsets_ptr, nseq, total_len):
+        index._check(self._lib.blmx_build_sharded_from_device_sequences(index._h, self._c, d_concat_ptr, d_offsets_ptr, nseq, total_len))
 
     def close(self):
         if getattr(self, "_c", None):

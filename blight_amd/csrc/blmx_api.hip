@@ -83,6 +83,24 @@ void build_host(blmx_index* h, const char* concat, const uint64_t* offsets, uint
 	ix.built = true;
 }
 
+// host sequences -> device staging, then fn(d_ascii, d_offs, total)
+template <typename F>
+void with_staged_sequences(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, F&& fn)
+{
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	const uint64_t total = nseq ? offsets[nseq] : 0;
+	if (nseq && offsets[0] != 0)
+		throw StatusError{BLMX_EINVAL, "offsets[0] must be 0"};
+	DevBuf d_ascii, d_offs;
+	BLMX_HIP(d_ascii.alloc(total + 64, false, ix.stream));
+	BLMX_HIP(d_offs.alloc((nseq + 1) * 8, true, ix.stream));
+	if (total)
+		BLMX_HIP(hipMemcpyAsync(d_ascii.p, concat, total, hipMemcpyHostToDevice, ix.stream));
+	if (nseq)
+		BLMX_HIP(hipMemcpyAsync(d_offs.p, offsets, (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
+	fn(d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), total);
+}
+
 }  // namespace
 
 extern "C" {
@@ -174,6 +192,7 @@ void blmx_destroy(blmx_index* h)
 	(void)hipDeviceSynchronize();  // device-pointer calls may still be running on the caller's streams
 	destroy_host_front(h->ix.hf);
 	h->ix.hf = nullptr;
+	shard_build_abort(h->ix);
 	for (hipEvent_t e : h->ix.prof_ev)
 		if (e)
 			(void)hipEventDestroy(e);
@@ -573,6 +592,72 @@ int blmx_query_kmers_sharded_device(blmx_index* h, blmx_comm* c, const void* d_k
 	if (!h || !c || (nq && (!d_kmers || !d_ids)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] { query_kmers_sharded(h->ix, *reinterpret_cast<Comm*>(c), d_kmers, nq, d_ids, reinterpret_cast<hipStream_t>(stream)); });
+}
+
+int blmx_build_sharded_from_sequences(blmx_index* h, blmx_comm* c, const char* concat, const uint64_t* offsets, uint64_t nseq)
+{
+	if (!h || !c || (nseq && (!concat || !offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		with_staged_sequences(h->ix, concat, offsets, nseq, [&](const uint8_t* a, const uint64_t* o, uint64_t total) {
+			build_sharded(h->ix, *reinterpret_cast<Comm*>(c), a, o, nseq, total);
+		});
+	});
+}
+
+int blmx_build_sharded_from_device_sequences(blmx_index* h, blmx_comm* c, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq,
+                                             uint64_t total_len)
+{
+	if (!h || !c || (nseq && (!d_concat || !d_offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		BLMX_HIP(hipDeviceSynchronize());
+		build_sharded(h->ix, *reinterpret_cast<Comm*>(c), reinterpret_cast<const uint8_t*>(d_concat), d_offsets, nseq, total_len);
+	});
+}
+
+int blmx_shard_build_begin(blmx_index* h, const char* concat, const uint64_t* offsets, uint64_t nseq, uint64_t* hist_out)
+{
+	if (!h || !hist_out || (nseq && (!concat || !offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		with_staged_sequences(h->ix, concat, offsets, nseq,
+		                      [&](const uint8_t* a, const uint64_t* o, uint64_t total) { shard_build_begin(h->ix, a, o, nseq, total, hist_out); });
+	});
+}
+
+int blmx_shard_build_begin_device(blmx_index* h, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq, uint64_t total_len, uint64_t* hist_out)
+{
+	if (!h || !hist_out || (nseq && (!d_concat || !d_offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		BLMX_HIP(hipDeviceSynchronize());
+		shard_build_begin(h->ix, reinterpret_cast<const uint8_t*>(d_concat), d_offsets, nseq, total_len, hist_out);
+	});
+}
+
+int blmx_shard_build_plan(blmx_index* h, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta, const void** d_words)
+{
+	if (!h || !global_hist || !send_sk || !send_words || !d_meta || !d_words)
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		shard_build_plan(h->ix, global_hist, send_sk, send_words, d_meta, d_words);
+	});
+}
+
+int blmx_shard_build_finish(blmx_index* h, const void* d_meta_in, const void* d_words_in, const uint64_t* recv_sk, const uint64_t* recv_words)
+{
+	if (!h || !recv_sk || !recv_words)
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		BLMX_HIP(hipDeviceSynchronize());  // the caller's transport filled the incoming buffers
+		shard_build_finish(h->ix, d_meta_in, d_words_in, recv_sk, recv_words);
+		h->ix.built = true;
+	});
 }
 
 int blmx_set_query_binning(blmx_index* h, int policy)

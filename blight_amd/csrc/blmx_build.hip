@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <cmath>
 
 #include "blmx_internal.h"
@@ -248,6 +249,89 @@ __global__ void k_shard_flags(const uint32_t* __restrict__ sk_mini, uint64_t nsk
 	flags[i] = (g >= glo && g < ghi) ? 1 : 0;
 }
 
+// ---- sharded build from slices: super-k-mers travel to the rank that owns their MPHF group ------------------------------
+struct OwnerTable {
+	uint32_t world;
+	uint32_t bound[17];    // group boundaries (shard_bounds)
+	uint64_t seg_first[17];  // first entry of every segment in the owner-sorted (or source-ordered) list
+	uint64_t seg_word[17];   // first u64 word of every segment in the packed stream (each segment starts on a word)
+};
+
+__global__ void k_sk_owner(const uint32_t* __restrict__ sk_mini, uint64_t nsk, int gshift, OwnerTable t, uint32_t* __restrict__ owner)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nsk)
+		return;
+	const uint32_t g = sk_mini[i] >> gshift;
+	uint32_t r = 0;
+	while (r + 1 < t.world && g >= t.bound[r + 1])
+		r++;
+	owner[i] = r;
+}
+
+// first index of every owner in the sorted owner list (world + 1 binary searches)
+__global__ void k_owner_segments(const uint32_t* __restrict__ sorted_owner, uint64_t nsk, uint32_t world, uint64_t* __restrict__ seg_first)
+{
+	const uint32_t d = threadIdx.x;
+	if (d > world)
+		return;
+	uint64_t lo = 0, hi = nsk;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (sorted_owner[mid] < d)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	seg_first[d] = lo;
+}
+
+__device__ __forceinline__ uint32_t segment_of(const OwnerTable& t, uint64_t i)
+{
+	uint32_t r = 0;
+	while (r + 1 < t.world && i >= t.seg_first[r + 1])
+		r++;
+	return r;
+}
+
+// nt offsets of a running scan -> offsets inside a stream whose segments each start on a u64 word
+__global__ void k_segment_offsets(const uint64_t* __restrict__ nt_scan, uint64_t nsk, OwnerTable t, uint64_t* __restrict__ nt_out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nsk)
+		return;
+	const uint32_t r = segment_of(t, i);
+	nt_out[i] = nt_scan[i] - nt_scan[t.seg_first[r]] + 32 * t.seg_word[r];
+}
+
+// what travels next to the packed nucleotides: (minimizer << 32) | length in nt, in owner order
+__global__ void k_sk_meta(const uint32_t* __restrict__ order, const uint32_t* __restrict__ sk_mini, const uint64_t* __restrict__ len_nt, uint64_t nsk,
+                          uint64_t* __restrict__ meta)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nsk)
+		meta[i] = ((uint64_t)sk_mini[order[i]] << 32) | (uint64_t)(uint32_t)len_nt[i];
+}
+
+struct MetaLen {
+	__host__ __device__ uint64_t operator()(uint64_t meta) const { return meta & 0xffffffffull; }
+};
+
+// received (meta, running nt scan) -> the super-k-mer list the rest of the build works on
+__global__ void k_sk_from_meta(const uint64_t* __restrict__ meta, const uint64_t* __restrict__ nt_scan, uint64_t nsk, int k, OwnerTable t,
+                               uint64_t* __restrict__ sk_pos, uint64_t* __restrict__ sk_last, uint32_t* __restrict__ sk_mini)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nsk)
+		return;
+	const uint32_t r = segment_of(t, i);
+	const uint64_t pos = nt_scan[i] - nt_scan[t.seg_first[r]] + 32 * t.seg_word[r];
+	const uint64_t len = meta[i] & 0xffffffffull;
+	sk_pos[i] = pos;
+	sk_last[i] = pos + len - (uint64_t)k;
+	sk_mini[i] = (uint32_t)(meta[i] >> 32);
+}
+
 // ---- K4 ----------------------------------------------------------------------------------------------------------------
 __global__ void k_sorted_lengths(const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
                                  const uint64_t* __restrict__ sk_last, uint64_t nsk, int k, uint64_t* __restrict__ len_nt,
@@ -342,13 +426,15 @@ __global__ void k_group_tables(const uint64_t* __restrict__ b_nt, const uint64_t
 // ---- K5 ----------------------------------------------------------------------------------------------------------------
 // str2bool (blight.cpp:311-324): copy the nucleotides of sorted super-k-mer j to its slot of the packed sequence.
 __global__ void k_scatter_pack(const uint64_t* __restrict__ src, const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
-                               const uint64_t* __restrict__ nt_start, uint64_t nsk, unsigned long long* __restrict__ seq)
+                               const uint64_t* __restrict__ nt_start, const uint64_t* __restrict__ len_nt, uint64_t nsk,
+                               unsigned long long* __restrict__ seq)
 {
 	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= nsk)
 		return;
 	const uint64_t p = sk_pos[order[j]];
-	const uint64_t d = nt_start[j], e = nt_start[j + 1];
+	// destinations are back to back (len_nt == nullptr: the next start is this end) or carry their own lengths (segmented streams)
+	const uint64_t d = nt_start[j], e = len_nt ? d + len_nt[j] : nt_start[j + 1];
 	for (uint64_t dw = d >> 5; dw <= (e - 1) >> 5; dw++) {
 		const uint64_t a = max(d, dw * 32), z = min(e, dw * 32 + 32);
 		const int cnt = (int)(z - a);
@@ -1143,39 +1229,57 @@ void check_build_err(const int* d_err, hipStream_t s)
 		throw StatusError{BLMX_ELIMIT, "a minimizer bucket holds 2^32 or more nucleotides"};
 }
 
-template <int KW>
-void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
-{
-	const auto t_begin = std::chrono::steady_clock::now();
-	// temporaries of this build recycle each other's device blocks (declared first: destroyed after every temporary)
-	struct PoolScope {
-		BuildPool pool;
-		PoolScope()
-		{
-			const char* e = getenv("BLIGHT_BUILD_POOL");
-			BuildPool::current() = (e && atoi(e) == 0) ? nullptr : &pool;
-		}
-		~PoolScope() { BuildPool::current() = nullptr; }
-	} pool_scope;
-	hipStream_t s = ix.stream;
-	const int k = (int)ix.prm.k, m = (int)ix.prm.m, n = (int)ix.prm.log2_mphf, b = (int)ix.prm.bits_saved;
-	const uint32_t nbuckets = ix.nbuckets, ngroups = ix.ngroups;
-	const int gshift = ix.gshift;
-	Scratch sc;
-	sc.s = s;
-	(void)n;
-	// BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream).
-	const bool trace = getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) != 0;
-	auto t_last = t_begin;
-	auto mark = [&](const char* what) {
-		if (!trace)
+// temporaries of a build recycle each other's device blocks
+struct BuildPoolScope {
+	BuildPool own;
+	explicit BuildPoolScope(BuildPool* shared = nullptr)
+	{
+		const char* e = getenv("BLIGHT_BUILD_POOL");
+		BuildPool::current() = (e && atoi(e) == 0) ? nullptr : (shared ? shared : &own);
+	}
+	~BuildPoolScope() { BuildPool::current() = nullptr; }
+};
+
+// BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream).
+struct PhaseMarks {
+	hipStream_t s;
+	bool on;
+	std::chrono::steady_clock::time_point t_last;
+	explicit PhaseMarks(hipStream_t st) : s(st), on(getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) != 0), t_last(std::chrono::steady_clock::now()) {}
+	void operator()(const char* what)
+	{
+		if (!on)
 			return;
 		(void)hipStreamSynchronize(s);
 		const auto now = std::chrono::steady_clock::now();
 		fprintf(stderr, "[blmx build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
 		t_last = now;
-	};
+	}
+};
 
+// K1-K3 of an input: its 2-bit packed text and its super-k-mers in input order
+struct Chopped {
+	DevBuf src, skpos, sklast, skmini;  // packed text; first nt of every super-k-mer; start of its last k-mer; its minimizer
+	uint64_t nsk = 0;
+};
+
+// what a shard knows about the whole index
+struct ShardCtx {
+	uint64_t id_base = 0, global_N = 0, global_nsk = 0;
+	uint32_t glo = 0, ghi = 0;
+};
+
+template <int KW>
+void chop_input(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, Chopped& out, PhaseMarks& mark)
+{
+	hipStream_t s = ix.stream;
+	const int k = (int)ix.prm.k, m = (int)ix.prm.m;
+	Scratch sc;
+	sc.s = s;
+	DevBuf& d_src = out.src;
+	DevBuf& d_skpos = out.skpos;
+	DevBuf& d_sklast = out.sklast;
+	DevBuf& d_skmini = out.skmini;
 	DevBuf d_err;
 	BLMX_HIP(d_err.alloc(sizeof(int), true, s));
 
@@ -1183,7 +1287,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	const uint64_t npos = total_len + 1;                      // positions 0 .. total_len
 	const uint64_t nbw = ((npos + kBlock - 1) / kBlock) * (kBlock / 64);  // bitmap words written by K2
 	const uint64_t src_words = (total_len + 31) / 32;
-	DevBuf d_src, d_ustart, d_Hb, d_Eb;
+	DevBuf d_ustart, d_Hb, d_Eb;
 	BLMX_HIP(d_src.alloc((src_words + 4) * 8, true, s));
 	BLMX_HIP(d_ustart.alloc((nbw + 4) * 8, true, s));
 	BLMX_HIP(d_Hb.alloc((nbw + 1) * 8, true, s));
@@ -1229,7 +1333,6 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 
 	mark("K2 flags+scans");
 	// ---- K3: compact super-k-mers
-	DevBuf d_skpos, d_sklast, d_skmini;
 	BLMX_HIP(d_skpos.alloc((nsk + 1) * 8, false, s));
 	BLMX_HIP(d_sklast.alloc((nsk + 1) * 8, false, s));
 	BLMX_HIP(d_skmini.alloc((nsk + 1) * 4, false, s));
@@ -1246,34 +1349,75 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	d_Epre.release();
 
 	mark("K3 collect");
-	// ---- sharding: every rank sees the whole input, derives the same key-balanced group boundaries from the
-	// global per-group key histogram, and keeps only the super-k-mers of its own groups.  IDs stay global (id_base).
-	uint64_t id_base = 0, global_N = 0;
-	const uint64_t global_nsk = nsk;
+	out.nsk = nsk;
+}
+
+template <int KW>
+void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& mark, std::chrono::steady_clock::time_point t_begin);
+
+// the per-group key histogram of a list of super-k-mers -> host
+std::vector<uint64_t> group_histogram(Index& ix, const Chopped& c)
+{
+	hipStream_t s = ix.stream;
+	DevBuf d_ghist;
+	BLMX_HIP(d_ghist.alloc((size_t)ix.ngroups * 8, true, s));
+	if (c.nsk)
+		hipLaunchKernelGGL(k_group_hist, dim3(grid_for(c.nsk)), dim3(kBlock), 0, s, c.skmini.as<uint32_t>(), c.skpos.as<uint64_t>(),
+		                   c.sklast.as<uint64_t>(), c.nsk, ix.gshift, d_ghist.as<unsigned long long>());
+	std::vector<uint64_t> h((size_t)ix.ngroups);
+	BLMX_HIP(hipMemcpyAsync(h.data(), d_ghist.p, (size_t)ix.ngroups * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	return h;
+}
+
+// key-balanced shard boundaries from the GLOBAL histogram (every rank derives the same ones); returns the ID prefix of each group
+std::vector<uint64_t> derive_shard_bounds(Index& ix, const std::vector<uint64_t>& hist)
+{
+	const uint32_t world = ix.shard_world, ngroups = ix.ngroups;
+	std::vector<uint64_t> pre((size_t)ngroups + 1, 0);
+	for (uint32_t g = 0; g < ngroups; g++)
+		pre[g + 1] = pre[g] + hist[g];
+	ix.shard_bounds.assign((size_t)world + 1, 0);
+	ix.shard_bounds[world] = ngroups;
+	for (uint32_t r = 1; r < world; r++) {
+		const uint64_t target = (uint64_t)(((unsigned __int128)pre[ngroups] * r) / world);
+		ix.shard_bounds[r] = (uint32_t)(std::lower_bound(pre.begin(), pre.begin() + ngroups, target) - pre.begin());
+	}
+	return pre;
+}
+
+template <int KW>
+void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
+{
+	const auto t_begin = std::chrono::steady_clock::now();
+	BuildPoolScope pool_scope;  // declared first: destroyed after every temporary
+	hipStream_t s = ix.stream;
+	PhaseMarks mark(s);
+	Scratch sc;
+	sc.s = s;
+	const uint32_t ngroups = ix.ngroups;
+	const int gshift = ix.gshift;
+	Chopped chopped;
+	chop_input<KW>(ix, d_ascii, d_offs, nseq, total_len, chopped, mark);
+	DevBuf& d_skpos = chopped.skpos;
+	DevBuf& d_sklast = chopped.sklast;
+	DevBuf& d_skmini = chopped.skmini;
+	uint64_t nsk = chopped.nsk;
+	// ---- sharding, whole-input mode: every rank sees the whole input, derives the same key-balanced group boundaries
+	// from the global per-group key histogram, and keeps only the super-k-mers of its own groups.  IDs stay global (id_base).
+	// (Ranks that only hold a slice of the input exchange super-k-mers instead: ShardExchange below.)
+	ShardCtx shard;
+	shard.global_nsk = nsk;
+	shard.ghi = ngroups;
 	const uint32_t world = ix.shard_world, rank = ix.shard_rank;
-	uint32_t glo = 0, ghi = ngroups;
 	ix.shard_bounds.assign((size_t)world + 1, 0);
 	ix.shard_bounds[world] = ngroups;
 	if (world > 1) {
-		DevBuf d_ghist;
-		BLMX_HIP(d_ghist.alloc((size_t)ngroups * 8, true, s));
-		if (nsk)
-			hipLaunchKernelGGL(k_group_hist, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_skmini.as<uint32_t>(), d_skpos.as<uint64_t>(),
-			                   d_sklast.as<uint64_t>(), nsk, gshift, d_ghist.as<unsigned long long>());
-		std::vector<uint64_t> h_hist(ngroups);
-		BLMX_HIP(hipMemcpyAsync(h_hist.data(), d_ghist.p, (size_t)ngroups * 8, hipMemcpyDeviceToHost, s));
-		BLMX_HIP(hipStreamSynchronize(s));
-		std::vector<uint64_t> pre((size_t)ngroups + 1, 0);
-		for (uint32_t g = 0; g < ngroups; g++)
-			pre[g + 1] = pre[g] + h_hist[g];
-		global_N = pre[ngroups];
-		for (uint32_t r = 1; r < world; r++) {
-			const uint64_t target = (uint64_t)(((unsigned __int128)global_N * r) / world);
-			ix.shard_bounds[r] = (uint32_t)(std::lower_bound(pre.begin(), pre.begin() + ngroups, target) - pre.begin());
-		}
-		glo = ix.shard_bounds[rank];
-		ghi = ix.shard_bounds[rank + 1];
-		id_base = pre[glo];
+		const std::vector<uint64_t> pre = derive_shard_bounds(ix, group_histogram(ix, chopped));
+		shard.global_N = pre[ngroups];
+		const uint32_t glo = shard.glo = ix.shard_bounds[rank];
+		const uint32_t ghi = shard.ghi = ix.shard_bounds[rank + 1];
+		shard.id_base = pre[glo];
 		DevBuf d_flags, d_cnt, d_pos2, d_last2, d_mini2;
 		BLMX_HIP(d_flags.alloc(nsk + 1, false, s));
 		BLMX_HIP(d_cnt.alloc(8, true, s));
@@ -1311,6 +1455,32 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	}
 
 	mark("shard filter");
+	chopped.nsk = nsk;
+	build_tail<KW>(ix, chopped, shard, mark, t_begin);
+}
+
+// K4 .. K9 and the public counters: from the super-k-mers this index keeps (in input order) to the finished arrays
+template <int KW>
+void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& mark, std::chrono::steady_clock::time_point t_begin)
+{
+	hipStream_t s = ix.stream;
+	const int k = (int)ix.prm.k, m = (int)ix.prm.m, b = (int)ix.prm.bits_saved;
+	const uint32_t nbuckets = ix.nbuckets, ngroups = ix.ngroups;
+	const int gshift = ix.gshift;
+	const uint32_t world = ix.shard_world, rank = ix.shard_rank;
+	const uint64_t id_base = shard.id_base, global_N = shard.global_N, global_nsk = shard.global_nsk;
+	const uint32_t glo = shard.glo, ghi = shard.ghi;
+	const bool trace = mark.on;
+	(void)trace;
+	Scratch sc;
+	sc.s = s;
+	DevBuf& d_src = chopped.src;
+	DevBuf& d_skpos = chopped.skpos;
+	DevBuf& d_sklast = chopped.sklast;
+	DevBuf& d_skmini = chopped.skmini;
+	const uint64_t nsk = chopped.nsk;
+	DevBuf d_err;
+	BLMX_HIP(d_err.alloc(sizeof(int), true, s));
 	// ---- K4: stable sort by minimizer, offsets, bucket + group tables
 	DevBuf d_smini, d_order, d_lennt, d_lenk, d_ntstart, d_keystart;
 	BLMX_HIP(d_smini.alloc((nsk + 1) * 4, false, s));
@@ -1447,7 +1617,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	BLMX_HIP(ix.seq.alloc(ix.seq_words * 8, true, s));
 	if (nsk)
 		hipLaunchKernelGGL(k_scatter_pack, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
-		                   d_skpos.as<uint64_t>(), d_ntstart.as<uint64_t>(), nsk, ix.seq.as<unsigned long long>());
+		                   d_skpos.as<uint64_t>(), d_ntstart.as<uint64_t>(), (const uint64_t*)nullptr, nsk, ix.seq.as<unsigned long long>());
 
 	mark("K5 scatter_pack");
 	// ---- K6: keys in (bucket, position) order
@@ -1793,6 +1963,205 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	st.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
+// ---- sharded build from slices: every rank chops ITS OWN sequences; super-k-mers travel to the owner of their
+// MPHF group.  Slices are consecutive pieces of the input in rank order, so "source rank, then position in the slice" is the
+// input order and the stable minimizer sort of the tail reproduces the single-GPU bucket content, hence the same IDs.
+}  // namespace
+
+struct ShardExchange {
+	BuildPool pool;  // first: outlives the buffers below
+	std::chrono::steady_clock::time_point t_begin;
+	Chopped local;
+	int phase = 0;  // 1 = chopped, 2 = outgoing streams packed
+	ShardCtx shard;
+	DevBuf out_words, out_meta;
+};
+
+void shard_build_abort(Index& ix)
+{
+	if (!ix.xb)
+		return;
+	PhaseMarks mark(ix.stream);
+	delete ix.xb;
+	ix.xb = nullptr;
+	mark("exchange: free scratch");
+}
+
+namespace {
+
+template <int KW>
+void shard_begin_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out)
+{
+	shard_build_abort(ix);
+	std::unique_ptr<ShardExchange> x(new ShardExchange());
+	x->t_begin = std::chrono::steady_clock::now();
+	BuildPoolScope scope(&x->pool);
+	PhaseMarks mark(ix.stream);
+	chop_input<KW>(ix, d_ascii, d_offs, nseq, total_len, x->local, mark);
+	const std::vector<uint64_t> h = group_histogram(ix, x->local);
+	memcpy(hist_out, h.data(), (size_t)ix.ngroups * 8);
+	hist_out[ix.ngroups] = x->local.nsk;
+	x->phase = 1;
+	ix.xb = x.release();
+}
+
+}  // namespace
+
+void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out)
+{
+	if (ix.built)
+		throw StatusError{BLMX_ESTATE, "index already built"};
+	if (ix.KW == 1)
+		shard_begin_impl<1>(ix, d_ascii, d_offs, nseq, total_len, hist_out);
+	else
+		shard_begin_impl<2>(ix, d_ascii, d_offs, nseq, total_len, hist_out);
+}
+
+void shard_build_plan(Index& ix, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta, const void** d_words)
+{
+	ShardExchange* x = ix.xb;
+	if (!x || x->phase != 1)
+		throw StatusError{BLMX_ESTATE, "blmx_shard_build_plan needs a blmx_shard_build_begin first"};
+	hipStream_t s = ix.stream;
+	BuildPoolScope scope(&x->pool);
+	Scratch sc;
+	sc.s = s;
+	const uint32_t world = ix.shard_world, rank = ix.shard_rank, ngroups = ix.ngroups;
+	const int k = (int)ix.prm.k;
+	const std::vector<uint64_t> hist(global_hist, global_hist + ngroups);
+	const std::vector<uint64_t> pre = derive_shard_bounds(ix, hist);
+	x->shard.global_N = pre[ngroups];
+	x->shard.global_nsk = global_hist[ngroups];
+	x->shard.glo = ix.shard_bounds[rank];
+	x->shard.ghi = ix.shard_bounds[rank + 1];
+	x->shard.id_base = pre[x->shard.glo];
+	Chopped& c = x->local;
+	const uint64_t nsk = c.nsk;
+	OwnerTable t{};
+	t.world = world;
+	for (uint32_t r = 0; r <= world; r++)
+		t.bound[r] = ix.shard_bounds[r];
+	DevBuf d_owner, d_sowner, d_order, d_lennt, d_lenk, d_ntscan, d_seg, d_nt2;
+	BLMX_HIP(d_owner.alloc((nsk + 1) * 4, false, s));
+	BLMX_HIP(d_sowner.alloc((nsk + 1) * 4, false, s));
+	BLMX_HIP(d_order.alloc((nsk + 1) * 4, false, s));
+	BLMX_HIP(d_seg.alloc(17 * 8, true, s));
+	if (nsk) {
+		hipLaunchKernelGGL(k_sk_owner, dim3(grid_for(nsk)), dim3(kBlock), 0, s, c.skmini.as<uint32_t>(), nsk, ix.gshift, t, d_owner.as<uint32_t>());
+		size_t bytes = 0;
+		rocprim::counting_iterator<uint32_t> iota(0);
+		BLMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_owner.as<uint32_t>(), d_sowner.as<uint32_t>(), iota, d_order.as<uint32_t>(), (size_t)nsk, 0u,
+		                                   5u, s));
+		void* tmp = sc.get(bytes);
+		BLMX_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_owner.as<uint32_t>(), d_sowner.as<uint32_t>(), iota, d_order.as<uint32_t>(), (size_t)nsk, 0u, 5u,
+		                                   s));
+	}
+	d_owner.release();
+	hipLaunchKernelGGL(k_owner_segments, dim3(1), dim3(64), 0, s, d_sowner.as<uint32_t>(), nsk, world, d_seg.as<uint64_t>());
+	BLMX_HIP(d_lennt.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(d_lenk.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(d_ntscan.alloc((nsk + 1) * 8, false, s));
+	hipLaunchKernelGGL(k_sorted_lengths, dim3(grid_for(nsk + 1)), dim3(kBlock), 0, s, d_order.as<uint32_t>(), c.skpos.as<uint64_t>(),
+	                   c.sklast.as<uint64_t>(), nsk, k, d_lennt.as<uint64_t>(), d_lenk.as<uint64_t>());
+	BLMX_HIP(hipGetLastError());
+	d_lenk.release();
+	exclusive_scan_u64(sc, d_lennt.as<uint64_t>(), d_ntscan.as<uint64_t>(), nsk + 1, s);
+	uint64_t seg[17] = {0};
+	BLMX_HIP(hipMemcpyAsync(seg, d_seg.p, ((size_t)world + 1) * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	uint64_t words = 0;
+	for (uint32_t r = 0; r <= world; r++)
+		t.seg_first[r] = seg[r];
+	for (uint32_t r = 0; r < world; r++) {
+		const uint64_t nt = read_scalar(d_ntscan.as<uint64_t>() + seg[r + 1], s) - read_scalar(d_ntscan.as<uint64_t>() + seg[r], s);
+		t.seg_word[r] = words;
+		send_sk[r] = seg[r + 1] - seg[r];
+		send_words[r] = (nt + 31) / 32;
+		words += send_words[r];
+	}
+	t.seg_word[world] = words;
+	BLMX_HIP(d_nt2.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(x->out_words.alloc((words + 4) * 8, true, s));
+	BLMX_HIP(x->out_meta.alloc((nsk + 1) * 8, false, s));
+	if (nsk) {
+		hipLaunchKernelGGL(k_segment_offsets, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_ntscan.as<uint64_t>(), nsk, t, d_nt2.as<uint64_t>());
+		hipLaunchKernelGGL(k_scatter_pack, dim3(grid_for(nsk)), dim3(kBlock), 0, s, c.src.as<uint64_t>(), d_order.as<uint32_t>(), c.skpos.as<uint64_t>(),
+		                   d_nt2.as<uint64_t>(), d_lennt.as<uint64_t>(), nsk, x->out_words.as<unsigned long long>());
+		hipLaunchKernelGGL(k_sk_meta, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_order.as<uint32_t>(), c.skmini.as<uint32_t>(), d_lennt.as<uint64_t>(), nsk,
+		                   x->out_meta.as<uint64_t>());
+		BLMX_HIP(hipGetLastError());
+	}
+	BLMX_HIP(hipStreamSynchronize(s));
+	// the slice itself is no longer needed
+	c.src.release();
+	c.skpos.release();
+	c.sklast.release();
+	c.skmini.release();
+	c.nsk = 0;
+	*d_meta = x->out_meta.p;
+	*d_words = x->out_words.p;
+	x->phase = 2;
+}
+
+void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in, const uint64_t* recv_sk, const uint64_t* recv_words)
+{
+	ShardExchange* x = ix.xb;
+	if (!x || x->phase != 2)
+		throw StatusError{BLMX_ESTATE, "blmx_shard_build_finish needs a blmx_shard_build_plan first"};
+	hipStream_t s = ix.stream;
+	struct Cleanup {
+		Index& ix;
+		~Cleanup() { shard_build_abort(ix); }
+	} cleanup{ix};
+	BuildPoolScope scope(&x->pool);
+	PhaseMarks mark(s);
+	Scratch sc;
+	sc.s = s;
+	const uint32_t world = ix.shard_world;
+	const int k = (int)ix.prm.k;
+	OwnerTable t{};
+	t.world = world;
+	uint64_t nsk = 0, words = 0;
+	for (uint32_t r = 0; r < world; r++) {
+		t.seg_first[r] = nsk;
+		t.seg_word[r] = words;
+		nsk += recv_sk[r];
+		words += recv_words[r];
+	}
+	t.seg_first[world] = nsk;
+	t.seg_word[world] = words;
+	if (nsk >= 0xffffffffull)
+		throw StatusError{BLMX_ELIMIT, "more than 2^32 super-k-mers on one shard"};
+	Chopped c;
+	BLMX_HIP(c.src.alloc((words + 4) * 8, true, s));
+	if (words)
+		BLMX_HIP(hipMemcpyAsync(c.src.p, d_words_in, words * 8, hipMemcpyDeviceToDevice, s));
+	BLMX_HIP(c.skpos.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(c.sklast.alloc((nsk + 1) * 8, false, s));
+	BLMX_HIP(c.skmini.alloc((nsk + 1) * 4, false, s));
+	c.nsk = nsk;
+	if (nsk) {
+		DevBuf d_ntscan;
+		BLMX_HIP(d_ntscan.alloc((nsk + 1) * 8, false, s));
+		auto lens = rocprim::make_transform_iterator(reinterpret_cast<const uint64_t*>(d_meta_in), MetaLen());
+		exclusive_scan_u64(sc, lens, d_ntscan.as<uint64_t>(), nsk, s);
+		hipLaunchKernelGGL(k_sk_from_meta, dim3(grid_for(nsk)), dim3(kBlock), 0, s, reinterpret_cast<const uint64_t*>(d_meta_in), d_ntscan.as<uint64_t>(), nsk,
+		                   k, t, c.skpos.as<uint64_t>(), c.sklast.as<uint64_t>(), c.skmini.as<uint32_t>());
+		BLMX_HIP(hipGetLastError());
+	}
+	BLMX_HIP(hipStreamSynchronize(s));
+	// only now: with a world of one rank a caller may hand the outgoing buffers straight back as the incoming ones
+	x->out_words.release();
+	x->out_meta.release();
+	mark("exchange: assemble");
+	if (ix.KW == 1)
+		build_tail<1>(ix, c, x->shard, mark, x->t_begin);
+	else
+		build_tail<2>(ix, c, x->shard, mark, x->t_begin);
+	mark("counters + query heads");
+}
+
+namespace {
 }  // namespace
 
 void make_query_heads(Index& ix)

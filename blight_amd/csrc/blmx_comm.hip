@@ -23,6 +23,8 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
+
 #include "blmx_internal.h"
 
 namespace blmx {
@@ -39,6 +41,7 @@ struct Rccl {
 	decltype(&ncclSend) Send = nullptr;
 	decltype(&ncclRecv) Recv = nullptr;
 	decltype(&ncclAllGather) AllGather = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 	std::string err;
 };
@@ -68,6 +71,7 @@ Rccl& rccl()
 		BLMX_SYM(Send, ncclSend)
 		BLMX_SYM(Recv, ncclRecv)
 		BLMX_SYM(AllGather, ncclAllGather)
+		BLMX_SYM(AllReduce, ncclAllReduce)
 		BLMX_SYM(GetErrorString, ncclGetErrorString)
 #undef BLMX_SYM
 		return x;
@@ -147,21 +151,33 @@ Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int devic
 
 void comm_destroy(Comm* c) { delete c; }
 
-// all-to-all-v as grouped point-to-point transfers; counts in elements of `words` uint64 each
+// all-to-all-v as grouped point-to-point transfers; counts in elements of `words` uint64 each.  A pairwise flow larger than
+// kFlowWords is cut into rounds (both ends of a flow know its length, so they cut it alike; ranks whose flows are shorter simply
+// take part in fewer rounds): one 1.7-GB ncclSend/ncclRecv pair delivered wrong data here (RCCL 2.26/2.27, self flow), 1 GB was fine.
+constexpr uint64_t kFlowWords = 1ull << 25;  // 256 MiB
+
 static void all_to_all_v(Comm& c, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t words, hipStream_t s)
 {
 	Rccl& R = rccl();
-	BLMX_NCCL(R.GroupStart());
-	uint64_t so = 0, ro = 0;
+	uint64_t so[17], ro[17], rounds = 0;
+	so[0] = ro[0] = 0;
 	for (uint32_t r = 0; r < c.world; r++) {
-		if (send_cnt[r])
-			BLMX_NCCL(R.Send((const uint64_t*)send + so * words, send_cnt[r] * words, ncclUint64, (int)r, c.comm, s));
-		if (recv_cnt[r])
-			BLMX_NCCL(R.Recv((uint64_t*)recv + ro * words, recv_cnt[r] * words, ncclUint64, (int)r, c.comm, s));
-		so += send_cnt[r];
-		ro += recv_cnt[r];
+		so[r + 1] = so[r] + send_cnt[r] * words;
+		ro[r + 1] = ro[r] + recv_cnt[r] * words;
+		rounds = std::max(rounds, (std::max(send_cnt[r], recv_cnt[r]) * words + kFlowWords - 1) / kFlowWords);
 	}
-	BLMX_NCCL(R.GroupEnd());
+	for (uint64_t j = 0; j < rounds; j++) {
+		const uint64_t off = j * kFlowWords;
+		BLMX_NCCL(R.GroupStart());
+		for (uint32_t r = 0; r < c.world; r++) {
+			const uint64_t sn = send_cnt[r] * words, rn = recv_cnt[r] * words;
+			if (off < sn)
+				BLMX_NCCL(R.Send((const uint64_t*)send + so[r] + off, std::min(kFlowWords, sn - off), ncclUint64, (int)r, c.comm, s));
+			if (off < rn)
+				BLMX_NCCL(R.Recv((uint64_t*)recv + ro[r] + off, std::min(kFlowWords, rn - off), ncclUint64, (int)r, c.comm, s));
+		}
+		BLMX_NCCL(R.GroupEnd());
+	}
 }
 
 // IDs of nq canonical k-mers in HBM, every k-mer answered by the rank that owns its MPHF group; collective: every rank of the
@@ -235,6 +251,91 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, i
 		launch_gather_ids(ix, c.ids_sorted[p].as<int64_t>(), c.inv[p].as<uint32_t>(), cut[p + 1] - cut[p], d_ids + cut[p], s);
 	}
 	ix.number_query.fetch_add(nq, std::memory_order_relaxed);
+}
+
+// Sharded construction from slices: every rank passes ITS OWN consecutive piece of the input (rank order = input order).  Collective.
+// Steps: chop locally -> all-reduce of the per-group key histograms (every rank derives the same key-balanced boundaries) ->
+// all-gather of the per-destination counts -> all-to-all-v of the super-k-mers (meta words, then packed nucleotides) -> the owner
+// finishes its shard.  A rank whose input is invalid still takes part in every collective and all ranks fail together.
+void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
+{
+	if (ix.built)
+		throw StatusError{BLMX_ESTATE, "index already built"};
+	if (ix.shard_world != c.world || ix.shard_rank != c.rank)
+		throw StatusError{BLMX_EINVAL, "the index was sharded for another rank / world than this communicator"};
+	if ((int)ix.prm.device != c.device)
+		throw StatusError{BLMX_EINVAL, "index and communicator live on different devices"};
+	std::lock_guard<std::mutex> lock(c.mu);
+	BLMX_HIP(hipSetDevice(c.device));
+	Rccl& R = rccl();
+	hipStream_t s = ix.stream;
+	const uint32_t world = c.world, me = c.rank, ngroups = ix.ngroups;
+	const size_t nh = (size_t)ngroups + 2;  // histogram, super-k-mer count, failed ranks
+	const bool trace = getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) != 0;
+	auto t_last = std::chrono::steady_clock::now();
+	auto mark = [&](const char* what) {
+		if (!trace)
+			return;
+		(void)hipStreamSynchronize(s);
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[blmx build] rank %u %-21s %8.2f ms\n", me, what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
+	std::vector<uint64_t> hist(nh, 0);
+	StatusError local{BLMX_OK, ""};
+	try {
+		shard_build_begin(ix, d_ascii, d_offs, nseq, total_len, hist.data());
+	} catch (const StatusError& e) {
+		local = e;
+		std::fill(hist.begin(), hist.end(), 0);
+		hist[nh - 1] = 1;
+	}
+	mark("exchange: chop slice");
+	DevBuf d_hist;
+	BLMX_HIP(d_hist.alloc(nh * 8, false, s));
+	BLMX_HIP(hipMemcpyAsync(d_hist.p, hist.data(), nh * 8, hipMemcpyHostToDevice, s));
+	BLMX_NCCL(R.AllReduce(d_hist.p, d_hist.p, nh, ncclUint64, ncclSum, c.comm, s));
+	BLMX_HIP(hipMemcpyAsync(hist.data(), d_hist.p, nh * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	if (hist[nh - 1]) {
+		shard_build_abort(ix);
+		if (local.code != BLMX_OK)
+			throw local;
+		throw StatusError{BLMX_ERCCL, "sharded build: the input of another rank was rejected"};
+	}
+	mark("exchange: all-reduce");
+	uint64_t send_sk[16], send_words[16], recv_sk[16], recv_words[16];
+	const void *d_meta = nullptr, *d_words = nullptr;
+	shard_build_plan(ix, hist.data(), send_sk, send_words, &d_meta, &d_words);
+	mark("exchange: pack outgoing");
+	std::vector<uint64_t> mine(2 * (size_t)world), all(2 * (size_t)world * world);
+	for (uint32_t r = 0; r < world; r++) {
+		mine[r] = send_sk[r];
+		mine[world + r] = send_words[r];
+	}
+	DevBuf d_mine, d_all;
+	BLMX_HIP(d_mine.alloc(mine.size() * 8, false, s));
+	BLMX_HIP(d_all.alloc(all.size() * 8, false, s));
+	BLMX_HIP(hipMemcpyAsync(d_mine.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, s));
+	BLMX_NCCL(R.AllGather(d_mine.p, d_all.p, mine.size(), ncclUint64, c.comm, s));
+	BLMX_HIP(hipMemcpyAsync(all.data(), d_all.p, all.size() * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	uint64_t in_sk = 0, in_words = 0;
+	for (uint32_t r = 0; r < world; r++) {
+		recv_sk[r] = all[(size_t)r * 2 * world + me];
+		recv_words[r] = all[(size_t)r * 2 * world + world + me];
+		in_sk += recv_sk[r];
+		in_words += recv_words[r];
+	}
+	DevBuf d_in_meta, d_in_words;
+	BLMX_HIP(d_in_meta.alloc((in_sk + 1) * 8, false, s));
+	BLMX_HIP(d_in_words.alloc((in_words + 1) * 8, false, s));
+	all_to_all_v(c, d_meta, send_sk, d_in_meta.p, recv_sk, 1, s);
+	all_to_all_v(c, d_words, send_words, d_in_words.p, recv_words, 1, s);
+	BLMX_HIP(hipStreamSynchronize(s));
+	mark("exchange: all-to-all-v");
+	shard_build_finish(ix, d_in_meta.p, d_in_words.p, recv_sk, recv_words);
+	ix.built = true;
 }
 
 }  // namespace blmx

@@ -202,6 +202,8 @@ void destroy_host_front(HostFront*);
 			                          std::string(#expr) + ": " + hipGetErrorString(_e)};                      \
 	} while (0)
 
+struct ShardExchange;
+
 struct Index {
 	blmx_params prm{};
 	int KW = 1;  // u64 words per k-mer
@@ -214,6 +216,7 @@ struct Index {
 	std::mutex mu;  // serialises the large host-buffer / file operations (they share the window slots)
 	std::atomic<uint64_t> number_query{0};  // blight.h:56; incremented atomically like the reference (blight.cpp:687-688, 717-718)
 	HostFront* hf = nullptr;                // created on first use (blmx_stream.hip)
+	ShardExchange* xb = nullptr;            // state of a sharded build between its phases (blmx_build.hip)
 	std::mutex hf_mu;
 
 	// finished index (HBM)
@@ -298,6 +301,11 @@ struct Index {
 // build (blmx_build.hip)
 void make_query_heads(Index& ix);  // from ix.h_groups, after the group table is final (build and load)
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
+// sharded build from slices, phase by phase (blmx_build.hip); hist_out holds ngroups + 1 words: key histogram, local super-k-mers
+void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out);
+void shard_build_plan(Index& ix, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta, const void** d_words);
+void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in, const uint64_t* recv_sk, const uint64_t* recv_words);
+void shard_build_abort(Index& ix);
 
 // query (blmx_query.hip).  mode: 0 = IDs (query_kmer_hash / query_get_hash), 1 = positions (query_get_pos_unitig),
 // 2 = membership byte.  d_minis == nullptr -> minimizers are computed on the device.
@@ -350,6 +358,7 @@ struct Comm;
 void comm_unique_id(void* id_out);
 Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int device);
 void comm_destroy(Comm* c);
+void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
 void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s);
 // streaming front end (blmx_stream.hip)
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);

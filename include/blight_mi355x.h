@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
  * so a stale caller binary is detected instead of corrupting memory. */
-#define BLMX_ABI_VERSION 8
+#define BLMX_ABI_VERSION 9
 
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
@@ -222,6 +222,31 @@ int blmx_comm_unique_id(void* id_out);
 int blmx_comm_create(const void* id, uint32_t rank, uint32_t world, int device, blmx_comm** out);
 void blmx_comm_destroy(blmx_comm* c);
 int blmx_query_kmers_sharded_device(blmx_index* ix, blmx_comm* c, const void* d_canon_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
+
+/* ---- sharded CONSTRUCTION from slices: every rank passes only ITS OWN consecutive piece of the input (rank order = input
+ * order) and the super-k-mers travel to the rank that owns their MPHF group; IDs, membership and every array are those of the
+ * whole-input build (blmx_set_shard + blmx_build_from_*), which every rank would have had to feed the complete input.
+ * blmx_build_sharded_from_sequences / _device_sequences: the native collective (all-reduce of the per-group key histograms,
+ * all-gather of the counts, all-to-all-v of the super-k-mers over RCCL); every rank of the communicator calls it; a rank whose
+ * input is rejected makes all ranks fail together.  Arguments as blmx_build_from_sequences / blmx_build_from_device_sequences.
+ * The three phases are also exported for callers with their own transport (and for the single-GPU virtual-rank tests):
+ *   blmx_shard_build_begin[_device]  chop the slice; hist_out[2^log2_mphf + 1] = this slice's keys per MPHF group, then its
+ *                                    super-k-mer count.  The caller sums hist_out over all ranks (element-wise).
+ *   blmx_shard_build_plan            global_hist = that sum.  Derives the shard boundaries, orders the slice's super-k-mers by
+ *                                    owner and packs them: send_sk[world] super-k-mers / send_words[world] u64 words go to each
+ *                                    rank, taken consecutively from *d_meta (one u64 per super-k-mer) and *d_words (2-bit
+ *                                    nucleotides; every destination's part starts on a word).  The buffers stay valid until finish.
+ *   blmx_shard_build_finish          d_meta_in / d_words_in = what this rank received, concatenated in SOURCE-RANK order;
+ *                                    recv_sk[world] / recv_words[world] = the counts per source.  Builds the shard. */
+int blmx_build_sharded_from_sequences(blmx_index* ix, blmx_comm* c, const char* concat, const uint64_t* offsets, uint64_t nseq);
+int blmx_build_sharded_from_device_sequences(blmx_index* ix, blmx_comm* c, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq,
+                                             uint64_t total_len);
+int blmx_shard_build_begin(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq, uint64_t* hist_out);
+int blmx_shard_build_begin_device(blmx_index* ix, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq, uint64_t total_len,
+                                  uint64_t* hist_out);
+int blmx_shard_build_plan(blmx_index* ix, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta,
+                          const void** d_words);
+int blmx_shard_build_finish(blmx_index* ix, const void* d_meta_in, const void* d_words_in, const uint64_t* recv_sk, const uint64_t* recv_words);
 
 /* Batch-query strategy of blmx_query_kmers / blmx_query_kmers_device: 0 = automatic (large batches on large indexes are first
  * partitioned by the top bits of their minimizer so that concurrently running blocks share a slice of the index in

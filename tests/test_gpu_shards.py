@@ -229,6 +229,24 @@ for pieces in ("1", "2", "3"):
         got = np.full(max(n_, 1), -7, dtype=np.int64)
         assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), d_ids, C.c_size_t(n_ * 8), 2) == 0
         assert np.array_equal(got[:n_], want[:n_]), (pieces, n_)
+# sharded construction from slices, world 1: chop -> all-reduce -> all-gather -> all-to-all-v (to itself) -> owner's build
+ix2 = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ix2.set_shard(0, 1)
+comm.build_sharded_from_sequences(ix2, seqs)
+for name in B.EXPORT:
+    assert np.array_equal(ix.export(name), ix2.export(name)), name
+assert np.array_equal(ix2.query_kmer_hash(q.reshape(-1)), want)
+s1, s2 = ix.stats(), ix2.stats()
+assert not [f for f in s1 if f not in ("build_seconds", "number_query") and s1[f] != s2[f]], [(f, s1[f], s2[f]) for f in s1 if s1[f] != s2[f]]
+ix3 = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ix3.set_shard(0, 1)
+try:
+    comm.build_sharded_from_sequences(ix3, seqs[:10] + ["ACGT"])      # a sequence shorter than k: every rank fails, nobody hangs
+    raise SystemExit("expected a failure")
+except B.BlightError as e:
+    assert e.code == B.BLMX_ESHORT, e
+comm.build_sharded_from_sequences(ix3, seqs)                           # ... and the communicator and the index are still usable
+assert np.array_equal(ix3.query_kmer_hash(q.reshape(-1)), want)
 comm.close()
 print("NATIVE-WORLD1-OK")
 """
@@ -248,3 +266,72 @@ def test_native_rccl_exchange_world1(tmp_path, k, b):
     env = dict(os.environ, BLIGHT_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script), str(k), str(b)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "NATIVE-WORLD1-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("world,k,m,n,b", [(2, 31, 9, 7, 6), (3, 31, 7, 5, 4), (8, 31, 9, 14, 6), (4, 63, 9, 7, 8)])
+def test_sharded_build_from_slices(world, k, m, n, b):
+    """Construction where every rank only sees ITS OWN consecutive slice of the input (blmx_shard_build_begin / _plan / _finish;
+    the native collective blmx_build_sharded_from_sequences runs the same three phases around RCCL): `world` virtual ranks on one
+    GPU, the all-reduce is a numpy sum and the all-to-all-v a set of device copies.  Every array of every shard must equal the
+    whole-input sharded build (which equals the unsharded index up to the shard's group range: test_virtual_shards)."""
+    import ctypes as C
+    import torch
+    import blight_amd as B
+    rng = np.random.default_rng(world * 11 + k)
+    seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 80))) for _ in range(3000)]
+    seqs += ["A" * (k + 40), "AC" * (k + 3), seqs[5], seqs[5][3:]]           # duplicates and low complexity: fallback keys, shared buckets
+    hip = C.CDLL([l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0])
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    # uneven consecutive slices; with three or more ranks one of them gets nothing
+    cuts = sorted(int(x) for x in rng.integers(0, len(seqs), world - 1))
+    if world >= 3:
+        cuts[1] = cuts[0]
+    cuts = [0] + cuts + [len(seqs)]
+    ref, ixs, hists = [], [], []
+    for r in range(world):
+        a = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+        a.set_shard(r, world)
+        a.construct_index_from_sequences(seqs)
+        ref.append(a)
+        x = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+        x.set_shard(r, world)
+        hists.append(x.shard_build_begin(seqs[cuts[r]:cuts[r + 1]]))
+        ixs.append(x)
+    gh = np.sum(hists, axis=0, dtype=np.uint64)
+    assert int(gh[-1]) == ref[0].stats()["number_super_kmer"]
+    plans = [x.shard_build_plan(gh, world) for x in ixs]
+    dev = torch.device("cuda", 0)
+    incoming = []
+    for d in range(world):
+        recv_sk = np.array([plans[r][0][d] for r in range(world)], dtype=np.uint64)
+        recv_w = np.array([plans[r][1][d] for r in range(world)], dtype=np.uint64)
+        meta = torch.zeros(int(recv_sk.sum()) + 1, dtype=torch.int64, device=dev)
+        words = torch.zeros(int(recv_w.sum()) + 1, dtype=torch.int64, device=dev)
+        om = ow = 0
+        for r in range(world):
+            sk, w, pm, pw = plans[r]
+            sm, sw = int(sk[:d].sum()), int(w[:d].sum())
+            if recv_sk[r]:
+                assert hip.hipMemcpy(meta.data_ptr() + 8 * om, pm + 8 * sm, 8 * int(recv_sk[r]), 3) == 0
+            if recv_w[r]:
+                assert hip.hipMemcpy(words.data_ptr() + 8 * ow, pw + 8 * sw, 8 * int(recv_w[r]), 3) == 0
+            om += int(recv_sk[r])
+            ow += int(recv_w[r])
+        incoming.append((meta, words, recv_sk, recv_w))
+    torch.cuda.synchronize()
+    for d, (meta, words, recv_sk, recv_w) in enumerate(incoming):     # the outgoing buffers of a rank live until ITS finish
+        ixs[d].shard_build_finish(meta.data_ptr(), words.data_ptr(), recv_sk, recv_w)
+    for r in range(world):
+        assert np.array_equal(ixs[r].shard_bounds(), ref[r].shard_bounds())
+        for name in B.EXPORT:
+            assert np.array_equal(ixs[r].export(name), ref[r].export(name)), (r, name)
+        s1, s2 = ixs[r].stats(), ref[r].stats()
+        assert not [f for f in s1 if f not in ("build_seconds", "number_query") and s1[f] != s2[f]], [(r, f, s1[f], s2[f]) for f in s1 if s1[f] != s2[f]]
+    # phase errors: finish without plan, plan twice
+    y = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+    y.set_shard(0, world)
+    with pytest.raises(B.BlightError):
+        y.shard_build_finish(0, 0, np.zeros(world, np.uint64), np.zeros(world, np.uint64))
+    y.shard_build_begin(seqs[:50])
+    with pytest.raises(B.BlightError):
+        y.shard_build_finish(0, 0, np.zeros(world, np.uint64), np.zeros(world, np.uint64))
