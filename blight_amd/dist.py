@@ -148,3 +148,74 @@ class ShardedQuerier:
             self.ops.unpermute_into(out_slice, vals, order)
         else:
             out_slice.copy_(self.ops.unpermute(vals, order))
+
+
+# ---- sharded CONSTRUCTION from slices --------------------------------------------------------------------------------------------
+class _DevicePointer:
+    """zero-copy torch view of a device buffer owned by the library (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+class DeviceSliceOps:
+    """The three phases of blmx_shard_build_* on this rank's GPU (the native collective blmx_build_sharded_from_sequences runs the
+    same phases around RCCL inside the library; this class is for callers that bring torch.distributed as their transport)."""
+
+    def __init__(self, index, device):
+        self.ix, self.dev = index, device
+
+    def begin(self, seqs):
+        return torch.from_numpy(self.ix.shard_build_begin(seqs).view("int64").copy())
+
+    def plan(self, global_hist, world):
+        sk, words, pm, pw = self.ix.shard_build_plan(global_hist.numpy().view("uint64"), world)
+        nsk, nw = int(sk.sum()), int(words.sum())
+        meta = torch.as_tensor(_DevicePointer(pm, nsk), device=self.dev) if nsk else torch.empty(0, dtype=torch.int64, device=self.dev)
+        packed = torch.as_tensor(_DevicePointer(pw, nw), device=self.dev) if nw else torch.empty(0, dtype=torch.int64, device=self.dev)
+        return [int(x) for x in sk], [int(x) for x in words], meta, packed
+
+    def empty(self, n):
+        return torch.empty(max(int(n), 1), dtype=torch.int64, device=self.dev)[:int(n)]
+
+    def finish(self, meta_in, words_in, recv_sk, recv_words):
+        torch.cuda.synchronize()
+        self.ix.shard_build_finish(meta_in.data_ptr(), words_in.data_ptr(), recv_sk, recv_words)
+
+
+class SlicedBuilder:
+    """build(seqs): every rank passes ITS OWN consecutive slice of the input (rank order = input order).  One all-reduce (per-group
+    key histograms -> identical key-balanced boundaries everywhere), one small all-to-all (counts), two all-to-all-v (one u64 of
+    (minimizer, length) per super-k-mer; the 2-bit packed nucleotides, every destination's part starting on a word).  What a rank
+    receives is concatenated in source-rank order = input order, so the owner's stable minimizer sort reproduces the bucket
+    content -- and hence the IDs -- of a single-GPU build."""
+
+    def __init__(self, ops, group=None):
+        self.ops, self.group = ops, group
+        self.world = dist.get_world_size(group)
+        self.host_staging = os.environ.get("BLIGHT_DIST_HOST_STAGING") == "1"
+        # the small host-side vectors (histogram, counts) travel through the device when the backend only moves device memory (nccl)
+        self.cdev = "cpu" if self.host_staging else getattr(ops, "dev", "cpu")
+
+    def _a2a(self, out, inp, out_split, in_split):
+        if self.host_staging and out.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+
+    def build(self, seqs):
+        hist = self.ops.begin(seqs).to(self.cdev)  # int64: keys per MPHF group of this slice, then its super-k-mer count
+        dist.all_reduce(hist, group=self.group)
+        send_sk, send_words, meta, packed = self.ops.plan(hist.cpu(), self.world)
+        mine = torch.tensor([[send_sk[r], send_words[r]] for r in range(self.world)], dtype=torch.int64, device=self.cdev)
+        theirs = torch.empty_like(mine)
+        dist.all_to_all_single(theirs.view(-1), mine.view(-1), group=self.group)
+        theirs = theirs.cpu()
+        recv_sk = [int(x) for x in theirs[:, 0]]
+        recv_words = [int(x) for x in theirs[:, 1]]
+        meta_in, words_in = self.ops.empty(sum(recv_sk)), self.ops.empty(sum(recv_words))
+        self._a2a(meta_in, meta, recv_sk, send_sk)
+        self._a2a(words_in, packed, recv_words, send_words)
+        self.ops.finish(meta_in, words_in, recv_sk, recv_words)

@@ -159,6 +159,17 @@ for chunks in (1, 2, 3):
     torch.cuda.synchronize()
     assert torch.equal(got, want), chunks
 assert int((want >= 0).sum().item()) >= len(seqs)
+# construction from slices with torch.distributed as the transport (blmx_shard_build_* phases, library buffers as zero-copy tensors)
+from blight_amd.dist import DeviceSliceOps, SlicedBuilder
+ix2 = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ix2.set_shard(0, 1)
+SlicedBuilder(DeviceSliceOps(ix2, dev)).build(seqs)
+for name in B.EXPORT:
+    assert np.array_equal(ix.export(name), ix2.export(name)), name
+got = torch.empty_like(want)
+ix2.query_kmers_device(q.data_ptr(), q.shape[0], got.data_ptr(), s)
+torch.cuda.synchronize()
+assert torch.equal(got, want)
 dist.destroy_process_group()
 print("NCCL-WORLD1-OK")
 """
