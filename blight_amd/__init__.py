@@ -106,6 +106,11 @@ def load_library():
     lib.blmx_comm_destroy.restype = None
     lib.blmx_query_kmers_sharded_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.blmx_build_sharded_from_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, _u64p, C.c_uint64]
+    lib.blmx_build_sharded_from_fasta.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    lib.blmx_query_kmers_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _i64p]
+    lib.blmx_query_sequences_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _i64p]
+    lib.blmx_query_sequences_sharded_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                                        C.c_void_p, C.c_void_p]
     lib.blmx_build_sharded_from_device_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
     lib.blmx_shard_build_begin.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _u64p]
     lib.blmx_shard_build_begin_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, _u64p]
@@ -460,6 +465,26 @@ class Comm:
         """collective: every rank passes ITS OWN consecutive slice of the input (rank order = input order)"""
         buf, offs = _concat(seqs)
         index._check(self._lib.blmx_build_sharded_from_sequences(index._h, self._c, buf, offs.ctypes.data_as(_u64p), len(offs) - 1))
+
+    def build_sharded_from_fasta(self, index, path):
+        """collective: every rank names the same file and indexes the rank-th consecutive part of its sequences"""
+        index._check(self._lib.blmx_build_sharded_from_fasta(index._h, self._c, os.fsencode(path)))
+
+    def query_kmers_sharded(self, index, kmers):
+        """collective, host buffers: canonical k-mers (uint64, two words per k-mer for k > 32) -> IDs"""
+        a = np.ascontiguousarray(kmers, dtype=np.uint64)
+        nq = a.size // (index.kmer_bytes // 8)
+        ids = np.empty(nq, dtype=np.int64)
+        index._check(self._lib.blmx_query_kmers_sharded(index._h, self._c, a.ctypes.data, nq, ids.ctypes.data_as(_i64p)))
+        return ids
+
+    def query_sequences_sharded(self, index, seqs):
+        """collective: query_sequence_hash of this rank's sequences against the sharded index"""
+        buf, offs = _concat(seqs)
+        nk = int(self._lib.blmx_sequence_kmer_count(index._h, offs.ctypes.data_as(_u64p), len(offs) - 1))
+        ids = np.empty(nk, dtype=np.int64)
+        index._check(self._lib.blmx_query_sequences_sharded(index._h, self._c, buf, offs.ctypes.data_as(_u64p), len(offs) - 1, ids.ctypes.data_as(_i64p)))
+        return ids
 
     def build_sharded_from_device(self, index, d_concat_ptr, d_offsets_ptr, nseq, total_len):
         index._check(self._lib.blmx_build_sharded_from_device_sequences(index._h, self._c, d_concat_ptr, d_offsets_ptr, nseq, total_len))

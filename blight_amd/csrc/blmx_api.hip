@@ -605,6 +605,38 @@ int blmx_build_sharded_from_sequences(blmx_index* h, blmx_comm* c, const char* c
 	});
 }
 
+int blmx_build_sharded_from_fasta(blmx_index* h, blmx_comm* c, const char* path)
+{
+	if (!h || !c || !path)
+		return BLMX_EINVAL;
+	return guarded(h, [&] { build_sharded_from_fasta(h->ix, *reinterpret_cast<Comm*>(c), path); });
+}
+
+int blmx_query_kmers_sharded(blmx_index* h, blmx_comm* c, const void* kmers, uint64_t nq, int64_t* ids_out)
+{
+	if (!h || !c || (nq && (!kmers || !ids_out)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { query_kmers_sharded_host(h->ix, *reinterpret_cast<Comm*>(c), kmers, nq, ids_out); });
+}
+
+int blmx_query_sequences_sharded(blmx_index* h, blmx_comm* c, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out)
+{
+	if (!h || !c || (nseq && (!concat || !offsets)))
+		return BLMX_EINVAL;
+	return guarded(h, [&] { query_sequences_sharded_host(h->ix, *reinterpret_cast<Comm*>(c), concat, offsets, nseq, ids_out); });
+}
+
+int blmx_query_sequences_sharded_device(blmx_index* h, blmx_comm* c, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq, uint64_t total_len,
+                                        uint64_t nk, int64_t* d_ids, int* d_err_flag, void* stream)
+{
+	if (!h || !c || (nseq && (!d_concat || !d_offsets)) || (nk && !d_ids))
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		query_sequences_sharded_device(h->ix, *reinterpret_cast<Comm*>(c), reinterpret_cast<const uint8_t*>(d_concat), d_offsets, nseq, total_len, nk,
+		                               d_ids, d_err_flag, reinterpret_cast<hipStream_t>(stream));
+	});
+}
+
 int blmx_build_sharded_from_device_sequences(blmx_index* h, blmx_comm* c, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq,
                                              uint64_t total_len)
 {

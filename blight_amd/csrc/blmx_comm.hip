@@ -257,7 +257,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, i
 // Steps: chop locally -> all-reduce of the per-group key histograms (every rank derives the same key-balanced boundaries) ->
 // all-gather of the per-destination counts -> all-to-all-v of the super-k-mers (meta words, then packed nucleotides) -> the owner
 // finishes its shard.  A rank whose input is invalid still takes part in every collective and all ranks fail together.
-void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
+void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, const StatusError* already_failed)
 {
 	if (ix.built)
 		throw StatusError{BLMX_ESTATE, "index already built"};
@@ -284,6 +284,8 @@ void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d
 	std::vector<uint64_t> hist(nh, 0);
 	StatusError local{BLMX_OK, ""};
 	try {
+		if (already_failed)  // e.g. this rank could not open its input: it still takes part, so that nobody waits for it
+			throw *already_failed;
 		shard_build_begin(ix, d_ascii, d_offs, nseq, total_len, hist.data());
 	} catch (const StatusError& e) {
 		local = e;
@@ -336,6 +338,54 @@ void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d
 	mark("exchange: all-to-all-v");
 	shard_build_finish(ix, d_in_meta.p, d_in_words.p, recv_sk, recv_words);
 	ix.built = true;
+}
+
+// every rank reads the file (the reader's pair rule needs the lines from the start) and keeps the rank-th consecutive part of its
+// sequences: rank r of w takes sequences [nseq * r / w, nseq * (r + 1) / w)
+void build_sharded_from_fasta(Index& ix, Comm& c, const char* path)
+{
+	if (ix.built)
+		throw StatusError{BLMX_ESTATE, "index already built"};
+	BLMX_HIP(hipSetDevice(c.device));
+	DevBuf d_ascii, d_offs;
+	std::vector<uint64_t> offs(1, 0);
+	uint64_t total = 0;
+	StatusError local{BLMX_OK, ""};
+	try {
+		load_fasta_to_device(ix, path, d_ascii, offs, total);
+	} catch (const StatusError& e) {
+		local = e;
+	}
+	if (local.code != BLMX_OK) {
+		build_sharded(ix, c, nullptr, nullptr, 0, 0, &local);  // throws `local` after the all-reduce
+		throw local;
+	}
+	const uint64_t nseq = offs.size() - 1;
+	const uint64_t u0 = nseq * c.rank / c.world, u1 = nseq * (c.rank + 1) / c.world;
+	std::vector<uint64_t> mine(u1 - u0 + 1);
+	for (uint64_t i = 0; i <= u1 - u0; i++)
+		mine[i] = offs[u0 + i] - offs[u0];
+	BLMX_HIP(d_offs.alloc(mine.size() * 8, false, ix.stream));
+	BLMX_HIP(hipMemcpyAsync(d_offs.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, ix.stream));
+	BLMX_HIP(hipStreamSynchronize(ix.stream));
+	build_sharded(ix, c, d_ascii.as<uint8_t>() + offs[u0], d_offs.as<uint64_t>(), u1 - u0, mine.back(), nullptr);
+}
+
+// host buffers in and out around the device exchange (collective)
+void query_kmers_sharded_host(Index& ix, Comm& c, const void* kmers, uint64_t nq, int64_t* ids_out)
+{
+	BLMX_HIP(hipSetDevice(c.device));
+	std::lock_guard<std::mutex> lock(ix.mu);
+	hipStream_t s = ix.stream;
+	const size_t kb = 8 * (size_t)ix.KW;
+	grow(ix.q_in, nq * kb + 16, s);
+	grow(ix.q_out, nq * 8 + 16, s);
+	if (nq)
+		BLMX_HIP(hipMemcpyAsync(ix.q_in.p, kmers, nq * kb, hipMemcpyHostToDevice, s));
+	query_kmers_sharded(ix, c, ix.q_in.p, nq, ix.q_out.as<int64_t>(), s);
+	if (nq)
+		BLMX_HIP(hipMemcpyAsync(ids_out, ix.q_out.p, nq * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
 }
 
 }  // namespace blmx

@@ -552,6 +552,73 @@ void query_sequences_device(Index& ix, const uint8_t* d_chars, const uint64_t* d
 	ix.number_query.fetch_add(nk, std::memory_order_relaxed);
 }
 
+// Sequences resident in HBM against a SHARDED index: the read front end of this rank turns them into canonical k-mers, the
+// exchange (blmx_comm.hip) sends every k-mer to the owner of its MPHF group and brings the IDs back.  Collective.
+void query_sequences_sharded_device(Index& ix, Comm& c, const uint8_t* d_chars, const uint64_t* d_offs, uint64_t nseq, uint64_t total, uint64_t nk,
+                                    int64_t* d_ids, int* d_err, hipStream_t s)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	if (total >= 0xffffffc0ull)
+		throw StatusError{BLMX_ELIMIT, "a device-resident batch holds fewer than 2^32 characters"};
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	HostFront& hf = host_front(ix);
+	std::lock_guard<std::mutex> lock(hf.dev_mu);
+	if (!hf.dev_done)
+		BLMX_HIP(hipEventCreateWithFlags(&hf.dev_done, hipEventDisableTiming));
+	if (hf.dev_used && hf.dev_last != s)
+		BLMX_HIP(hipStreamWaitEvent(s, hf.dev_done, 0));
+	if (!d_err) {
+		if (!hf.dev_err.p)
+			BLMX_HIP(hf.dev_err.alloc(64, true, s));
+		d_err = hf.dev_err.as<int>();
+	}
+	grow(hf.dev_kmers, nk * 8 * (size_t)ix.KW + 16, s);
+	grow(hf.dev_minis, nk * 4 + 16, s);
+	if (nk && nseq) {
+		front_valid_concat(ix, hf.dev_fs, d_offs, nseq + 1, 0, total, total, s);
+		launch_read_front(ix, &hf.dev_fs, d_chars, total, total, nullptr, nullptr, 0, hf.dev_kmers.p, hf.dev_minis.as<uint32_t>(), d_err, s);
+	}
+	query_kmers_sharded(ix, c, hf.dev_kmers.p, nk, d_ids, s);  // every rank takes part, also with an empty batch
+	BLMX_HIP(hipEventRecord(hf.dev_done, s));
+	hf.dev_last = s;
+	hf.dev_used = true;
+}
+
+// host characters in, host IDs out (staged through the index's device buffers)
+void query_sequences_sharded_host(Index& ix, Comm& c, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out)
+{
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	const uint64_t total = nseq ? offsets[nseq] : 0;
+	if (nseq && offsets[0] != 0)
+		throw StatusError{BLMX_EINVAL, "offsets[0] must be 0"};
+	const uint64_t k = ix.prm.k;
+	uint64_t nk = 0;
+	for (uint64_t i = 0; i < nseq; i++) {
+		const uint64_t len = offsets[i + 1] - offsets[i];
+		nk += len >= k ? len - k + 1 : 0;
+	}
+	std::lock_guard<std::mutex> lock(ix.mu);
+	hipStream_t s = ix.stream;
+	grow(ix.q_in, total + 64, s);
+	grow(ix.q_aux, (nseq + 1) * 8 + 16, s);
+	grow(ix.q_out, nk * 8 + 16, s);
+	DevBuf d_err;
+	BLMX_HIP(d_err.alloc(64, true, s));
+	if (total)
+		BLMX_HIP(hipMemcpyAsync(ix.q_in.p, concat, total, hipMemcpyHostToDevice, s));
+	if (nseq)
+		BLMX_HIP(hipMemcpyAsync(ix.q_aux.p, offsets, (nseq + 1) * 8, hipMemcpyHostToDevice, s));
+	query_sequences_sharded_device(ix, c, ix.q_in.as<uint8_t>(), ix.q_aux.as<uint64_t>(), nseq, total, nk, ix.q_out.as<int64_t>(), d_err.as<int>(), s);
+	int err = 0;
+	BLMX_HIP(hipMemcpyAsync(&err, d_err.p, sizeof err, hipMemcpyDeviceToHost, s));
+	if (nk)
+		BLMX_HIP(hipMemcpyAsync(ids_out, ix.q_out.p, nk * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	if (err)
+		throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
+}
+
 // ---- query_kmer_hash / query_kmer_bool / query_get_hash / query_get_pos_unitig for a host batch (blight.cpp:537-550, 686-742) ----
 void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode)
 {

@@ -358,7 +358,14 @@ struct Comm;
 void comm_unique_id(void* id_out);
 Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int device);
 void comm_destroy(Comm* c);
-void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
+void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len,
+                   const StatusError* already_failed = nullptr);
+void build_sharded_from_fasta(Index& ix, Comm& c, const char* path);
+void query_kmers_sharded_host(Index& ix, Comm& c, const void* kmers, uint64_t nq, int64_t* ids_out);
+void query_sequences_sharded_device(Index& ix, Comm& c, const uint8_t* d_chars, const uint64_t* d_offs, uint64_t nseq, uint64_t total, uint64_t nk,
+                                    int64_t* d_ids, int* d_err, hipStream_t s);
+void query_sequences_sharded_host(Index& ix, Comm& c, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
+void load_fasta_to_device(Index& ix, const char* path, DevBuf& d_ascii, std::vector<uint64_t>& offs, uint64_t& total_out);
 void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s);
 // streaming front end (blmx_stream.hip)
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);

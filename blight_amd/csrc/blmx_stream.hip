@@ -392,10 +392,9 @@ void Pinned::ensure(size_t n, size_t keep)
 // copies while the next chunk is being parsed, so the H2D transfer hides behind the (host-bound) parse and no pageable
 // whole-file copy of the input is ever made.  The device buffer starts at the file size (an upper bound for a plain file;
 // a guess for gzip) and doubles with a device-to-device copy when it runs out.
-void build_from_fasta_streamed(Index& ix, const char* path)
+// the sequences of a FASTA file (plain or gzip) -> device memory: characters back to back + host offsets
+void load_fasta_to_device(Index& ix, const char* path, DevBuf& d_ascii, std::vector<uint64_t>& offs, uint64_t& total_out)
 {
-	if (ix.built)
-		throw StatusError{BLMX_ESTATE, "index already built"};
 	RecordReader rd(path);
 	if (!rd.ok())
 		throw StatusError{BLMX_EIO, "Problem with files opening"};  // blight.cpp:188-189
@@ -431,9 +430,8 @@ void build_from_fasta_streamed(Index& ix, const char* path)
 		pin[i].ensure(kChunk);
 		BLMX_HIP(hipEventCreateWithFlags(&sent[i], hipEventDisableTiming));
 	}
-	DevBuf d_ascii, d_offs;
 	BLMX_HIP(d_ascii.alloc(std::max<uint64_t>(gz ? file_bytes * 5 : file_bytes + 64, kChunk) + 64, false, s));
-	std::vector<uint64_t> offs(1, 0);
+	offs.assign(1, 0);
 	uint64_t total = 0;  // bytes already on their way to the device
 	size_t fill = 0;
 	int cur = 0;
@@ -482,10 +480,22 @@ void build_from_fasta_streamed(Index& ix, const char* path)
 		offs.push_back(total + fill);
 	}
 	flush();
-	const uint64_t nseq = offs.size() - 1;
-	BLMX_HIP(d_offs.alloc((nseq + 1) * 8, false, s));
-	BLMX_HIP(hipMemcpyAsync(d_offs.p, offs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, s));
 	BLMX_HIP(hipStreamSynchronize(s));
+	total_out = total;
+}
+
+void build_from_fasta_streamed(Index& ix, const char* path)
+{
+	if (ix.built)
+		throw StatusError{BLMX_ESTATE, "index already built"};
+	DevBuf d_ascii, d_offs;
+	std::vector<uint64_t> offs;
+	uint64_t total = 0;
+	load_fasta_to_device(ix, path, d_ascii, offs, total);
+	const uint64_t nseq = offs.size() - 1;
+	BLMX_HIP(d_offs.alloc((nseq + 1) * 8, false, ix.stream));
+	BLMX_HIP(hipMemcpyAsync(d_offs.p, offs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
+	BLMX_HIP(hipStreamSynchronize(ix.stream));
 	build_from_device(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), nseq, total);
 	ix.built = true;
 }

@@ -15,6 +15,7 @@
 #ifndef BLIGHT_MI355X_FACADE_H
 #define BLIGHT_MI355X_FACADE_H
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -212,6 +213,76 @@ public:
 		std::cout << "Query performed: " << intToString(number_query.load()) << std::endl;
 		const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count();
 		std::cout << "The whole QUERY took me " << secs << " seconds." << std::endl;
+	}
+
+	// ---- several GPUs, one process per GPU (no counterpart in the reference, which is one shared-memory process): the MPHF
+	// groups are split over the ranks by key count, IDs stay those of the single index.  Rank 0 makes an id and hands it to the
+	// others by any means (a file, MPI_Bcast, a socket); every rank then creates its communicator (collective).
+	class communicator {
+	public:
+		typedef std::array<unsigned char, BLMX_COMM_ID_BYTES> id_t;
+		static id_t unique_id()
+		{
+			id_t id;
+			if (blmx_comm_unique_id(id.data()) != BLMX_OK)
+				throw std::runtime_error(blmx_last_error(nullptr));
+			return id;
+		}
+		communicator(const id_t& id, uint32_t rank_, uint32_t world_, int device = 0) : rank(rank_), world(world_)
+		{
+			if (blmx_comm_create(id.data(), rank, world, device, &_c) != BLMX_OK)
+				throw std::runtime_error(blmx_last_error(nullptr));
+		}
+		communicator(const communicator&) = delete;
+		communicator& operator=(const communicator&) = delete;
+		~communicator() { blmx_comm_destroy(_c); }
+		blmx_comm* handle() const { return _c; }
+		const uint32_t rank, world;
+
+	private:
+		blmx_comm* _c = nullptr;
+	};
+	// construct_index over several GPUs (collective).  File: every rank names the SAME file and indexes the rank-th consecutive part
+	// of its sequences.  Sequences: every rank passes ITS OWN consecutive part (rank order = input order).
+	void construct_index(const std::string& input_file, communicator& c)
+	{
+		check(blmx_set_shard(_h, c.rank, c.world));
+		check(blmx_build_sharded_from_fasta(_h, c.handle(), input_file.c_str()));
+		refresh();
+	}
+	void construct_index(const std::vector<std::string>& my_sequences, communicator& c)
+	{
+		std::string concat;
+		std::vector<uint64_t> offs(1, 0);
+		for (const auto& q : my_sequences) {
+			concat += q;
+			offs.push_back(concat.size());
+		}
+		check(blmx_set_shard(_h, c.rank, c.world));
+		check(blmx_build_sharded_from_sequences(_h, c.handle(), concat.data(), offs.data(), my_sequences.size()));
+		refresh();
+	}
+	// queries against the sharded index (collective: every rank calls with its own batch, possibly empty); every k-mer is answered
+	// by the rank that owns its MPHF group and the IDs come back in the caller's order
+	std::vector<int64_t> query_kmer_hash(const std::vector<kmer_t>& canon, communicator& c)
+	{
+		std::vector<int64_t> ids(canon.size());
+		check(blmx_query_kmers_sharded(_h, c.handle(), canon.data(), canon.size(), ids.data()));
+		number_query += canon.size();
+		return ids;
+	}
+	std::vector<int64_t> query_sequences_hash(const std::vector<std::string>& queries, communicator& c)
+	{
+		std::string concat;
+		std::vector<uint64_t> offs(1, 0);
+		for (const auto& q : queries) {
+			concat += q;
+			offs.push_back(concat.size());
+		}
+		std::vector<int64_t> res(blmx_sequence_kmer_count(_h, offs.data(), queries.size()));
+		check(blmx_query_sequences_sharded(_h, c.handle(), concat.data(), offs.data(), queries.size(), res.data()));
+		number_query += res.size();
+		return res;
 	}
 
 	blmx_index* handle() const { return _h; }

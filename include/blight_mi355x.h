@@ -222,6 +222,13 @@ int blmx_comm_unique_id(void* id_out);
 int blmx_comm_create(const void* id, uint32_t rank, uint32_t world, int device, blmx_comm** out);
 void blmx_comm_destroy(blmx_comm* c);
 int blmx_query_kmers_sharded_device(blmx_index* ix, blmx_comm* c, const void* d_canon_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
+/* the same collective with host buffers (staged through the index's device buffers; returns when ids_out is filled) */
+int blmx_query_kmers_sharded(blmx_index* ix, blmx_comm* c, const void* canon_kmers, uint64_t nq, int64_t* ids_out);
+/* query_sequence_hash against a sharded index: this rank's read front end makes the canonical k-mers, the exchange answers them.
+ * Arguments as blmx_query_sequences / blmx_query_sequences_device; collective (a rank without reads passes nseq = 0). */
+int blmx_query_sequences_sharded(blmx_index* ix, blmx_comm* c, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
+int blmx_query_sequences_sharded_device(blmx_index* ix, blmx_comm* c, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq,
+                                        uint64_t total_len, uint64_t nk, int64_t* d_ids_out, int* d_err_flag, void* stream);
 
 /* ---- sharded CONSTRUCTION from slices: every rank passes only ITS OWN consecutive piece of the input (rank order = input
  * order) and the super-k-mers travel to the rank that owns their MPHF group; IDs, membership and every array are those of the
@@ -239,6 +246,8 @@ int blmx_query_kmers_sharded_device(blmx_index* ix, blmx_comm* c, const void* d_
  *   blmx_shard_build_finish          d_meta_in / d_words_in = what this rank received, concatenated in SOURCE-RANK order;
  *                                    recv_sk[world] / recv_words[world] = the counts per source.  Builds the shard. */
 int blmx_build_sharded_from_sequences(blmx_index* ix, blmx_comm* c, const char* concat, const uint64_t* offsets, uint64_t nseq);
+/* every rank names the SAME file and keeps the rank-th consecutive part of its sequences ([nseq*rank/world, nseq*(rank+1)/world)) */
+int blmx_build_sharded_from_fasta(blmx_index* ix, blmx_comm* c, const char* path);
 int blmx_build_sharded_from_device_sequences(blmx_index* ix, blmx_comm* c, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq,
                                              uint64_t total_len);
 int blmx_shard_build_begin(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq, uint64_t* hist_out);

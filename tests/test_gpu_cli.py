@@ -84,3 +84,37 @@ def test_per_read_calls_from_openmp_threads(tmp_path):
         res = json.loads(out.stdout.strip().splitlines()[-1])
         assert (res["reads"], res["kmers"], res["found"], res["absent"], res["checksum"]) == (len(reads), kmers, found, absent, checksum)
         assert res["number_query"] == kmers + max(0, len(reads[0]) - 31 + 1)  # + the warm-up call
+
+
+def test_shard_query_cpp_world1(tmp_path):
+    """tools/shard_query: the multi-GPU path from C++ only (kmer_Set_Light::communicator of include/blight.h: construct_index from
+    this rank's part of the file over RCCL, query_sequences_hash through the native exchange), here with a world of one rank.
+    The reads are the indexed file itself plus foreign reads: counts and the (read, position, ID) checksum equal the oracle's."""
+    import json
+
+    import numpy as np
+    from oracle import oracle as O
+    exe = os.path.join(ROOT, "tools", "shard_query")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "shard_query"])
+    c = G.Case("lambda_k31_m7_n5_b6")
+    rng = np.random.default_rng(3)
+    reads = list(c.seqs) + ["".join("ACGT"[j] for j in rng.integers(0, 4, 120)) for _ in range(500)] + ["ACGT"]
+    rf = tmp_path / "reads.txt"
+    rf.write_text("\n".join(reads) + "\n")
+    orc = O.Oracle(c.k, c.m, c.n, c.b, c.seqs)
+    kmers = found = absent = checksum = 0
+    for i, r in enumerate(reads):
+        ids = orc.query_sequence(r) if len(r) >= c.k else np.zeros(0, np.int64)
+        kmers += ids.size
+        found += int((ids >= 0).sum())
+        absent += int((ids < 0).sum())
+        for j, v in enumerate(ids.tolist()):
+            checksum = (checksum + (i * 1000003 + j + 1) * ((v + 2) % (1 << 64))) % (1 << 64)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, "-g", G.LAMBDA, "-q", str(rf), "-k", "31", "-m", "7", "-n", "5", "-b", "6", "-r", "0", "-w", "1",
+                          "-i", str(tmp_path / "comm.id")], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert (res["number_kmer"], res["reads"], res["kmers"], res["found"], res["absent"], res["checksum"]) == (48462, len(reads), kmers, found, absent, checksum)
+    assert found >= 48462

@@ -258,6 +258,31 @@ except B.BlightError as e:
     assert e.code == B.BLMX_ESHORT, e
 comm.build_sharded_from_sequences(ix3, seqs)                           # ... and the communicator and the index are still usable
 assert np.array_equal(ix3.query_kmer_hash(q.reshape(-1)), want)
+# host-buffer collectives: k-mers and whole sequences (this rank's read front end + the exchange)
+assert np.array_equal(comm.query_kmers_sharded(ix3, q.reshape(-1)), want)
+some = seqs[:300] + ["".join("ACGT"[i] for i in rng.integers(0, 4, 200)) for _ in range(50)] + ["ACG"]
+assert np.array_equal(comm.query_sequences_sharded(ix3, some), ix.query_sequences_hash(some))
+assert comm.query_sequences_sharded(ix3, []).size == 0
+try:
+    comm.query_sequences_sharded(ix3, ["ACGTN" * 20])
+    raise SystemExit("expected Invalid char in DNA")
+except ValueError:
+    pass
+# the same file on every rank, each indexes its part
+fa = os.path.join(os.environ["BLIGHT_TMP"], "u.fa")
+open(fa, "w").write("".join(">u%d\n%s\n" % (i, s_) for i, s_ in enumerate(seqs)))
+ix4 = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ix4.set_shard(0, 1)
+comm.build_sharded_from_fasta(ix4, fa)
+for name in B.EXPORT:
+    assert np.array_equal(ix.export(name), ix4.export(name)), name
+ix5 = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ix5.set_shard(0, 1)
+try:
+    comm.build_sharded_from_fasta(ix5, fa + ".missing")
+    raise SystemExit("expected OSError")
+except OSError:
+    pass
 comm.close()
 print("NATIVE-WORLD1-OK")
 """
@@ -274,7 +299,8 @@ def test_native_rccl_exchange_world1(tmp_path, k, b):
     import sys
     script = tmp_path / "native_world1.py"
     script.write_text(_NATIVE_WORLD1)
-    env = dict(os.environ, BLIGHT_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, BLIGHT_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BLIGHT_TMP=str(tmp_path))
     r = subprocess.run([sys.executable, str(script), str(k), str(b)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "NATIVE-WORLD1-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
