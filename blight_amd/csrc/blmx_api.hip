@@ -170,6 +170,8 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	// tuning knobs: seeded from the environment once per index (blmx_set_tuning changes them later)
 	h->ix.bin_policy = env_int("BLIGHT_QUERY_BINNING", 0);
 	h->ix.tune_bin_bits = env_int("BLIGHT_BIN_BITS", 0);
+	h->ix.tune_filter_bits = env_int("BLIGHT_FILTER_BITS", 8);
+	h->ix.tune_absent_filter = env_int("BLIGHT_ABSENT_FILTER", 1);
 	h->ix.tune_mini_handoff = env_int("BLIGHT_MINI_HANDOFF", -1);
 	h->ix.tune_query_heads = env_int("BLIGHT_QUERY_HEADS", 1);
 	h->ix.tune_reads_mode = env_int("BLIGHT_READS_MODE", 0);
@@ -193,6 +195,11 @@ void blmx_destroy(blmx_index* h)
 	destroy_host_front(h->ix.hf);
 	h->ix.hf = nullptr;
 	shard_build_abort(h->ix);
+	h->ix.filter_wait();
+	if (h->ix.filter_ready)
+		(void)hipEventDestroy(h->ix.filter_ready);
+	if (h->ix.bg_stream)
+		(void)hipStreamDestroy(h->ix.bg_stream);
 	for (hipEvent_t e : h->ix.prof_ev)
 		if (e)
 			(void)hipEventDestroy(e);
@@ -708,6 +715,15 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 	const std::string k(key);
 	if (k == "bin_bits")
 		ix.tune_bin_bits = value;
+	else if (k == "filter_bits")  // bits per key of the absent-key filter built at construction (0 = none); set before building
+		ix.tune_filter_bits = value < 0 ? 0 : (value > 32 ? 32 : value);
+	else if (k == "filter_junctions")  // test hook, before building
+		ix.tune_filter_junctions = value != 0;
+	else if (k == "absent_filter") {  // 0 = queries ignore the filter the index has; 1 = use it (waits for its background pass)
+		ix.tune_absent_filter = value != 0;
+		if (value)
+			ix.filter_wait();
+	}
 	else if (k == "mini_handoff")
 		ix.tune_mini_handoff = value;
 	else if (k == "query_heads")

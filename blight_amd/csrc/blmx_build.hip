@@ -1059,7 +1059,8 @@ __global__ void k_fb_table(const uint32_t* __restrict__ perm, uint64_t F, const 
 template <int KW>
 __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
                                                            const uint64_t* __restrict__ key_start, uint64_t nsk, const uint64_t* __restrict__ keys,
-                                                           uint64_t id_base, uint32_t* __restrict__ field_of_rank)
+                                                           uint64_t id_base, uint32_t* __restrict__ field_of_rank,
+                                                           unsigned long long* __restrict__ filter)
 {
 	__shared__ uint64_t s_ks[kSkPerBlock + 1];
 	__shared__ uint64_t s_pos0[kSkPerBlock];
@@ -1086,6 +1087,10 @@ __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, co
 		const GroupDesc* gd = &v.groups[s_mini[j] >> v.gshift];
 		const GroupHead gh = load_group_head(gd);
 		const Kmer<KW> x = load_kmer<KW>(keys, idx);
+		if (filter) {  // every key, also the duplicates and the ones the fallback table ranks
+			const uint64_t fh = filter_hash<KW>(x);
+			atomicOr(&filter[filter_word(gh.prefix - id_base, gh.size0, v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
+		}
 		const uint64_t h = mphf_lookup_levels<KW>(v, gd, gh, x);
 		if (h != kNotFound)  // ranks are distinct: a plain 4-B store, no atomics (k_pack_positions makes the bit fields)
 			field_of_rank[gh.prefix - id_base + h] = (uint32_t)((s_pos0[j] + (idx - s_ks[j])) >> v.b);
@@ -1118,6 +1123,47 @@ __global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ p
 	const GroupDesc* gd = &v.groups[mi >> v.gshift];
 	const uint64_t pos = nt_start[lo] - v.buckets[mi].start + (idx - key_start[lo]);
 	field_of_rank[gd->prefix - id_base + trank[e]] = (uint32_t)(pos >> v.b);
+}
+
+// The absent-key filter must never reject a k-mer the reference answers.  Besides the keys, the reference's 2^b scan
+// (blight.cpp:729-739) can find k-mers that are NOT keys: it compares whatever it reads from the bucket's concatenated sequence,
+// and a k-mer read across the junction of two super-k-mers (or past the end of the bucket, into the next one) is not a key of
+// anybody.  A query for such a k-mer x is answered with an ID iff the MPHF of ITS minimizer's group happens to send x to a rank
+// whose position window covers the place where x can be read.  One lane per k-mer that starts in the last k-1 nucleotides of a
+// super-k-mer: canonical form, its own minimizer -> the bucket a query would look in, and exactly the query's test; the few that
+// pass (a 2^b window among a bucket's positions) are added to the filter.
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_filter_junctions(DeviceIndexView v, const uint64_t* __restrict__ nt_start, uint64_t nsk,
+                                                             unsigned long long* __restrict__ filter)
+{
+	const uint64_t idx = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+	const uint32_t per = (uint32_t)v.k - 1u;
+	const uint64_t j = idx / per + 1;
+	if (j >= nsk)
+		return;
+	const uint32_t t = (uint32_t)(idx - (j - 1) * per);
+	const uint64_t a = nt_start[j] - per + t;  // absolute position in the packed sequence: the k-mer ends inside super-k-mer j
+	const Kmer<KW> y = packed_kmer<KW>(v.seq, a, v.k);
+	const Kmer<KW> yr = kmer_rc<KW>(y, v.k);
+	const bool fwd = !(yr < y);
+	const Kmer<KW> x = fwd ? y : yr, xr = fwd ? yr : y;
+	const uint32_t mini = kmer_minimizer<KW>(x, xr, v.k, v.m);
+	const BucketDesc bd = v.buckets[mini];
+	if (bd.nt == 0 || a < bd.start)
+		return;
+	const uint64_t rel = a - bd.start;
+	if (rel >= (uint64_t)bd.nt + (1ull << v.b))  // beyond every window of that bucket
+		return;
+	const GroupDesc* gd = &v.groups[mini >> v.gshift];
+	const GroupHead gh = load_group_head(gd);
+	const uint64_t h = mphf_lookup<KW>(v, gd, gh, x);
+	if (h == kNotFound)
+		return;
+	const uint64_t pos = read_position(v.positions, gh.posstart, gh.nbits, h, v.b);
+	if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bd.nt) || rel < pos || rel >= pos + (1ull << v.b))
+		return;
+	const uint64_t fh = filter_hash<KW>(x);
+	atomicOr(&filter[filter_word(gh.prefix - v.id_base, gh.size0, v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
 }
 
 // int_to_bool for a whole group (blight.cpp:464-469): one workgroup packs the group's 32-bit fields (indexed by rank)
@@ -1232,12 +1278,20 @@ void check_build_err(const int* d_err, hipStream_t s)
 // temporaries of a build recycle each other's device blocks
 struct BuildPoolScope {
 	BuildPool own;
-	explicit BuildPoolScope(BuildPool* shared = nullptr)
+	Index* defer_to;  // while the filter's background pass runs, the cached blocks are parked in the index instead of being freed here
+	explicit BuildPoolScope(BuildPool* shared = nullptr, Index* defer = nullptr) : defer_to(defer)
 	{
 		const char* e = getenv("BLIGHT_BUILD_POOL");
 		BuildPool::current() = (e && atoi(e) == 0) ? nullptr : (shared ? shared : &own);
 	}
-	~BuildPoolScope() { BuildPool::current() = nullptr; }
+	~BuildPoolScope()
+	{
+		BuildPool::current() = nullptr;
+		if (defer_to && defer_to->filter_state.load() == 0) {
+			defer_to->deferred_blocks.insert(defer_to->deferred_blocks.end(), own.free_blocks.begin(), own.free_blocks.end());
+			own.free_blocks.clear();
+		}
+	}
 };
 
 // BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream).
@@ -1390,7 +1444,11 @@ template <int KW>
 void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
 {
 	const auto t_begin = std::chrono::steady_clock::now();
-	BuildPoolScope pool_scope;  // declared first: destroyed after every temporary
+	struct StartThread {  // declared before the pool scope: runs after it has parked its blocks in the index
+		Index& ix;
+		~StartThread() { ix.start_filter_thread(); }
+	} start_thread{ix};
+	BuildPoolScope pool_scope(nullptr, &ix);  // destroyed after every temporary
 	hipStream_t s = ix.stream;
 	PhaseMarks mark(s);
 	Scratch sc;
@@ -1913,13 +1971,26 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	ix.positions_words = total_pos / 64 + 3;
 	BLMX_HIP(ix.positions.alloc(ix.positions_words * 8, true, s));
 	ix.st.total_nt = total_nt;
+	// absent-key filter (index_device.h): tune_filter_bits per key, every key inserted by the positions pass
+	const uint32_t bpk = (uint32_t)std::max(0, std::min(ix.tune_filter_bits, 32));
+	ix.filter_bpk = 0;
+	ix.filter_words = 0;
+	ix.filter.release();
+	if (bpk && N) {
+		ix.filter_words = (uint64_t)(((unsigned __int128)N * bpk) >> 6) + 64;
+		BLMX_HIP(ix.filter.alloc(ix.filter_words * 8, true, s));
+		ix.filter_bpk = bpk;
+	}
 	{
-		const DeviceIndexView v = ix.view();
+		DeviceIndexView v = ix.view();
+		v.filter = ix.filter_bpk ? ix.filter.as<uint64_t>() : nullptr;  // whatever the query-time switch says
+		v.id_base = id_base;
+		unsigned long long* d_filter = ix.filter_bpk ? ix.filter.as<unsigned long long>() : nullptr;
 		DevBuf d_field;  // position field of every local rank (ranks nobody owns -- overwritten duplicates -- stay 0 like in the reference)
 		BLMX_HIP(d_field.alloc((N + 1) * 4, true, s));
 		if (nsk)
 			hipLaunchKernelGGL((k_fill_positions<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
-			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>());
+			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>(), d_filter);
 		if (F)
 			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint64_t>(), F,
 			                   ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(),
@@ -1929,9 +2000,33 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			                   ix.positions.as<unsigned long long>());
 		BLMX_HIP(hipGetLastError());
 		BLMX_HIP(hipStreamSynchronize(s));
+		mark("K9b positions");
+		// second pass of the filter, on its own stream: the build does not wait for it, queries use the filter once it is done
+		ix.filter_wait();
+		ix.filter_state.store(2);
+		if (d_filter && nsk > 1 && ix.tune_filter_junctions) {
+			if (!ix.bg_stream)
+				BLMX_HIP(hipStreamCreateWithFlags(&ix.bg_stream, hipStreamNonBlocking));
+			if (!ix.filter_ready)
+				BLMX_HIP(hipEventCreateWithFlags(&ix.filter_ready, hipEventDisableTiming));
+			ix.filter_pending.p = d_ntstart.p;  // the pass reads the super-k-mer starts: the block leaves the build's pool with it
+			ix.filter_pending.bytes = d_ntstart.bytes;
+			ix.filter_pending.owner = nullptr;
+			d_ntstart.p = nullptr;
+			d_ntstart.bytes = 0;
+			const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1), blocks = (cand + kBlock - 1) / kBlock;
+			const unsigned gx = (unsigned)std::min<uint64_t>(blocks, 1u << 22), gy = (unsigned)((blocks + gx - 1) / gx);
+			ix.filter_state.store(0);
+			hipLaunchKernelGGL((k_filter_junctions<KW>), dim3(gx, gy), dim3(kBlock), 0, ix.bg_stream, v, ix.filter_pending.as<uint64_t>(), nsk, d_filter);
+			BLMX_HIP(hipGetLastError());
+			BLMX_HIP(hipEventRecord(ix.filter_ready, ix.bg_stream));
+			if (mark.on) {
+				BLMX_HIP(hipEventSynchronize(ix.filter_ready));
+				mark("K9c filter junctions (in the background when not traced)");
+			}
+		}
 	}
 
-	mark("K9b positions");
 	// ---- public counters (blight.h:52-59, recap blight.cpp:361-378)
 	ix.total_lines = total_lines;
 	ix.total_logical_words = total_words;
@@ -1958,7 +2053,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	st.bits_saved = ix.prm.bits_saved;
 	st.kmer_bytes = (uint32_t)(8 * KW);
 	st.max_levels_used = (uint32_t)levels_used;
-	st.device_bytes = ix.buckets.bytes + ix.groups.bytes + ix.qheads.bytes + ix.seq.bytes + ix.positions.bytes + ix.lines.bytes + ix.fb_keys.bytes +
+	st.device_bytes = ix.buckets.bytes + ix.groups.bytes + ix.qheads.bytes + ix.seq.bytes + ix.positions.bytes + ix.lines.bytes + ix.filter.bytes + ix.fb_keys.bytes +
 	                  ix.fb_ranks.bytes;
 	st.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 }
@@ -1982,8 +2077,15 @@ void shard_build_abort(Index& ix)
 	if (!ix.xb)
 		return;
 	PhaseMarks mark(ix.stream);
+	if (ix.filter_state.load() == 0) {  // the filter's background pass is running: the helper thread frees the blocks
+		for (DevBuf* b : {&ix.xb->local.src, &ix.xb->local.skpos, &ix.xb->local.sklast, &ix.xb->local.skmini, &ix.xb->out_words, &ix.xb->out_meta})
+			b->release();
+		ix.deferred_blocks.insert(ix.deferred_blocks.end(), ix.xb->pool.free_blocks.begin(), ix.xb->pool.free_blocks.end());
+		ix.xb->pool.free_blocks.clear();
+	}
 	delete ix.xb;
 	ix.xb = nullptr;
+	ix.start_filter_thread();
 	mark("exchange: free scratch");
 }
 

@@ -638,7 +638,8 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 		memcpy(base, kmers, nq * kb);
 		if (minis)
 			memcpy(base + o_minis, minis, nq * 4);
-		launch_query(ix, base, minis ? reinterpret_cast<const uint32_t*>(base + o_minis) : nullptr, nq, base + o_out, mode, sl.s);
+		launch_query(ix, base, minis ? reinterpret_cast<const uint32_t*>(base + o_minis) : nullptr, nq, base + o_out,
+		             (QueryMode)(mode | (minis ? kQueryNoFilter : 0)), sl.s);
 		BLMX_HIP(hipStreamSynchronize(sl.s));
 		memcpy(out, base + o_out, nq * ob);
 		ix.number_query.fetch_add(nq, std::memory_order_relaxed);  // blight.cpp:717-718
@@ -694,7 +695,7 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 		if (mode == kQueryIds && !d_minis)
 			launch_query_ids_auto(ix, w.d_kmers.p, n, w.d_ids.as<int64_t>(), w.s);
 		else
-			launch_query(ix, w.d_kmers.p, d_minis, n, w.d_ids.p, mode, w.s);
+			launch_query(ix, w.d_kmers.p, d_minis, n, w.d_ids.p, (QueryMode)(mode | (minis ? kQueryNoFilter : 0)), w.s);
 		w.narrow = mode == kQueryIds && ids_fit_32(ix);
 		if (w.narrow) {
 			grow(w.d_aux2, n * 4, w.s);

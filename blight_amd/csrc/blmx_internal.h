@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,10 @@ struct DeviceIndexView {
 	const uint64_t* fb_keys;    // fallback keys (KW words each), sorted by (group, key)
 	const uint64_t* fb_ranks;
 	uint64_t total_nt;
+	// absent-key filter (blocked Bloom filter over the keys of this index, one 64-bit block per probe; nullptr = off)
+	const uint64_t* filter;
+	uint64_t id_base;     // ID of the first key this index holds (0 unless sharded): group regions of the filter follow local IDs
+	uint32_t filter_bpk;  // filter bits per key
 };
 
 // ---- tiny RAII device buffer ---------------------------------------------------------------------------------------
@@ -220,7 +225,38 @@ struct Index {
 	std::mutex hf_mu;
 
 	// finished index (HBM)
-	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks;
+	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks, filter;
+	uint64_t filter_words = 0;
+	uint32_t filter_bpk = 0;   // bits per key the filter was built with (0 = none)
+	// The filter's second pass (k_filter_junctions: the few non-keys the reference's scan can find) runs on its own stream AFTER the
+	// build has returned, and a helper thread waits for it, gives the build's temporaries back to the driver (hipFree waits for the
+	// device, so the build itself must not do it) and arms the filter.  0 = pass pending, 2 = filter usable.
+	mutable std::atomic<int> filter_state{2};
+	DevBuf filter_pending;                            // super-k-mer starts the pass reads
+	std::vector<BuildPool::Block> deferred_blocks;    // temporaries of the build, freed by the helper thread
+	std::thread filter_thread;
+	hipStream_t bg_stream = nullptr;
+	hipEvent_t filter_ready = nullptr;
+	bool filter_usable() const { return filter_state.load(std::memory_order_acquire) == 2; }
+	void start_filter_thread()
+	{
+		if (filter_state.load() != 0 || filter_thread.joinable())
+			return;
+		filter_thread = std::thread([this] {
+			(void)hipSetDevice(prm.device);
+			(void)hipEventSynchronize(filter_ready);
+			filter_pending.release();
+			for (const BuildPool::Block& b : deferred_blocks)
+				(void)hipFree(b.p);
+			deferred_blocks.clear();
+			filter_state.store(2, std::memory_order_release);
+		});
+	}
+	void filter_wait()  // block until the second pass is done (image writer, destroy, rebuild, blmx_set_tuning("absent_filter", 1))
+	{
+		if (filter_thread.joinable())
+			filter_thread.join();
+	}
 	bool has_qheads = false;
 	// host mirror of the group table (export / stats)
 	std::vector<GroupDesc> h_groups;
@@ -252,11 +288,14 @@ struct Index {
 	int tune_partition = 0;      // batch partition: 0 / 2 = exact (histogram, scan, scatter), 1 = one pass into fixed-capacity bins
 	int tune_slot_slack_pct = 0; // one-pass partition: slots per bin = mean occupancy + this many percent (0 = default 12)
 	int tune_narrow_ids = 1;     // host-buffer results cross PCIe as 32-bit words when every ID fits (0 = always 64-bit)
+	int tune_absent_filter = 1;  // queries consult the absent-key filter (when the index was built with one)
+	int tune_filter_junctions = 1;  // test hook: 0 = skip the filter's second pass (the filter then loses the reference's false positives)
+	int tune_filter_bits = 8;    // bits per key of the filter built at construction (0 = build none; BLIGHT_FILTER_BITS)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
 
 	Index()
 	{
-		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks})
+		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks, &filter})
 			b->persistent = true;
 	}
 
@@ -294,6 +333,9 @@ struct Index {
 		v.fb_keys = fb_keys.as<uint64_t>();
 		v.fb_ranks = fb_ranks.as<uint64_t>();
 		v.total_nt = st.total_nt;
+		v.filter = (filter_bpk && tune_absent_filter && filter_usable()) ? filter.as<uint64_t>() : nullptr;
+		v.filter_bpk = filter_bpk;
+		v.id_base = h_groups.empty() ? 0 : h_groups[0].prefix;
 		return v;
 	}
 };
@@ -310,7 +352,9 @@ void shard_build_abort(Index& ix);
 // query (blmx_query.hip).  mode: 0 = IDs (query_kmer_hash / query_get_hash), 1 = positions (query_get_pos_unitig),
 // 2 = membership byte.  d_minis == nullptr -> minimizers are computed on the device.
 enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2, kQueryIds32 = 3 /* IDs as 32-bit words, 0xffffffff = absent */,
-                 kQueryXcdMajor = 0x100 /* flag: XCD-major block order */ };
+                 kQueryXcdMajor = 0x100 /* flag: XCD-major block order */,
+                 kQueryNoFilter = 0x200 /* flag: the minimizers come from the caller and may be wrong: the absent-key filter only knows
+                                           what a query with the k-mer's OWN minimizer can find */ };
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
                   hipStream_t s);
 // Large batches: partition the queries by the top bits of their minimizer first (one counting pass), run the query

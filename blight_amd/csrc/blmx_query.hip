@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 		reinterpret_cast<uint8_t*>(out)[o] = id >= 0 ? 1 : 0;
 }
 
+// (An absent-key filter makes the absent half of a wave's lanes leave early; compacting the survivors through an LDS ring so that
+// the query body runs with all 64 lanes busy -- per workgroup, per wave, or persistent waves striding over the batch -- was built and
+// measured: 30 % fewer VALU instructions, but the kernel is bound by outstanding L1 misses, not by issue slots, and the dense body
+// raises the average L2 round trip from 713 to 979 cycles: 5.2 - 6.5 ms instead of 4.0 ms at C4.  Dropped;
+// profiles/r02_pmc_exp_compact_rejected_c4.json next to r02_pmc_exp_filter_perlane_c4.json.)
+
 // Generic window for b > 8 (rare): same semantics, words fetched on demand.
 template <int KW>
 __global__ __launch_bounds__(256) void k_query_anyb(DeviceIndexView v, const uint64_t* __restrict__ kmers,
@@ -316,7 +322,10 @@ template <int KW>
 static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, int mode,
                             hipStream_t s)
 {
-	const DeviceIndexView v = ix.view();
+	DeviceIndexView v = ix.view();
+	if (mode & kQueryNoFilter)
+		v.filter = nullptr;
+	mode &= ~(int)kQueryNoFilter;
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	unsigned grid = grid_for(nq, 256);
 	if ((mode & kQueryXcdMajor) && v.b <= 8)

@@ -509,12 +509,13 @@ namespace {
 constexpr char kImageMagic[8] = {'B', 'L', 'M', 'X', 'I', 'D', 'X', '1'};
 constexpr char kImageEnd[8] = {'B', 'L', 'M', 'X', 'E', 'N', 'D', '1'};
 constexpr uint32_t kImageVersion = 1;
+constexpr uint32_t kImageVersionFilter = 2;  // version 1 + the absent-key filter after the fallback ranks
 
 struct FileHeader {
 	char magic[8];
 	uint32_t version, abi, stats_bytes, group_desc_bytes;
 	uint32_t k, m, log2_mphf, log2_superbuckets, bits_saved, kmer_bytes;
-	uint32_t kw, gshift, nbuckets, ngroups, shard_rank, shard_world, nbounds, pad;
+	uint32_t kw, gshift, nbuckets, ngroups, shard_rank, shard_world, nbounds, filter_bpk;  // filter_bpk: 0 (version 1 images) = no absent-key filter
 	uint64_t nfb, positions_words, seq_words, total_lines, total_logical_words;
 	blmx_stats_t st;
 };
@@ -575,13 +576,15 @@ void save_index(Index& ix, const char* path)
 	if (!ix.built)
 		throw StatusError{BLMX_ESTATE, "index not built"};
 	BLMX_HIP(hipSetDevice(ix.prm.device));
+	ix.filter_wait();  // the image holds the finished filter
 	File fh;
 	fh.f = fopen(path, "wb");
 	if (!fh.f)
 		throw StatusError{BLMX_EIO, "Problem with files opening"};
 	FileHeader h{};
 	memcpy(h.magic, kImageMagic, 8);
-	h.version = kImageVersion;
+	h.version = ix.filter_bpk ? kImageVersionFilter : kImageVersion;
+	h.filter_bpk = ix.filter_bpk;
 	h.abi = BLMX_ABI_VERSION;
 	h.stats_bytes = sizeof(blmx_stats_t);
 	h.group_desc_bytes = sizeof(GroupDesc);
@@ -611,6 +614,8 @@ void save_index(Index& ix, const char* path)
 	pin.ensure(kBounce);
 	for (const DevBuf* b : {&ix.buckets, &ix.groups, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks})
 		put_device(fh.f, *b, pin, ix.stream);
+	if (ix.filter_bpk)
+		put_device(fh.f, ix.filter, pin, ix.stream);
 	put(fh.f, kImageEnd, 8);
 	if (fflush(fh.f) != 0)
 		throw StatusError{BLMX_EIO, "short write to the index file"};
@@ -623,7 +628,7 @@ int peek_index_params(const char* path, blmx_params& out)
 	if (!fh.f)
 		return BLMX_EIO;
 	FileHeader h{};
-	if (fread(&h, 1, sizeof h, fh.f) != sizeof h || memcmp(h.magic, kImageMagic, 8) != 0 || h.version != kImageVersion)
+	if (fread(&h, 1, sizeof h, fh.f) != sizeof h || memcmp(h.magic, kImageMagic, 8) != 0 || (h.version != kImageVersion && h.version != kImageVersionFilter))
 		return BLMX_EIO;
 	out = blmx_params{};
 	out.k = h.k;
@@ -649,7 +654,8 @@ void load_index(Index& ix, const char* path)
 	get(fh.f, &h, sizeof h);
 	if (memcmp(h.magic, kImageMagic, 8) != 0)
 		throw StatusError{BLMX_EIO, "not a Blight MI355X index file"};
-	if (h.version != kImageVersion || h.stats_bytes != sizeof(blmx_stats_t) || h.group_desc_bytes != sizeof(GroupDesc))
+	if ((h.version != kImageVersion && h.version != kImageVersionFilter) || (h.version == kImageVersion && h.filter_bpk) || h.filter_bpk > 32 ||
+	    h.stats_bytes != sizeof(blmx_stats_t) || h.group_desc_bytes != sizeof(GroupDesc))
 		throw StatusError{BLMX_EIO, "index file written by an incompatible library version"};
 	if (h.k != ix.prm.k || h.m != ix.prm.m || h.log2_mphf != ix.prm.log2_mphf || h.bits_saved != ix.prm.bits_saved ||
 	    h.kmer_bytes != ix.prm.kmer_bytes)
@@ -671,6 +677,16 @@ void load_index(Index& ix, const char* path)
 	get_device(fh.f, ix.lines, (h.total_lines + 1) * kLineBytes, pin, s);
 	get_device(fh.f, ix.fb_keys, (h.nfb + 1) * 8 * h.kw, pin, s);
 	get_device(fh.f, ix.fb_ranks, (h.nfb + 1) * 8, pin, s);
+	ix.filter_bpk = 0;
+	ix.filter_words = 0;
+	if (h.filter_bpk) {
+		if (h.st.local_number_kmer > (1ull << 40))
+			throw StatusError{BLMX_EIO, "index file is inconsistent (header)"};
+		ix.filter_words = ((h.st.local_number_kmer * h.filter_bpk) >> 6) + 64;
+		get_device(fh.f, ix.filter, ix.filter_words * 8, pin, s);
+		ix.filter_bpk = h.filter_bpk;
+	}
+	ix.filter_state.store(2);
 	char end[8];
 	get(fh.f, end, 8);
 	if (memcmp(end, kImageEnd, 8) != 0)
@@ -684,8 +700,9 @@ void load_index(Index& ix, const char* path)
 	// in BLMX_EIO here instead of a GPU memory fault later.
 	{
 		auto bad = [&](const char* what) {
-			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks})
+			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks, &ix.filter})
 				b->release();
+			ix.filter_bpk = 0;
 			ix.h_groups.clear();
 			ix.h_fb_group.clear();
 			throw StatusError{BLMX_EIO, std::string("index file is inconsistent (") + what + ")"};
@@ -710,6 +727,12 @@ void load_index(Index& ix, const char* path)
 			    gd.posstart > h.positions_words * 64 || gd.nkeys * gd.nbits > h.positions_words * 64 - gd.posstart || gd.fb_start > h.nfb ||
 			    gd.fb_count > h.nfb - gd.fb_start)
 				bad("group table");
+			if (ix.filter_bpk) {  // the filter region a query of this group can touch (index_device.h: filter_word)
+				const uint64_t local = gd.prefix - ix.h_groups[0].prefix;
+				if (gd.prefix < ix.h_groups[0].prefix || local > h.st.local_number_kmer ||
+				    ((local * ix.filter_bpk) >> 6) + (((gd.size[0] >> 1) * ix.filter_bpk) >> 6) + 1 > ix.filter_words)
+					bad("filter regions");
+			}
 			keys += gd.nkeys;
 		}
 		if (keys != h.st.local_number_kmer)

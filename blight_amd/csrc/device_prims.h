@@ -34,6 +34,23 @@ template <> struct Kmer<2> {
 	__host__ __device__ __forceinline__ bool operator<(const Kmer& o) const { return hi < o.hi || (hi == o.hi && lo < o.lo); }
 };
 
+template <int KW> __host__ __device__ __forceinline__ Kmer<KW> make_kmer(uint64_t lo, uint64_t hi);
+template <> __host__ __device__ __forceinline__ Kmer<1> make_kmer<1>(uint64_t lo, uint64_t)
+{
+	Kmer<1> x;
+	x.lo = lo;
+	return x;
+}
+template <> __host__ __device__ __forceinline__ Kmer<2> make_kmer<2>(uint64_t lo, uint64_t hi)
+{
+	Kmer<2> x;
+	x.lo = lo;
+	x.hi = hi;
+	return x;
+}
+__host__ __device__ __forceinline__ uint64_t kmer_hi(const Kmer<1>&) { return 0; }
+__host__ __device__ __forceinline__ uint64_t kmer_hi(const Kmer<2>& x) { return x.hi; }
+
 // nuc2int, kmer.h:56-69: A0 C1 T2 G3 = (c >> 1) & 3, either case; returns 4 for anything else.
 __device__ __forceinline__ uint32_t nuc_code(uint8_t c)
 {

@@ -119,6 +119,37 @@ __device__ __forceinline__ GroupHead load_bucket_and_qhead(const BucketDesc* __r
 	return h;
 }
 
+// ---- absent-key filter ---------------------------------------------------------------------------------------------------------
+// A blocked Bloom filter over the keys (plus the few non-keys the reference's scan can still find, see k_filter_junctions): ONE
+// 64-bit word per probe, five bits of it set per key.  The word of a key lies in its MPHF group's own region -- words
+// [local_prefix * bpk / 64, + (size0 / 2) * bpk / 64) -- so that the filter slice of a partition bin is as cache-resident as the
+// bin's MPHF lines.  No counterpart in the reference: a k-mer the filter rejects is one the reference's lookup would have carried
+// through 4 levels on average, a position read and a 2^b window before answering -1 as well.
+__device__ __forceinline__ uint64_t filter_hash(uint64_t lo, uint64_t hi)
+{
+	uint64_t h = lo ^ (hi * 0x9e3779b97f4a7c15ull);
+	h ^= h >> 33;
+	h *= 0xff51afd7ed558ccdull;
+	h ^= h >> 29;
+	h *= 0xc4ceb9fe1a85ec53ull;
+	return h ^ (h >> 32);
+}
+template <int KW> __device__ __forceinline__ uint64_t filter_hash(Kmer<KW> x);
+template <> __device__ __forceinline__ uint64_t filter_hash<1>(Kmer<1> x) { return filter_hash(x.lo, 0); }
+template <> __device__ __forceinline__ uint64_t filter_hash<2>(Kmer<2> x) { return filter_hash(x.lo, x.hi); }
+__device__ __forceinline__ uint64_t filter_mask(uint64_t h)
+{
+	const uint32_t u = (uint32_t)(h >> 32);
+	return (1ull << (u & 63u)) | (1ull << ((u >> 6) & 63u)) | (1ull << ((u >> 12) & 63u)) | (1ull << ((u >> 18) & 63u)) | (1ull << ((u >> 24) & 63u));
+}
+__device__ __forceinline__ uint64_t filter_word(uint64_t local_prefix, uint64_t size0, uint32_t bpk, uint64_t h)
+{
+	const uint64_t first = (local_prefix * bpk) >> 6;
+	uint64_t words = ((size0 >> 1) * bpk) >> 6;  // size0 / 2 = the group's key count rounded up to 32: a few words shared with the next group
+	words = words ? words : 1;
+	return first + (((h & 0xffffffffull) * words) >> 32);  // a group holds fewer than 2^32 keys
+}
+
 // mphf::lookup restricted to the level bit arrays (bbhash.h:561-566): probe levels until a set bit is found and rank it.
 // Levels 0..2 use the sizes that came with the group head; deeper levels read their size on demand.
 template <int KW>

@@ -381,3 +381,73 @@ def test_device_murmur3_x64_128(B, O):
             n = length or kb
             want = [O.p_murmur3_x64_128(bytes(r[:n]), seed) for r in data]
             assert [(int(a), int(b)) for a, b in got] == want
+
+
+@pytest.mark.parametrize("k,kb,m,n,b,nseq", [(31, 8, 7, 5, 6, 400), (21, 8, 5, 3, 8, 300), (63, 16, 9, 7, 8, 300)])
+def test_absent_filter_keeps_every_answer_of_the_reference(B, O, k, kb, m, n, b, nseq):
+    """The absent-key filter (a blocked Bloom filter over the keys, index_device.h) must never change an answer.  The hard case are
+    the reference's own false positives: its 2^b scan compares whatever it reads from the bucket's concatenated sequence, so a k-mer
+    read across the junction of two super-k-mers -- not a key of anybody -- is answered with an ID when the MPHF happens to send it to
+    a rank whose window covers that place.  Every k-mer readable ANYWHERE in the packed sequence is queried: the answers equal the
+    oracle's with the filter on, off, and before its second pass has finished; the reference's false positives really occur in this
+    data, and a filter without the second pass (test hook) loses exactly those."""
+    rng = np.random.default_rng(1000 + k + b)
+    seqs = [_rand_seq(rng, k + int(rng.integers(0, 60))) for _ in range(nseq)]
+    seqs += [seqs[1], seqs[2][3:], "A" * (k + 9)]
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    ix = _build(B, k, m, n, b, seqs, kmer_bytes=kb)
+    assert ix.stats()["device_bytes"] > 0
+    words = ix.export("seq")
+    total_nt = ix.stats()["total_nt"]
+    nts = ((words[:, None] >> np.arange(62, -2, -2, dtype=np.uint64)[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)[:total_nt]
+    vals = set()
+    v = 0
+    mask = (1 << (2 * k)) - 1
+    for p, c in enumerate(nts.tolist()):
+        v = ((v << 2) | c) & mask
+        if p >= k - 1:
+            vals.add(min(v, O.p_rc(v, k, kb)))
+    keys = set()
+    for s in seqs:
+        keys.update(O.array_to_kmers(orc.canonical_kmers(s), kb))
+    assert keys <= vals
+    q = O.kmers_to_array(sorted(vals), kb)
+    want = orc.query_kmers(q if kb == 8 else q.reshape(-1, 2))
+    is_key = np.array([x in keys for x in sorted(vals)])
+    assert (want[is_key] >= 0).all()
+    ref_false_positives = int((want[~is_key] >= 0).sum())
+    assert ref_false_positives > 0, "the data must contain answers the reference gives for k-mers that are not keys"
+    got_early = ix.query_kmer_hash(q.reshape(-1))          # maybe before the background pass has finished: unfiltered then
+    ix.set_tuning("absent_filter", 1)                        # waits for the pass
+    got_on = ix.query_kmer_hash(q.reshape(-1))
+    ix.set_tuning("query_binning", 1)                        # the partitioned pipeline
+    got_binned = ix.query_kmer_hash(np.tile(q.reshape(-1, kb // 8), (3, 1)).reshape(-1))
+    ix.set_tuning("query_binning", 0)
+    ix.set_tuning("absent_filter", 0)
+    got_off = ix.query_kmer_hash(q.reshape(-1))
+    for got in (got_early, got_on, got_off, got_binned[:len(want)], got_binned[len(want):2 * len(want)]):
+        assert np.array_equal(got, want)
+    # sequences through the read front end (fused kernel): junction k-mers inside longer reads
+    reads = ["".join("ACTG"[c] for c in nts[a:a + 3 * k].tolist()) for a in range(0, max(1, total_nt - 3 * k), 97)]
+    ix.set_tuning("absent_filter", 1)
+    assert np.array_equal(ix.query_sequences_hash(reads), np.concatenate([orc.query_sequence(r) for r in reads]))
+    # the image carries the finished filter
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        ix.dump_disk(td + "/i.blmx")
+        ld = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+        ld.load_disk(td + "/i.blmx")
+        assert np.array_equal(ld.query_kmer_hash(q.reshape(-1)), want)
+        assert ld.stats()["device_bytes"] == ix.stats()["device_bytes"]
+    # without the second pass the filter rejects (some of) the reference's false positives and nothing else
+    bare = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+    bare.set_tuning("filter_junctions", 0)
+    bare.construct_index_from_sequences(seqs)
+    got_bare = bare.query_kmer_hash(q.reshape(-1))
+    wrong = got_bare != want
+    assert wrong.sum() > 0 and not wrong[is_key].any() and (got_bare[wrong] == -1).all()
+    none = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+    none.set_tuning("filter_bits", 0)
+    none.construct_index_from_sequences(seqs)
+    assert np.array_equal(none.query_kmer_hash(q.reshape(-1)), want)
+    assert none.stats()["device_bytes"] < ix.stats()["device_bytes"]
