@@ -267,7 +267,8 @@ struct Index {
 	// staging for host-buffer queries
 	DevBuf q_in, q_aux, q_out;
 	// scratch of the locality-binned batch query (grow-only; guarded by bin_mu)
-	DevBuf b_bins, b_minis, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp;
+	DevBuf b_bins, b_minis, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp, b_plan, b_frac;
+	int plan_bits = -1;  // bin count (log2) the learnt shares in b_frac belong to, -1 = nothing learnt yet
 	std::mutex bin_mu;
 	hipEvent_t bin_done = nullptr;       // recorded after each binned pipeline: a call on another stream waits for it
 	hipStream_t bin_last_stream = nullptr;
@@ -285,7 +286,8 @@ struct Index {
 	int tune_query_heads = 1;    // 0 = query kernels read the full group descriptor instead of the compact 32-B head
 	int tune_reads_mode = 0;     // sequence / file queries: 0 = automatic, 1 = always fused front end + query, 2 = always front end -> binned pipeline
 	uint32_t staged_tile = 0;    // tile of the last blmx_partition_device (blmx_gather_ids_device reads the order back tile by tile)
-	int tune_partition = 0;      // batch partition: 0 / 2 = exact (histogram, scan, scatter), 1 = one pass into fixed-capacity bins
+	int tune_partition = 0;      // batch partition: 0 = exact for the first batch, then one pass into bin regions sized after the previous batch;
+	                             // 1 = always one pass; 2 = always exact (histogram, scan, scatter)
 	int tune_slot_slack_pct = 0; // one-pass partition: slots per bin = mean occupancy + this many percent (0 = default 12)
 	int tune_narrow_ids = 1;     // host-buffer results cross PCIe as 32-bit words when every ID fits (0 = always 64-bit)
 	int tune_absent_filter = 1;  // queries consult the absent-key filter (when the index was built with one)

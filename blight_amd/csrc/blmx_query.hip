@@ -532,17 +532,75 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 // for every bin 4-8 % of the batch overflows and the slot walk of the query kernel is 0.3 ms (k = 63: 0.9 ms) slower than on
 // the dense order: 7.28 vs 7.31 ms per step -- no gain without per-bin capacities learnt from earlier batches.  The exact
 // partition stays the default; this path is selected with blmx_set_tuning("partition", 1).
-struct SlotPlan {
-	uint32_t nbins, cap;     // slots per bin (multiple of 256)
-	uint32_t ovf_cap;        // slots of the overflow region
-	uint32_t main_blocks;    // nbins * cap / 256, a multiple of 8
+struct SlotPlan {            // lives in HBM (written by k_plan_make, read by the slot kernels): no host round trip per batch
+	uint32_t nbins;
+	uint32_t main_slots;     // slots of all bin regions, rounded up to a multiple of 2048 (8 XCDs x 256-slot blocks)
+	uint32_t ovf_cap;        // slots of the overflow region behind them
 	uint32_t ovf_blocks;     // looping blocks that answer the overflow region
-	__host__ __device__ uint64_t ovf_base() const { return (uint64_t)nbins * cap; }
-	__host__ __device__ uint64_t total_slots() const { return (uint64_t)nbins * cap + ovf_cap; }
+	uint32_t base[(1 << kBinBitsMax) + 1];  // first slot of every bin region (multiples of 256); base[nbins] = end of the last one
+	__device__ uint64_t ovf_base() const { return main_slots; }
+	__device__ uint64_t total_slots() const { return (uint64_t)main_slots + ovf_cap; }
 };
 
+// Capacities of the bin regions for a batch of nq k-mers: the share every bin had of the PREVIOUS batch (frac, learnt by k_plan_learn*)
+// plus slack_pct percent plus one block, or equal shares when nothing has been learnt.  One workgroup, one thread per bin.
+__global__ __launch_bounds__(1 << kBinBitsMax) void k_plan_make(const float* __restrict__ frac, uint64_t nq, uint32_t nbins, uint32_t slack_pct,
+                                                              uint32_t max_main_slots, uint32_t ovf_cap, uint32_t ovf_blocks, SlotPlan* __restrict__ sp,
+                                                              uint32_t* __restrict__ cursors)
+{
+	__shared__ uint32_t s_wsum[(1 << kBinBitsMax) / 64];
+	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+	uint32_t cap = 0;
+	if (t < nbins) {
+		const double share = frac ? (double)frac[t] * (double)nq : (double)nq / (double)nbins;
+		const double want = share * (100.0 + (double)slack_pct) / 100.0 + 256.0;
+		cap = (uint32_t)(((uint64_t)want + 255u) & ~255ull);
+	}
+	uint32_t v = cap;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t u = __shfl_up(v, o);
+		if ((int)lane >= o)
+			v += u;
+	}
+	if (lane == 63)
+		s_wsum[wave] = v;
+	__syncthreads();
+	uint32_t wbase = 0;
+	for (uint32_t w = 0; w < wave; w++)
+		wbase += s_wsum[w];
+	uint32_t start = wbase + v - cap;
+	start = min(start, max_main_slots);  // what does not fit the region goes to the overflow slots
+	const uint32_t end = min(start + cap, max_main_slots);
+	if (t < nbins)
+		sp->base[t] = start;
+	if (t + 1 == nbins) {
+		sp->base[nbins] = end;
+		sp->nbins = nbins;
+		sp->main_slots = (end + 2047u) & ~2047u;  // <= max_main_slots, itself a multiple of 2048
+		sp->ovf_cap = ovf_cap;
+		sp->ovf_blocks = ovf_blocks;
+	}
+	if (t <= nbins)
+		cursors[t] = 0;
+}
+// what the capacities of the next batch are made from: this batch's k-mers per bin
+__global__ void k_plan_learn(const uint32_t* __restrict__ cursors, uint64_t nq, uint32_t nbins, float* __restrict__ frac)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nbins)
+		frac[t] = (float)((double)cursors[t] / (double)nq);
+}
+__global__ void k_plan_learn_offs(const uint32_t* __restrict__ offs, uint32_t nblk, uint64_t nq, uint32_t nbins, float* __restrict__ frac)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nbins) {
+		const uint64_t a = offs[(uint64_t)t * nblk], z = t + 1 < nbins ? offs[(uint64_t)(t + 1) * nblk] : nq;
+		frac[t] = (float)((double)(z - a) / (double)nq);
+	}
+}
+
 template <int KW>
-__global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, SlotPlan sp, const uint64_t* __restrict__ kmers,
+__global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, const SlotPlan* __restrict__ sp, const uint64_t* __restrict__ kmers,
                                                              const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
                                                              uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint32_t* __restrict__ inv)
 {
@@ -554,10 +612,19 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	__shared__ uint32_t s_cnt[kNB];     // k-mers of this tile per bin, then the tile-local start of the bin
 	__shared__ uint32_t s_gbase[kNB];   // first slot (inside the bin) of this tile's run
 	__shared__ uint32_t s_obase[kNB];   // first overflow slot of the part of the run that does not fit the bin
+	__shared__ uint32_t s_rbase[kNB];   // the bin's region: first slot ...
+	__shared__ uint32_t s_rcap[kNB];    // ... and slots
 	__shared__ uint32_t s_wsum[kBinThreads / 64];
 	static_assert(kBinThreads == kNB, "one bin per thread");
 	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	s_cnt[t] = 0;
+	{
+		const uint32_t nb = sp->nbins;
+		const uint32_t rb = t < nb ? sp->base[t] : 0u;
+		s_rbase[t] = rb;
+		s_rcap[t] = t < nb ? sp->base[t + 1] - rb : 0u;
+	}
+	const uint32_t ovf_at = sp->main_slots, all_slots = sp->main_slots + sp->ovf_cap, nbins_p = sp->nbins;
 	__syncthreads();
 	const uint64_t base = (uint64_t)blockIdx.x * kTile;
 	Kmer<KW> x[kPer];
@@ -587,10 +654,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 			s_wsum[wave] = v;
 		uint32_t g = 0, ob = 0;
 		if (c) {
+			const uint32_t capb = s_rcap[t];
 			g = atomicAdd(&cursors[t], c);
-			const uint32_t over = g + c > sp.cap ? g + c - max(g, sp.cap) : 0u;
+			const uint32_t over = g + c > capb ? g + c - max(g, capb) : 0u;
 			if (over)
-				ob = atomicAdd(&cursors[sp.nbins], over);
+				ob = atomicAdd(&cursors[nbins_p], over);
 		}
 		s_gbase[t] = g;
 		s_obase[t] = ob;
@@ -601,10 +669,9 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		s_cnt[t] = wbase + v - c;  // tile-local start of bin t
 	}
 	__syncthreads();
-	const uint64_t ovf_base = sp.ovf_base();
 	auto slot_of = [&](uint32_t b, uint32_t r) -> uint64_t {  // r-th k-mer of this tile's run of bin b
-		const uint32_t g = s_gbase[b], gs = g + r;
-		return gs < sp.cap ? (uint64_t)b * sp.cap + gs : ovf_base + s_obase[b] + (gs - max(g, sp.cap));
+		const uint32_t g = s_gbase[b], gs = g + r, capb = s_rcap[b];
+		return gs < capb ? (uint64_t)s_rbase[b] + gs : (uint64_t)ovf_at + s_obase[b] + (gs - max(g, capb));
 	};
 #pragma unroll
 	for (int e = 0; e < kPer; e++) {
@@ -620,7 +687,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 			}
 			s_mini[ls] = mini[e];
 			const uint64_t dst = slot_of(b, rank[e]);
-			inv[i] = dst < sp.total_slots() ? (uint32_t)dst : 0xffffffffu;
+			inv[i] = dst < all_slots ? (uint32_t)dst : 0xffffffffu;
 		}
 	}
 	__syncthreads();
@@ -629,7 +696,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		const uint32_t mi = s_mini[sidx];
 		const uint32_t b = bm.bin_of(mi);
 		const uint64_t dst = slot_of(b, sidx - s_cnt[b]);
-		if (dst >= sp.total_slots())
+		if (dst >= all_slots)
 			continue;  // cannot happen: the overflow region holds a whole batch
 		if (slot_minis)
 			slot_minis[dst] = mi;
@@ -646,7 +713,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 // behind them loop over the overflow region.  IDs go to ids[slot].
 template <int KW, int LOGP>
 __device__ __forceinline__ void query_slot(const DeviceIndexView& v, const uint64_t* __restrict__ slots, const uint32_t* __restrict__ slot_minis,
-                                           int64_t* __restrict__ ids, uint64_t slot)
+                                           void* __restrict__ ids, bool narrow, uint64_t slot)
 {
 	const Kmer<KW> x = load_kmer<KW>(slots, slot);
 	const Kmer<KW> xr = kmer_rc<KW>(x, v.k);
@@ -654,31 +721,48 @@ __device__ __forceinline__ void query_slot(const DeviceIndexView& v, const uint6
 	int64_t id;
 	int32_t posj;
 	query_one<KW, LOGP, false>(v, x, xr, mini, id, posj);
-	ids[slot] = id;
+	if (narrow)
+		reinterpret_cast<uint32_t*>(ids)[slot] = (uint32_t)id;
+	else
+		reinterpret_cast<int64_t*>(ids)[slot] = id;
 }
+// the grid covers the largest region the plan may describe; workgroups behind the actual one leave at once
 template <int KW, int LOGP>
-__global__ __launch_bounds__(256) void k_query_slots(DeviceIndexView v, SlotPlan sp, const uint32_t* __restrict__ cursors, const uint64_t* __restrict__ slots,
-                                                     const uint32_t* __restrict__ slot_minis, int64_t* __restrict__ ids)
+__global__ __launch_bounds__(256) void k_query_slots(DeviceIndexView v, const SlotPlan* __restrict__ sp, const uint32_t* __restrict__ cursors,
+                                                     const uint64_t* __restrict__ slots, const uint32_t* __restrict__ slot_minis, void* __restrict__ ids,
+                                                     int narrow)
 {
-	const uint32_t blk = (blockIdx.x & 7u) * (sp.main_blocks >> 3) + (blockIdx.x >> 3);
-	const uint32_t per_bin = sp.cap >> 8, b = blk / per_bin;
-	const uint32_t used = min(cursors[b], sp.cap);
-	const uint64_t slot = (uint64_t)blk * 256 + threadIdx.x;
-	if (slot < (uint64_t)b * sp.cap + used)
-		query_slot<KW, LOGP>(v, slots, slot_minis, ids, slot);
+	const uint32_t mb = sp->main_slots >> 8;  // a multiple of 8
+	if (blockIdx.x >= mb)
+		return;
+	const uint32_t blk = (blockIdx.x & 7u) * (mb >> 3) + (blockIdx.x >> 3);
+	const uint32_t first = blk << 8;
+	uint32_t lo = 0, hi = sp->nbins;  // the bin whose region holds this block: base[lo] <= first < base[lo + 1] (uniform: scalar loads)
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (sp->base[mid] <= first)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const uint32_t rb = sp->base[lo], cap = sp->base[lo + 1] - rb;
+	const uint32_t used = min(cursors[lo], cap);
+	const uint32_t slot = first + threadIdx.x;
+	if (slot < rb + used)
+		query_slot<KW, LOGP>(v, slots, slot_minis, ids, narrow != 0, slot);
 }
 
 // The overflow region (usually empty) in its own launch: a fixed number of blocks loop over it.  (Looping blocks inside
 // k_query_slots made the register allocator keep 256 VGPRs for 128-bit k-mers, a call 70-98: the common path stays loop-free.)
 template <int KW, int LOGP>
-__global__ __launch_bounds__(256) void k_query_slots_overflow(DeviceIndexView v, SlotPlan sp, const uint32_t* __restrict__ cursors,
+__global__ __launch_bounds__(256) void k_query_slots_overflow(DeviceIndexView v, const SlotPlan* __restrict__ sp, const uint32_t* __restrict__ cursors,
                                                               const uint64_t* __restrict__ slots, const uint32_t* __restrict__ slot_minis,
-                                                              int64_t* __restrict__ ids)
+                                                              void* __restrict__ ids, int narrow)
 {
-	const uint64_t end = sp.ovf_base() + min(cursors[sp.nbins], sp.ovf_cap);
+	const uint64_t end = sp->ovf_base() + min(cursors[sp->nbins], sp->ovf_cap);
 #pragma nounroll
-	for (uint64_t slot = sp.ovf_base() + (uint64_t)blockIdx.x * 256 + threadIdx.x; slot < end; slot += (uint64_t)sp.ovf_blocks * 256)
-		query_slot<KW, LOGP>(v, slots, slot_minis, ids, slot);
+	for (uint64_t slot = sp->ovf_base() + (uint64_t)blockIdx.x * 256 + threadIdx.x; slot < end; slot += (uint64_t)gridDim.x * 256)
+		query_slot<KW, LOGP>(v, slots, slot_minis, ids, narrow != 0, slot);
 }
 
 // out[i] = ids_sorted[inv[i]].  One block per partition TILE: the (tile, bin) runs written by k_bin_scatter are consumed by
@@ -771,12 +855,12 @@ void partition_launch(Index& ix, const PartitionPlan& pl, const uint64_t* km, co
 }
 
 PartitionPlan partition_batch(Index& ix, const void* d_kmers, const uint32_t* d_minis_in, uint64_t nq, bool owner_bins, void* d_sorted,
-                              uint32_t* d_sorted_minis, uint32_t* d_inv, hipStream_t s)
+                              uint32_t* d_sorted_minis, uint32_t* d_inv, hipStream_t s, int default_bits = kBinBitsDefault)
 {
 	const int mbits = 2 * (int)ix.prm.m - 1;
 	PartitionPlan pl;
 	pl.handoff = d_sorted_minis != nullptr;
-	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsDefault;
+	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : default_bits;
 	int tbits = mbits < want_bits ? mbits : want_bits;
 	const uint32_t nbound = (owner_bins && ix.shard_world > 1) ? ix.shard_world - 1 : 0;
 	while (tbits > 1 && (1u << tbits) + nbound > (1u << kBinBitsMax))  // the kernels hold at most 2^kBinBitsMax bins
@@ -838,15 +922,15 @@ bool query_batch_worth_binning(const Index& ix, uint64_t nq)
 }
 
 template <int KW>
-static void launch_query_slots_kw(const Index& ix, const SlotPlan& sp, const uint32_t* d_cursors, const void* d_slots, const uint32_t* d_slot_minis,
-                                  int64_t* d_ids, hipStream_t s)
+static void launch_query_slots_kw(const Index& ix, const SlotPlan* d_plan, uint32_t max_main_blocks, uint32_t ovf_blocks, const uint32_t* d_cursors,
+                                  const void* d_slots, const uint32_t* d_slot_minis, void* d_ids, bool narrow, hipStream_t s)
 {
 	const DeviceIndexView v = ix.view();
 	const uint64_t* sl = reinterpret_cast<const uint64_t*>(d_slots);
 #define BLMX_QS(LP)                                                                                                                                    \
 	case LP:                                                                                                                                           \
-		hipLaunchKernelGGL((k_query_slots<KW, LP>), dim3(sp.main_blocks), dim3(256), 0, s, v, sp, d_cursors, sl, d_slot_minis, d_ids);                 \
-		hipLaunchKernelGGL((k_query_slots_overflow<KW, LP>), dim3(sp.ovf_blocks), dim3(256), 0, s, v, sp, d_cursors, sl, d_slot_minis, d_ids);        \
+		hipLaunchKernelGGL((k_query_slots<KW, LP>), dim3(max_main_blocks), dim3(256), 0, s, v, d_plan, d_cursors, sl, d_slot_minis, d_ids, (int)narrow); \
+		hipLaunchKernelGGL((k_query_slots_overflow<KW, LP>), dim3(ovf_blocks), dim3(256), 0, s, v, d_plan, d_cursors, sl, d_slot_minis, d_ids, (int)narrow); \
 		break;
 	switch (v.b) {
 		BLMX_QS(0)
@@ -864,68 +948,86 @@ static void launch_query_slots_kw(const Index& ix, const SlotPlan& sp, const uin
 #undef BLMX_QS
 }
 
-// partition into fixed-capacity bins (one pass) -> query the slots -> gather the IDs into the caller's order
+// 1024 bins for the one-pass partition (and for the exact pass in front of it, which it learns from): its runs are written region by
+// region, and with the histogram pass gone the query kernel's gain from finer bins (3.9 -> 3.5 ms at C4) is no longer eaten by the
+// passes around it (C4: 6.14 -> 5.73 ms per step)
+constexpr int kBinBitsOnepass = 10;
+static int onepass_bits(const Index& ix)
+{
+	const int mbits = 2 * (int)ix.prm.m - 1;
+	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsOnepass;
+	return std::max(3, std::min(mbits, want_bits));
+}
+
+// partition into bin regions whose capacities follow the previous batch (one pass, no histogram) -> query the slots -> gather the
+// IDs into the caller's order -> learn this batch's shares.  Everything stays on the device: no host round trip.
 static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, bool handoff, hipStream_t s)
 {
 	const int mbits = 2 * (int)ix.prm.m - 1;
-	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsDefault;
-	const int tbits = std::max(3, std::min(mbits, want_bits));  // main_blocks must be a multiple of 8
+	const int tbits = onepass_bits(ix);
 	BinMap bm;
 	bm.shift = mbits - tbits;
 	bm.nbound = 0;
-	SlotPlan sp;
-	sp.nbins = 1u << tbits;
-	const uint64_t mean = (nq + sp.nbins - 1) / sp.nbins;
-	const uint64_t pct = ix.tune_slot_slack_pct > 0 ? (uint64_t)ix.tune_slot_slack_pct : 12;
-	const uint64_t slack = std::max<uint64_t>(mean * pct / 100, (uint64_t)(6.0 * std::sqrt((double)mean)) + 64);
-	sp.cap = (uint32_t)(((mean + slack + 255) / 256) * 256);
-	sp.ovf_cap = (uint32_t)nq;
-	sp.main_blocks = sp.nbins * (sp.cap >> 8);
-	sp.ovf_blocks = 1024;
-	const uint64_t slots = sp.total_slots();
+	const uint32_t nbins = 1u << tbits;
+	const bool learnt = ix.plan_bits == tbits;
+	// slack on top of the learnt shares (a few percent: consecutive batches of one workload differ by sampling noise) or, with nothing
+	// learnt, on top of equal shares (minimizer bins are uneven: whatever does not fit goes through the overflow region)
+	const uint32_t pct = ix.tune_slot_slack_pct > 0 ? (uint32_t)ix.tune_slot_slack_pct : (learnt ? 6u : 12u);
+	const uint64_t max_main = ((nq + nq * pct / 100 + (uint64_t)nbins * 512 + 2047) / 2048) * 2048;
+	const uint64_t slots = max_main + nq;
 	if (slots >= 0xffffffffull)
 		throw StatusError{BLMX_ELIMIT, "a partitioned batch holds fewer than 2^31 k-mers"};
 	const uint32_t tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
 	const uint32_t nblk = (uint32_t)((nq + tile - 1) / tile);
+	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
 	ensure_buf(ix.b_sorted, slots * 8 * (size_t)ix.KW, s);
 	ensure_buf(ix.b_inv, nq * 4, s);
 	ensure_buf(ix.b_ids, slots * 8, s);
-	ensure_buf(ix.b_offs, ((size_t)sp.nbins + 1) * 4, s);
+	ensure_buf(ix.b_offs, ((size_t)nbins + 1) * 4, s);
+	ensure_buf(ix.b_plan, sizeof(SlotPlan), s);
+	ensure_buf(ix.b_frac, sizeof(float) << kBinBitsMax, s);
 	if (handoff)
 		ensure_buf(ix.b_minis, slots * 4, s);
 	uint32_t* d_slot_minis = handoff ? ix.b_minis.as<uint32_t>() : nullptr;
 	uint32_t* d_cursors = ix.b_offs.as<uint32_t>();
-	BLMX_HIP(hipMemsetAsync(d_cursors, 0, ((size_t)sp.nbins + 1) * 4, s));
+	const SlotPlan* d_plan = ix.b_plan.as<SlotPlan>();
+	const uint32_t ovf_blocks = 1024;
+	hipLaunchKernelGGL(k_plan_make, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac.as<float>() : nullptr, nq, nbins, pct, (uint32_t)max_main,
+	                   (uint32_t)nq, ovf_blocks, ix.b_plan.as<SlotPlan>(), d_cursors);
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	ix.prof_mark(2, s);
 	ix.prof_mark(3, s);
 	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp, km, d_minis, nq, d_cursors,
+		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
 		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, ix.b_inv.as<uint32_t>());
 	else
-		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp, km, d_minis, nq, d_cursors,
+		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
 		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, ix.b_inv.as<uint32_t>());
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(4, s);
 	if (ix.KW == 1)
-		launch_query_slots_kw<1>(ix, sp, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.as<int64_t>(), s);
+		launch_query_slots_kw<1>(ix, d_plan, (uint32_t)(max_main >> 8), ovf_blocks, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.p, narrow, s);
 	else
-		launch_query_slots_kw<2>(ix, sp, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.as<int64_t>(), s);
+		launch_query_slots_kw<2>(ix, d_plan, (uint32_t)(max_main >> 8), ovf_blocks, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.p, narrow, s);
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(5, s);
-	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, tile, false, s);
+	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, tile, narrow, s);
 	ix.prof_mark(6, s);
+	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>());
+	ix.plan_bits = tbits;
 	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 2) {  // bin occupancy of this batch (synchronises)
-		std::vector<uint32_t> h(sp.nbins + 1);
+		std::vector<uint32_t> h(nbins + 1);
+		SlotPlan hp;
 		BLMX_HIP(hipMemcpyAsync(h.data(), d_cursors, h.size() * 4, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipMemcpyAsync(&hp, d_plan, sizeof hp, hipMemcpyDeviceToHost, s));
 		BLMX_HIP(hipStreamSynchronize(s));
 		uint32_t mx = 0, mn = ~0u;
-		for (uint32_t b2 = 0; b2 < sp.nbins; b2++) {
+		for (uint32_t b2 = 0; b2 < nbins; b2++) {
 			mx = std::max(mx, h[b2]);
 			mn = std::min(mn, h[b2]);
 		}
-		fprintf(stderr, "[blmx partition] nq %llu bins %u cap %u mean %llu min %u max %u overflow %u\n", (unsigned long long)nq, sp.nbins, sp.cap,
-		        (unsigned long long)mean, mn, mx, h[sp.nbins]);
+		fprintf(stderr, "[blmx partition] nq %llu bins %u learnt %d main slots %u (bound %llu) min %u max %u overflow %u\n", (unsigned long long)nq, nbins,
+		        (int)learnt, hp.main_slots, (unsigned long long)max_main, mn, mx, h[nbins]);
 	}
 }
 
@@ -950,7 +1052,9 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	// hand the minimizers over to the query kernel?  Known minimizers always travel; computed ones only for 128-bit k-mers
 	// (55 m-mers hashed once instead of twice; for 64-bit k-mers the extra 8 B/query of traffic ate the gain) unless tuned.
 	const bool handoff = ix.tune_mini_handoff >= 0 ? ix.tune_mini_handoff != 0 : (d_minis != nullptr || ix.KW == 2);
-	if (ix.tune_partition == 1 && ix.prm.bits_saved <= 8 && nq < (1ull << 31) && 2 * (int)ix.prm.m - 1 >= 3) {
+	// One pass into bin regions sized after the previous batch when there is one to learn from (automatic), always (1) or never (2)
+	const bool onepass_ok = ix.prm.bits_saved <= 8 && nq < (1ull << 31) && 2 * (int)ix.prm.m - 1 >= 3;
+	if (onepass_ok && (ix.tune_partition == 1 || (ix.tune_partition == 0 && ix.plan_bits == onepass_bits(ix)))) {
 		query_ids_onepass(ix, d_kmers, d_minis, nq, d_out, handoff, s);
 		partition_end(ix, s);
 		return;
@@ -961,7 +1065,8 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	ensure_buf(ix.b_sorted, nq * 8 * (size_t)ix.KW, s);
 	ensure_buf(ix.b_inv, nq * 4, s);
 	ensure_buf(ix.b_ids, nq * 8, s);
-	const PartitionPlan pl = partition_batch(ix, d_kmers, d_minis, nq, false, ix.b_sorted.p, d_sorted_minis, ix.b_inv.as<uint32_t>(), s);
+	const PartitionPlan pl = partition_batch(ix, d_kmers, d_minis, nq, false, ix.b_sorted.p, d_sorted_minis, ix.b_inv.as<uint32_t>(), s,
+	                                         (onepass_ok && ix.tune_partition == 0) ? kBinBitsOnepass : kBinBitsDefault);
 	// (storing each ID straight into the caller's slot from k_query was measured 2.8 ms SLOWER per 1e8 queries than this
 	// separate gather: 1e8 scattered 8-B stores cost more than reading the IDs back through the inverse permutation)
 	// The ordered IDs are 32-bit words when every ID fits: half the bytes written by the query kernel and gathered at random.
@@ -970,6 +1075,11 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	ix.prof_mark(5, s);
 	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, pl.tile, narrow, s);
 	ix.prof_mark(6, s);
+	if (onepass_ok && ix.tune_partition == 0 && pl.bm.nbound == 0 && (int)pl.nbins == (1 << onepass_bits(ix))) {  // the next batch can skip the histogram
+		ensure_buf(ix.b_frac, sizeof(float) << kBinBitsMax, s);
+		hipLaunchKernelGGL(k_plan_learn_offs, dim3((pl.nbins + 255) / 256), dim3(256), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, nq, pl.nbins, ix.b_frac.as<float>());
+		ix.plan_bits = onepass_bits(ix);
+	}
 	partition_end(ix, s);
 }
 
