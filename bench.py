@@ -321,17 +321,21 @@ def roofline_block(args, k, kw, b, nq, stages, step_ms, st):
     achieved = algo * nq / (kq_ms * 1e-3) / 1e9
     pipe_ach = algo * nq / (step_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-           "kernel": "k_query<%d,%d,false> (dominant kernel of the pipeline)" % (kw, b), "kernel_ms": kq_ms,
+           "kernel": "k_query_slots<%d,%d> (dominant kernel of the pipeline; the first batch of an index runs k_query<%d,%d,false> behind the "
+                     "exact partition)" % (kw, b, kw, b), "kernel_ms": kq_ms,
            "algorithmic_bytes_per_query": algo, "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
            "per_kernel_ms": {a: round(v, 4) for a, v in stages.items()},
-           "pipeline": {"kernels": "k_bin_hist + scan + k_bin_scatter + k_query + k_gather_ids (what `value` times)", "ms": step_ms,
+           "pipeline": {"kernels": "k_plan_make + k_bin_onepass [stage k_bin_scatter] + k_query_slots [stage k_query] + k_gather_ids + k_plan_learn "
+                                   "(what `value` times; stages k_bin_hist / scan are empty once the bin shares are learnt)", "ms": step_ms,
                         "achieved": pipe_ach, "frac": pipe_ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": pipe_ach / HBM_COPY_GBS}}
     pmc = load_pmc(args.workload)
     if pmc and not args.skew and not args.kmers and not args.queries and args.present == 0.5:
         kern = pmc.get("kernels", {})
         out["pmc"] = {"file": pmc["file"], "source_digest_matches": pmc.get("source_digest") == source_digest()}
-        kq = next((v for name, v in kern.items() if name.startswith("k_query")), None)
+        cands = [(v.get("trace_avg_ns", 0.0) * v.get("trace_calls", 1), name) for name, v in kern.items() if name.startswith("k_query")]
+        kq = kern[max(cands)[1]] if cands else None
         if kq:
+            out["pmc"]["kernel"] = max(cands)[1]
             # FETCH_SIZE counts a coalesced 16-B-per-lane stream at half its bytes on gfx950 (MI355X_MICROARCH.md) and random
             # 64-B lines exactly (tools/gather_ceiling): k_query's traffic is divergent line accesses -> no correction
             out["traffic"] = kq["fetch_bytes"] + kq["write_bytes"]
@@ -348,7 +352,9 @@ def roofline_block(args, k, kw, b, nq, stages, step_ms, st):
                 out["frac_of_gather_ceiling"] = kq["fetch_bytes"] / 64.0 / (kq_ms * 1e-3) / ceil
         tot = 0.0
         for name, v in kern.items():  # the partition passes read wide coalesced streams: FETCH_SIZE counts those at half their bytes
-            tot += v["fetch_bytes"] * (2.0 if name.startswith(("k_bin_hist", "k_bin_scatter")) else 1.0) + v["write_bytes"]
+            if not name.startswith(("k_bin_onepass", "k_query_slots", "k_gather_ids", "k_plan_")):
+                continue  # kernels of the first (exact) batch are not part of a steady-state step
+            tot += v["fetch_bytes"] * (2.0 if name.startswith(("k_bin_hist", "k_bin_scatter", "k_bin_onepass")) else 1.0) + v["write_bytes"]
         out["pipeline"]["traffic"] = tot
     return out
 

@@ -580,8 +580,10 @@ __global__ __launch_bounds__(1 << kBinBitsMax) void k_plan_make(const float* __r
 		sp->ovf_cap = ovf_cap;
 		sp->ovf_blocks = ovf_blocks;
 	}
-	if (t <= nbins)
+	if (t < nbins)
 		cursors[t] = 0;
+	if (t == 0)
+		cursors[nbins] = 0;  // the overflow cursor (with 1024 bins there is no thread number nbins)
 }
 // what the capacities of the next batch are made from: this batch's k-mers per bin
 __global__ void k_plan_learn(const uint32_t* __restrict__ cursors, uint64_t nq, uint32_t nbins, float* __restrict__ frac)
@@ -776,11 +778,14 @@ __global__ __launch_bounds__(kBinThreads) void k_gather_ids(const void* __restri
 	for (int it = 0; it < TILE / kBinThreads; it++) {
 		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
 		if (i < nq) {
-			if constexpr (NARROW) {
-				const uint32_t v = reinterpret_cast<const uint32_t*>(ids_sorted)[inv[i]];
+			const uint32_t j = inv[i];
+			if (j == 0xffffffffu) {  // a k-mer the one-pass partition could not place: cannot happen (its overflow region holds a whole batch)
+				out[i] = -1;
+			} else if constexpr (NARROW) {
+				const uint32_t v = reinterpret_cast<const uint32_t*>(ids_sorted)[j];
 				out[i] = v == 0xffffffffu ? -1 : (int64_t)v;
 			} else {
-				out[i] = reinterpret_cast<const int64_t*>(ids_sorted)[inv[i]];
+				out[i] = reinterpret_cast<const int64_t*>(ids_sorted)[j];
 			}
 		}
 	}
@@ -1055,7 +1060,10 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	// One pass into bin regions sized after the previous batch when there is one to learn from (automatic), always (1) or never (2)
 	const bool onepass_ok = ix.prm.bits_saved <= 8 && nq < (1ull << 31) && 2 * (int)ix.prm.m - 1 >= 3;
 	if (onepass_ok && (ix.tune_partition == 1 || (ix.tune_partition == 0 && ix.plan_bits == onepass_bits(ix)))) {
-		query_ids_onepass(ix, d_kmers, d_minis, nq, d_out, handoff, s);
+		// behind the filter and with 1024 bins the slot kernel is issue-bound (90 % VALU, profiles/r02_pmc_c4.json): now the 4 B per
+		// k-mer of a handed-over minimizer are cheaper than computing it again (C4: 5.71 -> 5.62 ms per step)
+		const bool handoff1 = ix.tune_mini_handoff >= 0 ? ix.tune_mini_handoff != 0 : true;
+		query_ids_onepass(ix, d_kmers, d_minis, nq, d_out, handoff1, s);
 		partition_end(ix, s);
 		return;
 	}

@@ -10,7 +10,7 @@ OUT="$R/gpurun_out/pmc_$LABEL"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="${*:---cpu-seconds 0 --reads 0 --steps 3 --warmup 1}"
-RE="k_query|k_bin_hist|k_bin_scatter|k_gather_ids|k_read_front|k_read_query"
+RE="k_query|k_bin_hist|k_bin_scatter|k_bin_onepass|k_plan_|k_gather_ids|k_read_front|k_read_query"
 i=0
 while read -r counters; do
 	[ -z "$counters" ] && continue
