@@ -262,12 +262,26 @@ int blmx_shard_build_finish(blmx_index* ix, const void* d_meta_in, const void* d
  * L2 / Infinity Cache; results are identical and in the caller's order), 1 = always partition, -1 = never.
  * Environment override when 0: BLIGHT_QUERY_BINNING=1|-1. */
 int blmx_set_query_binning(blmx_index* ix, int policy);
-/* Per-index tuning knobs (experiments, tests; results never depend on them).  The environment variables BLIGHT_BIN_BITS,
- * BLIGHT_MINI_HANDOFF, BLIGHT_QUERY_HEADS, BLIGHT_READS_MODE, BLIGHT_WINDOW_KB, BLIGHT_QUERY_BINNING seed them when the index is
- * created.  Keys: "bin_bits" (partition bins = 2^value, 0 = default), "mini_handoff" (1/0/-1: the partition pass hands the
- * minimizers to the query kernel / it recomputes them / automatic), "query_heads" (0: query kernels read the full group
- * descriptor instead of the compact head), "reads_mode" (sequence / file queries: 0 automatic, 1 front end fused with the query
- * body, 2 front end -> binned pipeline), "window_kb" (KiB of characters per front-end window), "partition" (1: one-pass partition into fixed-capacity bins instead of the exact one -- histogram, scan, scatter), "slot_slack_pct" (its slack), "narrow_ids" (0: host-buffer results cross PCIe as 64-bit words even when every ID fits 32 bits), "query_binning" (as blmx_set_query_binning). */
+/* Per-index tuning knobs (experiments, tests, workload hints; results never depend on them).  The environment variables
+ * BLIGHT_BIN_BITS, BLIGHT_MINI_HANDOFF, BLIGHT_QUERY_HEADS, BLIGHT_READS_MODE, BLIGHT_WINDOW_KB, BLIGHT_QUERY_BINNING,
+ * BLIGHT_FILTER_BITS, BLIGHT_ABSENT_FILTER seed them when the index is created.  Keys:
+ *   "filter_bits"    bits per key of the absent-key filter built at construction (default 8; 0 = build none).  Set before building.
+ *                    The filter is a blocked Bloom filter over the keys plus the few non-keys the reference's scan can find; a k-mer
+ *                    it rejects is answered -1 after one 8-byte load.  It costs filter_bits / 8 bytes of HBM per indexed k-mer.
+ *   "absent_filter"  0: queries ignore the filter (workloads in which nearly every k-mer is indexed run ~5 % faster without it);
+ *                    1: use it, and wait for its background pass if that is still running (it starts when the build returns and
+ *                    takes about half as long as the build; until it is done queries run unfiltered).
+ *   "partition"      large k-mer batches are ordered by minimizer prefix in front of the query kernel: 0 = exact counting sort for
+ *                    the first batch, afterwards one pass into bin regions sized after the previous batch (default); 1 = always
+ *                    one pass; 2 = always the exact sort.  "slot_slack_pct": slack of the regions (0 = default).
+ *   "bin_bits"       partition bins = 2^value (0 = default: 10 with the one-pass partition, 9 with the exact one)
+ *   "mini_handoff"   1/0/-1: the partition pass hands the minimizers to the query kernel / it recomputes them / automatic
+ *   "query_heads"    0: query kernels read the full group descriptor instead of the compact head
+ *   "reads_mode"     sequence / file queries: 0 automatic, 1 front end fused with the query body, 2 front end -> partitioned pipeline
+ *   "window_kb"      KiB of characters per front-end window
+ *   "narrow_ids"     0: host-buffer results cross PCIe as 64-bit words even when every ID fits 32 bits
+ *   "query_binning"  as blmx_set_query_binning
+ *   "filter_junctions"  test hook: 0 skips the filter's second pass (the filter then loses the reference's false positives) */
 int blmx_set_tuning(blmx_index* ix, const char* key, int value);
 
 int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
