@@ -533,7 +533,7 @@ def main():
     ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
     t_build = time.time() - t0
     t0 = time.time()
-    ix.set_tuning("absent_filter", 1)  # the filter's second pass runs in the background after the build: the timed steps start with it armed
+    ix.set_tuning("absent_filter", 1)  # the filter's passes run in the background after the build: the timed steps start with it armed
     t_filter_bg = time.time() - t0
     st = ix.stats()
     if rank == 0:
@@ -722,7 +722,7 @@ def main():
                        "parallelism": "1 GPU" if not multi else ("%s x%d" % (effective_mode, world)),
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
                        "build_kmers_per_sec": st["number_kmer"] / t_build,
-                       "absent_filter": "blocked Bloom filter over the keys, %s bits/key; its second pass ran %.2f s in the background after the build returned" % (
+                       "absent_filter": "blocked Bloom filter over the keys, %s bits/key; its passes ran %.2f s in the background after the build returned" % (
                            os.environ.get("BLIGHT_FILTER_BITS", "8"), t_filter_bg), "largest_mphf": st["largest_mphf"], "largest_bucket": st["largest_bucket"],
                        "mphf_groups_lds_built": st["mphf_groups_lds_built"], "mphf_groups": st["ngroups"], "fallback_keys": st["fallback_keys"]},
             "roofline": roofline_block(args, k, kw, b, nq, stages, kern_ms, st) if not multi else

@@ -1059,8 +1059,7 @@ __global__ void k_fb_table(const uint32_t* __restrict__ perm, uint64_t F, const 
 template <int KW>
 __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
                                                            const uint64_t* __restrict__ key_start, uint64_t nsk, const uint64_t* __restrict__ keys,
-                                                           uint64_t id_base, uint32_t* __restrict__ field_of_rank,
-                                                           unsigned long long* __restrict__ filter)
+                                                           uint64_t id_base, uint32_t* __restrict__ field_of_rank)
 {
 	__shared__ uint64_t s_ks[kSkPerBlock + 1];
 	__shared__ uint64_t s_pos0[kSkPerBlock];
@@ -1087,10 +1086,6 @@ __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, co
 		const GroupDesc* gd = &v.groups[s_mini[j] >> v.gshift];
 		const GroupHead gh = load_group_head(gd);
 		const Kmer<KW> x = load_kmer<KW>(keys, idx);
-		if (filter) {  // every key, also the duplicates and the ones the fallback table ranks
-			const uint64_t fh = filter_hash<KW>(x);
-			atomicOr(&filter[filter_word(gh.prefix - id_base, gh.size0, v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
-		}
 		const uint64_t h = mphf_lookup_levels<KW>(v, gd, gh, x);
 		if (h != kNotFound)  // ranks are distinct: a plain 4-B store, no atomics (k_pack_positions makes the bit fields)
 			field_of_rank[gh.prefix - id_base + h] = (uint32_t)((s_pos0[j] + (idx - s_ks[j])) >> v.b);
@@ -1123,6 +1118,34 @@ __global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ p
 	const GroupDesc* gd = &v.groups[mi >> v.gshift];
 	const uint64_t pos = nt_start[lo] - v.buckets[mi].start + (idx - key_start[lo]);
 	field_of_rank[gd->prefix - id_base + trank[e]] = (uint32_t)(pos >> v.b);
+}
+
+// Absent-key filter, first pass: every key (also the duplicates and the ones the fallback table ranks) sets its five bits in the
+// word its group's region assigns it.  Same walk over the keys as k_fill_positions; the atomics of a workgroup fall into the few
+// hundred KB of one group's region (XCD-major block order: one L2 owns it).
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_filter_keys(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ key_start,
+                                                        uint64_t nsk, const uint64_t* __restrict__ keys, unsigned long long* __restrict__ filter)
+{
+	__shared__ uint64_t s_ks[kSkPerBlock + 1];
+	__shared__ uint32_t s_mini[kSkPerBlock];
+	const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+	const uint64_t j0 = (uint64_t)blk * kSkPerBlock;
+	if (j0 >= nsk)
+		return;
+	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, nsk - j0);
+	for (uint32_t t = threadIdx.x; t <= nj; t += kBlock)
+		s_ks[t] = key_start[j0 + t];
+	for (uint32_t t = threadIdx.x; t < nj; t += kBlock)
+		s_mini[t] = smini[j0 + t];
+	__syncthreads();
+	const uint64_t k1 = s_ks[nj];
+	for (uint64_t idx = s_ks[0] + threadIdx.x; idx < k1; idx += kBlock) {
+		const uint32_t j = sk_of_key(s_ks, nj, idx);
+		const GroupDesc* gd = &v.groups[s_mini[j] >> v.gshift];
+		const uint64_t fh = filter_hash<KW>(load_kmer<KW>(keys, idx));
+		atomicOr(&filter[filter_word(gd->prefix - v.id_base, gd->size[0], v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
+	}
 }
 
 // The absent-key filter must never reject a k-mer the reference answers.  Besides the keys, the reference's 2^b scan
@@ -1990,7 +2013,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		BLMX_HIP(d_field.alloc((N + 1) * 4, true, s));
 		if (nsk)
 			hipLaunchKernelGGL((k_fill_positions<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
-			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>(), d_filter);
+			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>());
 		if (F)
 			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint64_t>(), F,
 			                   ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(),
@@ -2004,25 +2027,34 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		// second pass of the filter, on its own stream: the build does not wait for it, queries use the filter once it is done
 		ix.filter_wait();
 		ix.filter_state.store(2);
-		if (d_filter && nsk > 1 && ix.tune_filter_junctions) {
+		if (d_filter && nsk) {
 			if (!ix.bg_stream)
 				BLMX_HIP(hipStreamCreateWithFlags(&ix.bg_stream, hipStreamNonBlocking));
 			if (!ix.filter_ready)
 				BLMX_HIP(hipEventCreateWithFlags(&ix.filter_ready, hipEventDisableTiming));
-			ix.filter_pending.p = d_ntstart.p;  // the pass reads the super-k-mer starts: the block leaves the build's pool with it
-			ix.filter_pending.bytes = d_ntstart.bytes;
-			ix.filter_pending.owner = nullptr;
-			d_ntstart.p = nullptr;
-			d_ntstart.bytes = 0;
-			const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1), blocks = (cand + kBlock - 1) / kBlock;
-			const unsigned gx = (unsigned)std::min<uint64_t>(blocks, 1u << 22), gy = (unsigned)((blocks + gx - 1) / gx);
+			// what the two passes read leaves the build's pool with them (the helper thread frees it)
+			DevBuf* hand_over[4] = {&d_ntstart, &d_smini, &d_keystart, &d_keys};
+			for (int i = 0; i < 4; i++) {
+				ix.filter_pending[i].release();
+				ix.filter_pending[i].p = hand_over[i]->p;
+				ix.filter_pending[i].bytes = hand_over[i]->bytes;
+				ix.filter_pending[i].owner = nullptr;
+				hand_over[i]->p = nullptr;
+				hand_over[i]->bytes = 0;
+			}
 			ix.filter_state.store(0);
-			hipLaunchKernelGGL((k_filter_junctions<KW>), dim3(gx, gy), dim3(kBlock), 0, ix.bg_stream, v, ix.filter_pending.as<uint64_t>(), nsk, d_filter);
+			hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, ix.bg_stream, v,
+			                   ix.filter_pending[1].as<uint32_t>(), ix.filter_pending[2].as<uint64_t>(), nsk, ix.filter_pending[3].as<uint64_t>(), d_filter);
+			if (nsk > 1 && ix.tune_filter_junctions) {
+				const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1), blocks = (cand + kBlock - 1) / kBlock;
+				const unsigned gx = (unsigned)std::min<uint64_t>(blocks, 1u << 22), gy = (unsigned)((blocks + gx - 1) / gx);
+				hipLaunchKernelGGL((k_filter_junctions<KW>), dim3(gx, gy), dim3(kBlock), 0, ix.bg_stream, v, ix.filter_pending[0].as<uint64_t>(), nsk, d_filter);
+			}
 			BLMX_HIP(hipGetLastError());
 			BLMX_HIP(hipEventRecord(ix.filter_ready, ix.bg_stream));
 			if (mark.on) {
 				BLMX_HIP(hipEventSynchronize(ix.filter_ready));
-				mark("K9c filter junctions (in the background when not traced)");
+				mark("K9c filter: keys + junctions (in the background when not traced)");
 			}
 		}
 	}

@@ -228,11 +228,11 @@ struct Index {
 	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks, filter;
 	uint64_t filter_words = 0;
 	uint32_t filter_bpk = 0;   // bits per key the filter was built with (0 = none)
-	// The filter's second pass (k_filter_junctions: the few non-keys the reference's scan can find) runs on its own stream AFTER the
-	// build has returned, and a helper thread waits for it, gives the build's temporaries back to the driver (hipFree waits for the
+	// The filter's passes (k_filter_keys: every key; k_filter_junctions: the few non-keys the reference's scan can find) run on their
+	// own stream AFTER the build has returned, and a helper thread waits for it, gives the build's temporaries back to the driver (hipFree waits for the
 	// device, so the build itself must not do it) and arms the filter.  0 = pass pending, 2 = filter usable.
 	mutable std::atomic<int> filter_state{2};
-	DevBuf filter_pending;                            // super-k-mer starts the pass reads
+	DevBuf filter_pending[4];                         // what the passes read: super-k-mer starts, their minimizers, key offsets, keys
 	std::vector<BuildPool::Block> deferred_blocks;    // temporaries of the build, freed by the helper thread
 	std::thread filter_thread;
 	hipStream_t bg_stream = nullptr;
@@ -245,7 +245,8 @@ struct Index {
 		filter_thread = std::thread([this] {
 			(void)hipSetDevice(prm.device);
 			(void)hipEventSynchronize(filter_ready);
-			filter_pending.release();
+			for (DevBuf& b : filter_pending)
+				b.release();
 			for (const BuildPool::Block& b : deferred_blocks)
 				(void)hipFree(b.p);
 			deferred_blocks.clear();

@@ -774,20 +774,33 @@ template <int TILE, bool NARROW>
 __global__ __launch_bounds__(kBinThreads) void k_gather_ids(const void* __restrict__ ids_sorted, const uint32_t* __restrict__ inv, uint64_t nq,
                                                             int64_t* __restrict__ out)
 {
+	constexpr int kPer = TILE / kBinThreads;
 	const uint64_t base = (uint64_t)blockIdx.x * TILE;
-	for (int it = 0; it < TILE / kBinThreads; it++) {
+	// all positions first, then all IDs: kPer independent random reads in flight per lane instead of one dependent pair at a time
+	uint32_t j[kPer];
+#pragma unroll
+	for (int it = 0; it < kPer; it++) {
 		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
-		if (i < nq) {
-			const uint32_t j = inv[i];
-			if (j == 0xffffffffu) {  // a k-mer the one-pass partition could not place: cannot happen (its overflow region holds a whole batch)
-				out[i] = -1;
-			} else if constexpr (NARROW) {
-				const uint32_t v = reinterpret_cast<const uint32_t*>(ids_sorted)[j];
-				out[i] = v == 0xffffffffu ? -1 : (int64_t)v;
+		j[it] = i < nq ? inv[i] : 0xffffffffu;
+	}
+	int64_t v[kPer];
+#pragma unroll
+	for (int it = 0; it < kPer; it++) {
+		v[it] = -1;
+		if (j[it] != 0xffffffffu) {  // (an unplaced k-mer cannot happen: the overflow region of the one-pass partition holds a whole batch)
+			if constexpr (NARROW) {
+				const uint32_t w = reinterpret_cast<const uint32_t*>(ids_sorted)[j[it]];
+				v[it] = w == 0xffffffffu ? -1 : (int64_t)w;
 			} else {
-				out[i] = reinterpret_cast<const int64_t*>(ids_sorted)[j];
+				v[it] = reinterpret_cast<const int64_t*>(ids_sorted)[j[it]];
 			}
 		}
+	}
+#pragma unroll
+	for (int it = 0; it < kPer; it++) {
+		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
+		if (i < nq)
+			out[i] = v[it];
 	}
 }
 

@@ -269,8 +269,8 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
  *                    The filter is a blocked Bloom filter over the keys plus the few non-keys the reference's scan can find; a k-mer
  *                    it rejects is answered -1 after one 8-byte load.  It costs filter_bits / 8 bytes of HBM per indexed k-mer.
  *   "absent_filter"  0: queries ignore the filter (workloads in which nearly every k-mer is indexed run ~5 % faster without it);
- *                    1: use it, and wait for its background pass if that is still running (it starts when the build returns and
- *                    takes about half as long as the build; until it is done queries run unfiltered).
+ *                    1: use it, and wait for its background passes if they are still running (they start when the build returns and
+ *                    take about as long as the build; until they are done queries run unfiltered).
  *   "partition"      large k-mer batches are ordered by minimizer prefix in front of the query kernel: 0 = exact counting sort for
  *                    the first batch, afterwards one pass into bin regions sized after the previous batch (default); 1 = always
  *                    one pass; 2 = always the exact sort.  "slot_slack_pct": slack of the regions (0 = default).
