@@ -439,6 +439,15 @@ def test_absent_filter_keeps_every_answer_of_the_reference(B, O, k, kb, m, n, b,
         ld.load_disk(td + "/i.blmx")
         assert np.array_equal(ld.query_kmer_hash(q.reshape(-1)), want)
         assert ld.stats()["device_bytes"] == ix.stats()["device_bytes"]
+    # an image written right after the build (the writer waits for the background passes), an index destroyed right after its build
+    with tempfile.TemporaryDirectory() as td:
+        fresh = _build(B, k, m, n, b, seqs, kmer_bytes=kb)
+        fresh.dump_disk(td + "/j.blmx")
+        fresh.close()
+        ld = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+        ld.load_disk(td + "/j.blmx")
+        assert np.array_equal(ld.query_kmer_hash(q.reshape(-1)), want)
+    _build(B, k, m, n, b, seqs, kmer_bytes=kb).close()
     # without the second pass the filter rejects (some of) the reference's false positives and nothing else
     bare = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
     bare.set_tuning("filter_junctions", 0)
