@@ -519,19 +519,19 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 	}
 }
 
-// ---- one-pass partition into fixed-capacity bins ----------------------------------------------------------------------------
+// ---- one-pass partition into bin regions -----------------------------------------------------------------------------------
 // The exact partition above costs two passes over the batch (histogram, scan, scatter) because every (tile, bin) run needs its
-// final offset before anything is written.  A batch that is only going to be QUERIED does not need a dense order: bin b owns the
-// slots [b * cap, (b + 1) * cap) (cap = mean occupancy + slack, a multiple of the query block), a tile reserves the slot range
-// of each of its runs with ONE global atomic per (tile, bin) on the bin's cursor, and whatever does not fit a bin goes to an
-// overflow region behind the bins (reserved with one more atomic per overflowing run).  One kernel computes the minimizers,
-// sorts the tile in LDS and writes the runs; the query kernel walks the slots and skips the unused tail of every bin.
-// Skewed batches (all k-mers in a few bins) only lose locality for the overflowing part; results never depend on the layout.
-// MEASURED (C4, 1e8 random / indexed 31-mers): the pass itself takes 1.41 ms instead of 0.87 + 0.04 + 0.88 ms, but minimizer-prefix
-// bins are far from equally loaded (99 k .. 328 k k-mers around a mean of 195 k; 54 k .. 399 k for 63-mers), so with one capacity
-// for every bin 4-8 % of the batch overflows and the slot walk of the query kernel is 0.3 ms (k = 63: 0.9 ms) slower than on
-// the dense order: 7.28 vs 7.31 ms per step -- no gain without per-bin capacities learnt from earlier batches.  The exact
-// partition stays the default; this path is selected with blmx_set_tuning("partition", 1).
+// final offset before anything is written.  A batch that is only going to be QUERIED does not need a dense order: bin b owns a
+// region of slots (a multiple of the query block), a tile reserves the slot range of each of its runs with ONE global atomic per
+// (tile, bin) on the bin's cursor, and whatever does not fit a region goes to an overflow region behind them (one more atomic per
+// overflowing run).  One kernel computes the minimizers, sorts the tile in LDS and writes the runs; the query kernel walks the
+// slots and skips the unused tail of every region.  Results never depend on the layout.
+// Minimizer-prefix bins are far from equally loaded (99 k .. 328 k k-mers around a mean of 195 k at C4; 54 k .. 399 k for
+// 63-mers): with ONE capacity for every bin 4-8 % of a batch overflows and nothing is gained (7.28 vs 7.31 ms per step).  The
+// regions are therefore sized after the shares the bins had of the PREVIOUS batch (k_plan_learn* -> k_plan_make, all on the
+// device); the first batch of an index goes through the exact partition and leaves its shares behind.  A batch distributed unlike
+// its predecessor (tests: a few k-mers repeated a thousand times after a uniform batch) only loses locality for what overflows.
+// C4: 1.63 ms for this pass instead of 0.92 + 0.04 + 0.86, and 1024 bins become affordable.
 struct SlotPlan {            // lives in HBM (written by k_plan_make, read by the slot kernels): no host round trip per batch
 	uint32_t nbins;
 	uint32_t main_slots;     // slots of all bin regions, rounded up to a multiple of 2048 (8 XCDs x 256-slot blocks)

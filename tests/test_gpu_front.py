@@ -320,7 +320,8 @@ def test_tuning_knobs_do_not_change_results(B, O, k, kb, b):
 
 @pytest.mark.parametrize("k,kb,b", [(31, 8, 6), (63, 16, 8)])
 def test_partition_paths_and_skewed_batches(B, O, k, kb, b):
-    """The batch partition in front of the query kernel: one pass into fixed-capacity bins (default) and the exact partition
+    """The batch partition in front of the query kernel: one pass into bin regions sized after the previous batch (default after the
+    first batch; 1 = always) and the exact partition
     give the direct kernel's answers -- also when nearly the whole batch falls into a few bins and spills into the overflow
     region (a few k-mers repeated a thousand times), and for batches that are not a multiple of anything."""
     ix, orc, seqs, rng = _index(B, O, k, 9, 7, b, kb, 1300 + k, nseq=2500)
@@ -337,10 +338,17 @@ def test_partition_paths_and_skewed_batches(B, O, k, kb, b):
         ix.set_query_binning(-1)
         assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), name
         ix.set_query_binning(1)
-        for part in (0, 1):  # exact partition / one pass into fixed-capacity bins
+        for part in (0, 1, 2):  # automatic (exact, then one pass with learnt regions) / always one pass / always exact
             for bits in (0, 4, 10):
                 ix.set_tuning("partition", part)
                 ix.set_tuning("bin_bits", bits)
                 assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), (name, part, bits)
     ix.set_tuning("partition", 0)
     ix.set_tuning("bin_bits", 0)
+    # automatic mode over a sequence of batches: regions learnt from a batch of the same distribution, then from a very different one
+    wants = {name: orc.query_kmers(q.reshape(-1) if kb == 8 else q) for name, q in (("uniform", uniform), ("skewed", skewed), ("one k-mer", one))}
+    batches = {"uniform": uniform, "skewed": skewed, "one k-mer": one}
+    for name in ("skewed", "skewed", "uniform", "uniform", "one k-mer", "uniform", "skewed"):
+        assert np.array_equal(ix.query_kmer_hash(batches[name].reshape(-1)), wants[name]), name
+    half = uniform[: len(uniform) // 3]  # another batch size: the shares scale
+    assert np.array_equal(ix.query_kmer_hash(half.reshape(-1)), wants["uniform"][: len(half)])
