@@ -28,6 +28,7 @@ def test_virtual_shards(world, k, m, n, b):
         ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
         ix.set_shard(r, world)
         ix.construct_index_from_sequences(seqs)
+        ix.set_tuning("absent_filter", 1)  # wait for the filter's background passes: the shard's filter regions follow LOCAL IDs (id_base > 0)
         shards.append(ix)
     bounds = shards[0].shard_bounds()
     assert np.array_equal(bounds, shard_bounds_from_counts(full.export("g_nkeys"), world))
@@ -364,6 +365,11 @@ def test_sharded_build_from_slices(world, k, m, n, b):
             assert np.array_equal(ixs[r].export(name), ref[r].export(name)), (r, name)
         s1, s2 = ixs[r].stats(), ref[r].stats()
         assert not [f for f in s1 if f not in ("build_seconds", "number_query") and s1[f] != s2[f]], [(r, f, s1[f], s2[f]) for f in s1 if s1[f] != s2[f]]
+        for x in (ixs[r], ref[r]):
+            x.set_tuning("absent_filter", 1)  # filter armed: its regions follow the shard's LOCAL IDs
+        some = seqs[::7] + [_rand_seq(rng, 3 * k) for _ in range(50)]
+        got = ixs[r].query_sequences_hash(some)
+        assert np.array_equal(got, ref[r].query_sequences_hash(some)) and (got >= 0).any()
     # phase errors: finish without plan, plan twice
     y = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
     y.set_shard(0, world)
