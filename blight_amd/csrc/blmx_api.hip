@@ -172,6 +172,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.tune_bin_bits = env_int("BLIGHT_BIN_BITS", 0);
 	h->ix.tune_filter_bits = env_int("BLIGHT_FILTER_BITS", 8);
 	h->ix.tune_absent_filter = env_int("BLIGHT_ABSENT_FILTER", 1);
+	h->ix.tune_filter_gate = env_int("BLIGHT_FILTER_GATE", 1);
 	h->ix.tune_mini_handoff = env_int("BLIGHT_MINI_HANDOFF", -1);
 	h->ix.tune_query_heads = env_int("BLIGHT_QUERY_HEADS", 1);
 	h->ix.tune_reads_mode = env_int("BLIGHT_READS_MODE", 0);
@@ -717,6 +718,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_bin_bits = value;
 	else if (k == "filter_bits")  // bits per key of the absent-key filter built at construction (0 = none); set before building
 		ix.tune_filter_bits = value < 0 ? 0 : (value > 32 ? 32 : value);
+	else if (k == "filter_gate")  // 0: large batches never switch the filter off for their successors
+		ix.tune_filter_gate = value != 0;
 	else if (k == "filter_junctions")  // test hook, before building
 		ix.tune_filter_junctions = value != 0;
 	else if (k == "absent_filter") {  // 0 = queries ignore the filter the index has; 1 = use it (waits for its background pass)

@@ -2003,6 +2003,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		ix.filter_words = (uint64_t)(((unsigned __int128)N * bpk) >> 6) + 64;
 		BLMX_HIP(ix.filter.alloc(ix.filter_words * 8, true, s));
 		ix.filter_bpk = bpk;
+		init_filter_gate(ix, s);
 	}
 	{
 		DeviceIndexView v = ix.view();
@@ -2297,6 +2298,14 @@ void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in
 
 namespace {
 }  // namespace
+
+void init_filter_gate(Index& ix, hipStream_t s)
+{
+	const uint32_t one = 1;  // consult the filter until a large batch says otherwise
+	BLMX_HIP(ix.filter_gate.alloc((1 + kGateStripes) * 4, true, s));
+	BLMX_HIP(hipMemcpyAsync(ix.filter_gate.p, &one, 4, hipMemcpyHostToDevice, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+}
 
 void make_query_heads(Index& ix)
 {

@@ -66,7 +66,11 @@ struct DeviceIndexView {
 	const uint64_t* filter;
 	uint64_t id_base;     // ID of the first key this index holds (0 unless sharded): group regions of the filter follow local IDs
 	uint32_t filter_bpk;  // filter bits per key
+	// word 0: 1 = consult the filter, 0 = skip it (the last large batch had almost no absent k-mers: the filter would only cost its
+	// load); words 1..64: absent answers of the running batch, striped (k_gate_update folds them into word 0).  nullptr = always use.
+	uint32_t* filter_gate;
 };
+constexpr uint32_t kGateStripes = 64;
 
 // ---- tiny RAII device buffer ---------------------------------------------------------------------------------------
 // Cache of device blocks for the temporaries of ONE build.  On this driver hipMalloc of recycled VRAM costs 30-50 ms per GB
@@ -225,7 +229,7 @@ struct Index {
 	std::mutex hf_mu;
 
 	// finished index (HBM)
-	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks, filter;
+	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks, filter, filter_gate;
 	uint64_t filter_words = 0;
 	uint32_t filter_bpk = 0;   // bits per key the filter was built with (0 = none)
 	// The filter's passes (k_filter_keys: every key; k_filter_junctions: the few non-keys the reference's scan can find) run on their
@@ -292,13 +296,14 @@ struct Index {
 	int tune_slot_slack_pct = 0; // one-pass partition: slots per bin = mean occupancy + this many percent (0 = default 12)
 	int tune_narrow_ids = 1;     // host-buffer results cross PCIe as 32-bit words when every ID fits (0 = always 64-bit)
 	int tune_absent_filter = 1;  // queries consult the absent-key filter (when the index was built with one)
+	int tune_filter_gate = 1;       // large batches with almost no absent k-mers switch the filter off for the next ones (0 = never)
 	int tune_filter_junctions = 1;  // test hook: 0 = skip the filter's second pass (the filter then loses the reference's false positives)
 	int tune_filter_bits = 8;    // bits per key of the filter built at construction (0 = build none; BLIGHT_FILTER_BITS)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
 
 	Index()
 	{
-		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks, &filter})
+		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks, &filter, &filter_gate})
 			b->persistent = true;
 	}
 
@@ -338,6 +343,7 @@ struct Index {
 		v.total_nt = st.total_nt;
 		v.filter = (filter_bpk && tune_absent_filter && filter_usable()) ? filter.as<uint64_t>() : nullptr;
 		v.filter_bpk = filter_bpk;
+		v.filter_gate = (v.filter && tune_filter_gate) ? filter_gate.as<uint32_t>() : nullptr;
 		v.id_base = h_groups.empty() ? 0 : h_groups[0].prefix;
 		return v;
 	}
@@ -345,6 +351,7 @@ struct Index {
 
 // build (blmx_build.hip)
 void make_query_heads(Index& ix);  // from ix.h_groups, after the group table is final (build and load)
+void init_filter_gate(Index& ix, hipStream_t s);  // with the filter (build and load)
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
 // sharded build from slices, phase by phase (blmx_build.hip); hist_out holds ngroups + 1 words: key histogram, local super-k-mers
 void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out);

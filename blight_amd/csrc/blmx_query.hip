@@ -21,6 +21,30 @@
 
 namespace blmx {
 
+// Absent answers of a large batch -> the filter gate of the NEXT batch.  Device-scope atomics from eight XCDs on a handful of
+// addresses are served at memory, one after the other, about a microsecond each (a counter per wave made the kernel 8x slower, one
+// workgroup in 64 still cost 0.7 ms): one workgroup in 1024 (picked by a hash of its number, so that every XCD and bin
+// contributes) counts, one atomic per wave, on striped counters -- 10^5 sampled k-mers per batch of 10^8.
+constexpr uint32_t kGateSampleShift = 10;
+__device__ __forceinline__ void count_absent(const DeviceIndexView& v, bool absent)
+{
+	if (!v.filter_gate || ((blockIdx.x * 0x9E3779B1u) >> (32 - kGateSampleShift)) != 0)
+		return;
+	const uint64_t bal = __ballot(absent);
+	if (bal && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u)
+		atomicAdd(&v.filter_gate[1 + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kGateStripes - 1))], (uint32_t)__popcll(bal));
+}
+// gate of the next batch: consult the filter iff at least 1 in 12 answers of this batch (of its sampled 1024th) was "absent"
+__global__ void k_gate_update(uint32_t* __restrict__ gate, uint64_t nq)
+{
+	uint32_t c = gate[1 + threadIdx.x];
+	gate[1 + threadIdx.x] = 0;
+	for (int o = 32; o > 0; o >>= 1)
+		c += __shfl_down(c, o);
+	if (threadIdx.x == 0)
+		gate[0] = ((uint64_t)c << kGateSampleShift) * 12 >= nq ? 1u : 0u;
+}
+
 template <int KW, int LOGP, bool WANT_POS>
 __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t* __restrict__ kmers,
                                                const uint32_t* __restrict__ minis, uint64_t nq, void* __restrict__ out,
@@ -29,8 +53,10 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 	// kQueryXcdMajor (batch partitioned by minimizer): workgroup b runs on XCD b % 8, each XCD has its own L2.  Give XCD x
 	// the x-th contiguous eighth of the batch, so that one bin's slice of the index is cached by ONE L2 instead of being
 	// fetched into all eight (the grid is a multiple of 8).
+	const DeviceIndexView vq = gated_view(v);
 	uint32_t blk = blockIdx.x;
-	if (mode & kQueryXcdMajor)
+	const bool partitioned = (mode & kQueryXcdMajor) != 0;
+	if (partitioned)
 		blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
 	mode &= 0xff;
 	const uint64_t i = (uint64_t)blk * blockDim.x + threadIdx.x;
@@ -49,7 +75,9 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 		mini = kmer_minimizer<KW>(x, xr, v.k, v.m);
 	}
 	if (in_range)
-		query_one<KW, LOGP, WANT_POS>(v, x, xr, mini, id, posj);
+		query_one<KW, LOGP, WANT_POS>(vq, x, xr, mini, id, posj);
+	if (partitioned)  // large batches only: their pipeline folds the counters into the gate (k_gate_update)
+		count_absent(v, id < 0);
 	const uint64_t o = i;
 	if (mode == kQueryIds)
 		reinterpret_cast<int64_t*>(out)[o] = id;
@@ -723,6 +751,7 @@ __device__ __forceinline__ void query_slot(const DeviceIndexView& v, const uint6
 	int64_t id;
 	int32_t posj;
 	query_one<KW, LOGP, false>(v, x, xr, mini, id, posj);
+	count_absent(v, id < 0);
 	if (narrow)
 		reinterpret_cast<uint32_t*>(ids)[slot] = (uint32_t)id;
 	else
@@ -737,6 +766,7 @@ __global__ __launch_bounds__(256) void k_query_slots(DeviceIndexView v, const Sl
 	const uint32_t mb = sp->main_slots >> 8;  // a multiple of 8
 	if (blockIdx.x >= mb)
 		return;
+	const DeviceIndexView vq = gated_view(v);
 	const uint32_t blk = (blockIdx.x & 7u) * (mb >> 3) + (blockIdx.x >> 3);
 	const uint32_t first = blk << 8;
 	uint32_t lo = 0, hi = sp->nbins;  // the bin whose region holds this block: base[lo] <= first < base[lo + 1] (uniform: scalar loads)
@@ -751,7 +781,7 @@ __global__ __launch_bounds__(256) void k_query_slots(DeviceIndexView v, const Sl
 	const uint32_t used = min(cursors[lo], cap);
 	const uint32_t slot = first + threadIdx.x;
 	if (slot < rb + used)
-		query_slot<KW, LOGP>(v, slots, slot_minis, ids, narrow != 0, slot);
+		query_slot<KW, LOGP>(vq, slots, slot_minis, ids, narrow != 0, slot);
 }
 
 // The overflow region (usually empty) in its own launch: a fixed number of blocks loop over it.  (Looping blocks inside
@@ -762,9 +792,10 @@ __global__ __launch_bounds__(256) void k_query_slots_overflow(DeviceIndexView v,
                                                               void* __restrict__ ids, int narrow)
 {
 	const uint64_t end = sp->ovf_base() + min(cursors[sp->nbins], sp->ovf_cap);
+	const DeviceIndexView vq = gated_view(v);
 #pragma nounroll
 	for (uint64_t slot = sp->ovf_base() + (uint64_t)blockIdx.x * 256 + threadIdx.x; slot < end; slot += (uint64_t)gridDim.x * 256)
-		query_slot<KW, LOGP>(v, slots, slot_minis, ids, narrow != 0, slot);
+		query_slot<KW, LOGP>(vq, slots, slot_minis, ids, narrow != 0, slot);
 }
 
 // out[i] = ids_sorted[inv[i]].  One block per partition TILE: the (tile, bin) runs written by k_bin_scatter are consumed by
@@ -939,6 +970,13 @@ bool query_batch_worth_binning(const Index& ix, uint64_t nq)
 	return nq >= (1ull << 20) && ix.st.device_bytes >= (64ull << 20) && mbits >= 4;
 }
 
+static void update_filter_gate(const Index& ix, uint64_t nq, hipStream_t s)
+{
+	const DeviceIndexView v = ix.view();
+	if (v.filter_gate && nq)
+		hipLaunchKernelGGL(k_gate_update, dim3(1), dim3(kGateStripes), 0, s, v.filter_gate, nq);
+}
+
 template <int KW>
 static void launch_query_slots_kw(const Index& ix, const SlotPlan* d_plan, uint32_t max_main_blocks, uint32_t ovf_blocks, const uint32_t* d_cursors,
                                   const void* d_slots, const uint32_t* d_slot_minis, void* d_ids, bool narrow, hipStream_t s)
@@ -1033,6 +1071,7 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	ix.prof_mark(6, s);
 	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>());
 	ix.plan_bits = tbits;
+	update_filter_gate(ix, nq, s);
 	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 2) {  // bin occupancy of this batch (synchronises)
 		std::vector<uint32_t> h(nbins + 1);
 		SlotPlan hp;
@@ -1096,6 +1135,7 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	ix.prof_mark(5, s);
 	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, pl.tile, narrow, s);
 	ix.prof_mark(6, s);
+	update_filter_gate(ix, nq, s);
 	if (onepass_ok && ix.tune_partition == 0 && pl.bm.nbound == 0 && (int)pl.nbins == (1 << onepass_bits(ix))) {  // the next batch can skip the histogram
 		ensure_buf(ix.b_frac, sizeof(float) << kBinBitsMax, s);
 		hipLaunchKernelGGL(k_plan_learn_offs, dim3((pl.nbins + 255) / 256), dim3(256), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, nq, pl.nbins, ix.b_frac.as<float>());
@@ -1150,6 +1190,7 @@ void launch_query_partitioned(Index& ix, const void* d_sorted_kmers, uint64_t nq
 	if (nq == 0)
 		return;
 	launch_query(ix, d_sorted_kmers, nullptr, nq, d_ids, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
+	update_filter_gate(ix, nq, s);
 }
 
 void launch_gather_ids(Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s)

@@ -685,6 +685,7 @@ void load_index(Index& ix, const char* path)
 		ix.filter_words = ((h.st.local_number_kmer * h.filter_bpk) >> 6) + 64;
 		get_device(fh.f, ix.filter, ix.filter_words * 8, pin, s);
 		ix.filter_bpk = h.filter_bpk;
+		init_filter_gate(ix, s);
 	}
 	ix.filter_state.store(2);
 	char end[8];
@@ -700,7 +701,7 @@ void load_index(Index& ix, const char* path)
 	// in BLMX_EIO here instead of a GPU memory fault later.
 	{
 		auto bad = [&](const char* what) {
-			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks, &ix.filter})
+			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks, &ix.filter, &ix.filter_gate})
 				b->release();
 			ix.filter_bpk = 0;
 			ix.h_groups.clear();

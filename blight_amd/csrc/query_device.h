@@ -212,6 +212,15 @@ __device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uin
 // query_get_hash / query_get_pos_unitig for ONE canonical k-mer whose minimizer is known and inside [0, nbuckets)
 // (reference blight.cpp:716-742 / 686-712).  id = h + group prefix (:736) or -1; posj = bucket-relative position of the
 // first match (:706) or -1.
+// The filter gate (word 0 of filter_gate: 0 = the last large batch had almost no absent k-mers) is read ONCE at the start of a
+// kernel and folded into the view, away from the dependent chain of the query body.
+__device__ __forceinline__ DeviceIndexView gated_view(DeviceIndexView v)
+{
+	if (v.filter && v.filter_gate && *reinterpret_cast<const volatile uint32_t*>(v.filter_gate) == 0)
+		v.filter = nullptr;
+	return v;
+}
+
 template <int KW, int LOGP, bool WANT_POS>
 __device__ __forceinline__ void query_one(const DeviceIndexView& v, Kmer<KW> x, Kmer<KW> xr, uint32_t mini, int64_t& id, int32_t& posj)
 {

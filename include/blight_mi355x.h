@@ -271,6 +271,8 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
  *   "absent_filter"  0: queries ignore the filter (workloads in which nearly every k-mer is indexed run ~5 % faster without it);
  *                    1: use it, and wait for its background passes if they are still running (they start when the build returns and
  *                    take about as long as the build; until they are done queries run unfiltered).
+ *   "filter_gate"    1 (default): a large batch in which fewer than 1 in 12 answers were "absent" switches the filter off for the
+ *                    batches after it (and one with more switches it on again); 0: the filter is always consulted.
  *   "partition"      large k-mer batches are ordered by minimizer prefix in front of the query kernel: 0 = exact counting sort for
  *                    the first batch, afterwards one pass into bin regions sized after the previous batch (default); 1 = always
  *                    one pass; 2 = always the exact sort.  "slot_slack_pct": slack of the regions (0 = default).
