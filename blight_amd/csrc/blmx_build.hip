@@ -2302,7 +2302,7 @@ namespace {
 void init_filter_gate(Index& ix, hipStream_t s)
 {
 	const uint32_t one = 1;  // consult the filter until a large batch says otherwise
-	BLMX_HIP(ix.filter_gate.alloc((1 + kGateStripes) * 4, true, s));
+	BLMX_HIP(ix.filter_gate.alloc(64, true, s));
 	BLMX_HIP(hipMemcpyAsync(ix.filter_gate.p, &one, 4, hipMemcpyHostToDevice, s));
 	BLMX_HIP(hipStreamSynchronize(s));
 }

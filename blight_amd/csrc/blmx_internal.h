@@ -66,11 +66,10 @@ struct DeviceIndexView {
 	const uint64_t* filter;
 	uint64_t id_base;     // ID of the first key this index holds (0 unless sharded): group regions of the filter follow local IDs
 	uint32_t filter_bpk;  // filter bits per key
-	// word 0: 1 = consult the filter, 0 = skip it (the last large batch had almost no absent k-mers: the filter would only cost its
-	// load); words 1..64: absent answers of the running batch, striped (k_gate_update folds them into word 0).  nullptr = always use.
+	// one word: 1 = consult the filter, 0 = skip it (the last large batch had almost no absent k-mers: the filter would only cost its
+	// load; k_gate_sample decides after every large batch).  nullptr = always use.
 	uint32_t* filter_gate;
 };
-constexpr uint32_t kGateStripes = 64;
 
 // ---- tiny RAII device buffer ---------------------------------------------------------------------------------------
 // Cache of device blocks for the temporaries of ONE build.  On this driver hipMalloc of recycled VRAM costs 30-50 ms per GB

@@ -21,28 +21,35 @@
 
 namespace blmx {
 
-// Absent answers of a large batch -> the filter gate of the NEXT batch.  Device-scope atomics from eight XCDs on a handful of
-// addresses are served at memory, one after the other, about a microsecond each (a counter per wave made the kernel 8x slower, one
-// workgroup in 64 still cost 0.7 ms): one workgroup in 1024 (picked by a hash of its number, so that every XCD and bin
-// contributes) counts, one atomic per wave, on striped counters -- 10^5 sampled k-mers per batch of 10^8.
-constexpr uint32_t kGateSampleShift = 10;
-__device__ __forceinline__ void count_absent(const DeviceIndexView& v, bool absent)
+// The filter gate of the NEXT batch from a sample of THIS batch's answers (16384 of them, evenly spaced in the caller's order, read
+// back after the gather): consult the filter iff at least 1 in 12 was "absent".  Counting inside the query kernel was tried first:
+// device-scope atomics from eight XCDs on a few addresses are served at memory at about one per microsecond -- a counter per wave
+// made the kernel 8x slower, one workgroup in 1024 still cost 2 %.  One workgroup, after the pipeline, costs nothing there.
+constexpr uint32_t kGateSamples = 1u << 14;  // 16 workgroups, one sample per lane (one workgroup reading 2^17 took 0.3 ms)
+__global__ __launch_bounds__(1024) void k_gate_sample(const int64_t* __restrict__ ids, uint64_t nq, uint32_t* __restrict__ gate)
 {
-	if (!v.filter_gate || ((blockIdx.x * 0x9E3779B1u) >> (32 - kGateSampleShift)) != 0)
-		return;
-	const uint64_t bal = __ballot(absent);
-	if (bal && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(true)) - 1u)
-		atomicAdd(&v.filter_gate[1 + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kGateStripes - 1))], (uint32_t)__popcll(bal));
-}
-// gate of the next batch: consult the filter iff at least 1 in 12 answers of this batch (of its sampled 1024th) was "absent"
-__global__ void k_gate_update(uint32_t* __restrict__ gate, uint64_t nq)
-{
-	uint32_t c = gate[1 + threadIdx.x];
-	gate[1 + threadIdx.x] = 0;
+	__shared__ uint32_t s_cnt[16];
+	const uint64_t stride = nq < kGateSamples ? 1 : nq / kGateSamples, n = nq < kGateSamples ? nq : kGateSamples;
+	const uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+	uint32_t c = (t < n && ids[t * stride] < 0) ? 1u : 0u;
 	for (int o = 32; o > 0; o >>= 1)
 		c += __shfl_down(c, o);
-	if (threadIdx.x == 0)
-		gate[0] = ((uint64_t)c << kGateSampleShift) * 12 >= nq ? 1u : 0u;
+	if ((threadIdx.x & 63u) == 0)
+		s_cnt[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (int w = 0; w < 16; w++)
+			tot += s_cnt[w];
+		if (tot)
+			atomicAdd(&gate[1], tot);
+	}
+}
+__global__ void k_gate_set(uint32_t* __restrict__ gate, uint64_t nq)
+{
+	const uint64_t n = nq < kGateSamples ? nq : kGateSamples;
+	gate[0] = (uint64_t)gate[1] * 12 >= n ? 1u : 0u;
+	gate[1] = 0;
 }
 
 template <int KW, int LOGP, bool WANT_POS>
@@ -76,8 +83,6 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 	}
 	if (in_range)
 		query_one<KW, LOGP, WANT_POS>(vq, x, xr, mini, id, posj);
-	if (partitioned)  // large batches only: their pipeline folds the counters into the gate (k_gate_update)
-		count_absent(v, id < 0);
 	const uint64_t o = i;
 	if (mode == kQueryIds)
 		reinterpret_cast<int64_t*>(out)[o] = id;
@@ -751,7 +756,6 @@ __device__ __forceinline__ void query_slot(const DeviceIndexView& v, const uint6
 	int64_t id;
 	int32_t posj;
 	query_one<KW, LOGP, false>(v, x, xr, mini, id, posj);
-	count_absent(v, id < 0);
 	if (narrow)
 		reinterpret_cast<uint32_t*>(ids)[slot] = (uint32_t)id;
 	else
@@ -970,11 +974,13 @@ bool query_batch_worth_binning(const Index& ix, uint64_t nq)
 	return nq >= (1ull << 20) && ix.st.device_bytes >= (64ull << 20) && mbits >= 4;
 }
 
-static void update_filter_gate(const Index& ix, uint64_t nq, hipStream_t s)
+static void update_filter_gate(const Index& ix, const int64_t* d_ids, uint64_t nq, hipStream_t s)
 {
 	const DeviceIndexView v = ix.view();
-	if (v.filter_gate && nq)
-		hipLaunchKernelGGL(k_gate_update, dim3(1), dim3(kGateStripes), 0, s, v.filter_gate, nq);
+	if (v.filter_gate && nq) {
+		hipLaunchKernelGGL(k_gate_sample, dim3(kGateSamples / 1024), dim3(1024), 0, s, d_ids, nq, v.filter_gate);
+		hipLaunchKernelGGL(k_gate_set, dim3(1), dim3(1), 0, s, v.filter_gate, nq);
+	}
 }
 
 template <int KW>
@@ -1071,7 +1077,7 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	ix.prof_mark(6, s);
 	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>());
 	ix.plan_bits = tbits;
-	update_filter_gate(ix, nq, s);
+	update_filter_gate(ix, d_out, nq, s);
 	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 2) {  // bin occupancy of this batch (synchronises)
 		std::vector<uint32_t> h(nbins + 1);
 		SlotPlan hp;
@@ -1135,7 +1141,7 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	ix.prof_mark(5, s);
 	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, pl.tile, narrow, s);
 	ix.prof_mark(6, s);
-	update_filter_gate(ix, nq, s);
+	update_filter_gate(ix, d_out, nq, s);
 	if (onepass_ok && ix.tune_partition == 0 && pl.bm.nbound == 0 && (int)pl.nbins == (1 << onepass_bits(ix))) {  // the next batch can skip the histogram
 		ensure_buf(ix.b_frac, sizeof(float) << kBinBitsMax, s);
 		hipLaunchKernelGGL(k_plan_learn_offs, dim3((pl.nbins + 255) / 256), dim3(256), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, nq, pl.nbins, ix.b_frac.as<float>());
@@ -1190,7 +1196,7 @@ void launch_query_partitioned(Index& ix, const void* d_sorted_kmers, uint64_t nq
 	if (nq == 0)
 		return;
 	launch_query(ix, d_sorted_kmers, nullptr, nq, d_ids, (QueryMode)(kQueryIds | kQueryXcdMajor), s);
-	update_filter_gate(ix, nq, s);
+	update_filter_gate(ix, d_ids, nq, s);  // (an owner's segments of a sharded batch: 64-bit IDs, dense)
 }
 
 void launch_gather_ids(Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s)
