@@ -456,16 +456,19 @@ def host_kmer_legs(torch, ix, q, ids, kw):
     nq = min(q.shape[0], 100_000_000)
     h_q = q[:nq].cpu().numpy().view(np.uint64).reshape(-1)
     want = ids[:nq].cpu().numpy()
-    out = {"queries": nq}
-    for name, call, dtype in (("blmx_query_kmers", ix.query_kmer_hash, np.int64), ("blmx_query_membership", ix.query_kmer_bool, None)):
-        best = None
-        for _ in range(3):
+    out = {"queries": nq, "note": "caller-owned host buffers as in the C ABI; best of 4 calls into the same result buffer (the first call also "
+                                  "pays for the fresh pages of that buffer: first_call_seconds)"}
+    for name, call, dtype in (("blmx_query_kmers", ix.query_kmer_hash, np.int64), ("blmx_query_membership", ix.query_kmer_bool, np.uint8)):
+        res = np.empty(nq, dtype=dtype)
+        best = first = None
+        for _ in range(4):
             t = time.perf_counter()
-            got = call(h_q)
+            got = call(h_q, out=res)
             dt = time.perf_counter() - t
+            first = dt if first is None else first
             best = dt if best is None else min(best, dt)
-        same = bool(np.array_equal(got, want)) if dtype is not None else bool(np.array_equal(got, want >= 0))
-        out[name] = {"queries_per_s": nq / best, "seconds": best, "equal_to_device_path": same}
+        same = bool(np.array_equal(got, want)) if dtype is np.int64 else bool(np.array_equal(got, want >= 0))
+        out[name] = {"queries_per_s": nq / best, "seconds": best, "first_call_seconds": first, "equal_to_device_path": same}
     return out
 
 

@@ -254,21 +254,30 @@ class kmer_Set_Light:
     positions_total_size = property(lambda self: self.stats()["positions_total_size"])
 
     # -- queries
-    def query_kmer_hash(self, canon):
-        """blight.cpp:545-550; scalar int -> int, batch -> int64 array"""
+    @staticmethod
+    def _out_array(out, nq, dtype):
+        """the caller's result buffer (like the C ABI: a caller that reuses it does not pay for fresh pages on every call) or a new one"""
+        if out is None:
+            return np.empty(nq, dtype=dtype)
+        if not isinstance(out, np.ndarray) or out.dtype != dtype or out.size != nq or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous %s array of %d elements" % (np.dtype(dtype).name, nq))
+        return out
+
+    def query_kmer_hash(self, canon, out=None):
+        """blight.cpp:545-550; scalar int -> int, batch -> int64 array (written into `out` when given)"""
         scalar = not hasattr(canon, "__iter__")
         a, nq = _kmers_array(canon, self.kmer_bytes)
-        out = np.empty(nq, dtype=np.int64)
+        out = self._out_array(out, nq, np.int64)
         self._check(self._lib.blmx_query_kmers(self._h, a.ctypes.data, nq, out.ctypes.data_as(_i64p)))
         return int(out[0]) if scalar else out
 
-    def query_kmer_bool(self, canon):
-        """blight.cpp:537-541"""
+    def query_kmer_bool(self, canon, out=None):
+        """blight.cpp:537-541; batch -> bool array (one byte per k-mer; written into the uint8 array `out` when given)"""
         scalar = not hasattr(canon, "__iter__")
         a, nq = _kmers_array(canon, self.kmer_bytes)
-        out = np.empty(nq, dtype=np.uint8)
+        out = self._out_array(out, nq, np.uint8)
         self._check(self._lib.blmx_query_membership(self._h, a.ctypes.data, nq, out.ctypes.data_as(C.POINTER(C.c_uint8))))
-        return bool(out[0]) if scalar else out.astype(bool)
+        return bool(out[0]) if scalar else out.view(np.bool_)
 
     def query_get_hash(self, canon, minimizer):
         """blight.cpp:716-742"""
