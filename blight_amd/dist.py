@@ -219,3 +219,36 @@ class SlicedBuilder:
         self._a2a(meta_in, meta, recv_sk, send_sk)
         self._a2a(words_in, packed, recv_words, send_words)
         self.ops.finish(meta_in, words_in, recv_sk, recv_words)
+
+
+# ---- the native exchange (RCCL inside libblight_mi355x.so) behind the same two method names --------------------------------------
+class NativeSharded:
+    """Thin caller of the library's own multi-GPU path (blmx_comm_*, include/blight_mi355x.h): rank 0's communicator id travels through
+    the launcher's process group, everything else -- construction from this rank's slice, the query exchange -- runs inside the
+    library on RCCL.  ShardedQuerier / SlicedBuilder above are the same choreographies over torch.distributed, kept for the gloo
+    CPU tests and as a fallback where the library cannot open RCCL itself."""
+
+    def __init__(self, index, device, group=None):
+        import blight_amd
+        self.ix, self.dev, self.group = index, device, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = torch.zeros(blight_amd.COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        if self.rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(blight_amd.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0, group=group)
+        self.comm = blight_amd.Comm(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world, device=device.index or 0)
+
+    def build(self, seqs):
+        """collective: this rank's consecutive slice of the sequences"""
+        self.ix.set_shard(self.rank, self.world)
+        self.comm.build_sharded_from_sequences(self.ix, seqs)
+
+    def query(self, kmers):
+        """collective: canonical k-mers (int64 tensor on the device, one row per k-mer) -> IDs in the caller's order"""
+        n = kmers.shape[0]
+        out = torch.empty(n, dtype=torch.int64, device=self.dev)
+        self.comm.query_kmers_sharded_device(self.ix, kmers.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def close(self):
+        self.comm.close()

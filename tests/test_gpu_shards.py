@@ -171,6 +171,13 @@ got = torch.empty_like(want)
 ix2.query_kmers_device(q.data_ptr(), q.shape[0], got.data_ptr(), s)
 torch.cuda.synchronize()
 assert torch.equal(got, want)
+# the thin caller of the library's own RCCL path
+from blight_amd.dist import NativeSharded
+ix3 = B.kmer_Set_Light(k, m, n, 3, 1, b)
+ns = NativeSharded(ix3, dev)
+ns.build(seqs)
+assert torch.equal(ns.query(q), want)
+ns.close()
 dist.destroy_process_group()
 print("NCCL-WORLD1-OK")
 """
