@@ -24,6 +24,7 @@ def big():
     torch.cuda.synchronize()
     ix = B.kmer_Set_Light(k, m, n, 6, 1, b)
     ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+    ix.set_tuning("absent_filter", 1)  # wait for the filter's background passes: every query below goes through the armed filter
     return dict(torch=torch, B=B, bench=bench, dev=dev, ascii=ascii_, offs=offs, total=total, ix=ix, k=k, m=m, n=n, b=b)
 
 
@@ -120,6 +121,7 @@ def test_shards_union_equals_unsharded(big):
         sh = B.kmer_Set_Light(big["k"], big["m"], big["n"], 6, 1, big["b"])
         sh.set_shard(r, world)
         sh.construct_index_from_device(big["ascii"].data_ptr(), big["offs"].data_ptr(), big["offs"].numel() - 1, big["total"])
+        sh.set_tuning("absent_filter", 1)
         local += sh.stats()["local_number_kmer"]
         part = torch.empty(nq, device=dev, dtype=torch.int64)
         sh.query_kmers_device(q.data_ptr(), nq, part.data_ptr(), s)
@@ -186,6 +188,7 @@ def big63():
     torch.cuda.synchronize()
     ix = B.kmer_Set_Light(k, m, n, 6, 1, b)
     ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+    ix.set_tuning("absent_filter", 1)  # wait for the filter's background passes: every query below goes through the armed filter
     return dict(torch=torch, B=B, bench=bench, dev=dev, ascii=ascii_, offs=offs, total=total, ix=ix, k=k, m=m, n=n, b=b)
 
 
@@ -275,6 +278,7 @@ def test_more_than_2_pow_32_kmers():
     torch.cuda.synchronize()
     ix = B.kmer_Set_Light(k, m, n, 6, 1, b)
     ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
+    ix.set_tuning("absent_filter", 1)  # wait for the filter's background passes: every query below goes through the armed filter
     st = ix.stats()
     N = st["number_kmer"]  # (the generator trims to whole unitigs)
     assert abs(N - 4_400_000_000) < 1_000_000 and N > (1 << 32)
