@@ -1161,11 +1161,20 @@ __global__ __launch_bounds__(kBlock) void k_filter_junctions(DeviceIndexView v, 
 {
 	const uint64_t idx = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
 	const uint32_t per = (uint32_t)v.k - 1u;
-	const uint64_t j = idx / per + 1;
-	if (j >= nsk)
-		return;
-	const uint32_t t = (uint32_t)(idx - (j - 1) * per);
-	const uint64_t a = nt_start[j] - per + t;  // absolute position in the packed sequence: the k-mer ends inside super-k-mer j
+	const uint64_t junction_cand = (nsk - 1) * per;
+	uint64_t a;  // absolute position in the packed sequence
+	if (idx < junction_cand) {
+		const uint64_t j = idx / per + 1;
+		a = nt_start[j] - per + (uint32_t)(idx - (j - 1) * per);  // the k-mer ends inside super-k-mer j
+	} else {
+		// ... and the end of the whole sequence is a junction too: the windows of the last buckets run past it into the zero padding
+		// (the reference reads its vector<bool> out of range there; here and in the oracle those reads are defined as 'A'), so the
+		// k-mers that start in the last k-1 nucleotides or in the padding a window can reach are candidates like the others
+		const uint64_t e = idx - junction_cand;
+		if (e >= (uint64_t)per + (1ull << v.b))
+			return;
+		a = v.total_nt - per + e;
+	}
 	const Kmer<KW> y = packed_kmer<KW>(v.seq, a, v.k);
 	const Kmer<KW> yr = kmer_rc<KW>(y, v.k);
 	const bool fwd = !(yr < y);
@@ -2046,8 +2055,8 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			ix.filter_state.store(0);
 			hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, ix.bg_stream, v,
 			                   ix.filter_pending[1].as<uint32_t>(), ix.filter_pending[2].as<uint64_t>(), nsk, ix.filter_pending[3].as<uint64_t>(), d_filter);
-			if (nsk > 1 && ix.tune_filter_junctions) {
-				const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1), blocks = (cand + kBlock - 1) / kBlock;
+			if (ix.tune_filter_junctions) {
+				const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1) + (uint64_t)(k - 1) + (1ull << b), blocks = (cand + kBlock - 1) / kBlock;
 				const unsigned gx = (unsigned)std::min<uint64_t>(blocks, 1u << 22), gy = (unsigned)((blocks + gx - 1) / gx);
 				hipLaunchKernelGGL((k_filter_junctions<KW>), dim3(gx, gy), dim3(kBlock), 0, ix.bg_stream, v, ix.filter_pending[0].as<uint64_t>(), nsk, d_filter);
 			}

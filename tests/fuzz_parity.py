@@ -35,6 +35,8 @@ def sweep(runs, seed, verbose=True):
         try:
             ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
             ix.construct_index_from_sequences(seqs)
+            if rng.random() < 0.8:
+                ix.set_tuning("absent_filter", 1)  # queries through the armed absent-key filter (else: maybe before its passes are done)
             orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
             st = ix.stats()
             for f, g in (("number_kmer", "number_kmer"), ("number_super_kmer", "number_super_kmer"), ("total_nt", "total_nt"),
@@ -48,11 +50,32 @@ def sweep(runs, seed, verbose=True):
             neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
             allq = np.ascontiguousarray(np.concatenate([q, neg]))
             want = orc.query_kmers(allq.reshape(-1) if kb == 8 else allq)
-            for pol in (-1, 1):
+            for pol in (-1, 1, 1):  # direct kernel; partitioned pipeline: exact pass, then one pass with the learnt regions
                 ix.set_query_binning(pol)
                 got = ix.query_kmer_hash(allq.reshape(-1))
                 assert np.array_equal(got, want), (tag, "ids", pol, int((got != want).sum()))
             assert (want[: len(q)] >= 0).all(), tag
+            # every k-mer readable anywhere in the packed sequence (junctions of super-k-mers and of buckets included): the
+            # reference answers some of those although they are not keys, and so must the filter
+            words = ix.export("seq")
+            nts = ((words[:, None] >> np.arange(62, -2, -2, dtype=np.uint64)[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)[: st["total_nt"]]
+            nts = np.concatenate([nts, np.zeros((1 << b) + k, np.uint8)])  # reads past the end are defined as 'A' (windows of the last buckets)
+            vals, v, mask = set(), 0, (1 << (2 * k)) - 1
+            for p, c in enumerate(nts.tolist()):
+                v = ((v << 2) | c) & mask
+                if p >= k - 1:
+                    vals.add(min(v, O.p_rc(v, k, kb)))
+            rq = O.kmers_to_array(sorted(vals), kb)
+            got = ix.query_kmer_hash(rq.reshape(-1))
+            rwant = orc.query_kmers(rq if kb == 8 else rq.reshape(-1, 2))
+            if not np.array_equal(got, rwant):
+                bad = np.flatnonzero(got != rwant)
+                ix.set_tuning("absent_filter", 0)
+                nofilter = ix.query_kmer_hash(rq.reshape(-1))
+                ix.set_query_binning(-1)
+                direct = ix.query_kmer_hash(rq.reshape(-1))
+                raise AssertionError((tag, "readable k-mers", len(bad), [(int(i), [hex(int(x)) for x in rq.reshape(len(got), -1)[i]], int(got[i]), int(rwant[i]),
+                                                                         int(nofilter[i]), int(direct[i])) for i in bad[:5]]))
             mut = []
             for s in seqs[:50]:
                 p = int(rng.integers(0, len(s)))
