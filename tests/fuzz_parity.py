@@ -76,6 +76,10 @@ def sweep(runs, seed, verbose=True):
                 direct = ix.query_kmer_hash(rq.reshape(-1))
                 raise AssertionError((tag, "readable k-mers", len(bad), [(int(i), [hex(int(x)) for x in rq.reshape(len(got), -1)[i]], int(got[i]), int(rwant[i]),
                                                                          int(nofilter[i]), int(direct[i])) for i in bad[:5]]))
+            # reads cut from the packed sequence itself (junctions and padding included) through the sequence front end
+            step = max(1, len(nts) // 40)
+            rd = ["".join("ACTG"[c] for c in nts[a0:a0 + k + int(rng.integers(0, 2 * k))].tolist()) for a0 in range(0, max(1, len(nts) - k), step)]
+            assert np.array_equal(ix.query_sequences_hash(rd), np.concatenate([orc.query_sequence(r_) for r_ in rd])), (tag, "reads from the packed sequence")
             mut = []
             for s in seqs[:50]:
                 p = int(rng.integers(0, len(s)))
