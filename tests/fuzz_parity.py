@@ -86,6 +86,9 @@ def sweep(runs, seed, verbose=True):
                 mut.append(s[:p] + "ACGT"[("ACGT".index(s[p]) + 1) % 4] + s[p + 1:])
             assert np.array_equal(ix.query_sequences_hash(mut), np.concatenate([orc.query_sequence(s) for s in mut])), (tag, "mut")
             ix.close(); orc.close()
+            if rng.random() < 0.12:  # the same parameters through the sharded construction from slices (virtual ranks on this GPU)
+                import test_gpu_shards
+                test_gpu_shards.test_sharded_build_from_slices(int(rng.integers(2, 7)), k, m, n, b)
         except Exception as e:
             print("FAIL", tag, repr(e)[:400], flush=True)
             raise

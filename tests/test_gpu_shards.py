@@ -324,7 +324,8 @@ def test_sharded_build_from_slices(world, k, m, n, b):
     import blight_amd as B
     rng = np.random.default_rng(world * 11 + k)
     seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 80))) for _ in range(3000)]
-    seqs += ["A" * (k + 40), "AC" * (k + 3), seqs[5], seqs[5][3:]]           # duplicates and low complexity: fallback keys, shared buckets
+    longest = max(seqs[:40], key=len)
+    seqs += ["A" * (k + 40), "AC" * (k + 3), seqs[5], longest[min(3, len(longest) - k):]]  # duplicates and low complexity: fallback keys, shared buckets
     hip = C.CDLL([l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0])
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     # uneven consecutive slices; with three or more ranks one of them gets nothing
@@ -376,7 +377,8 @@ def test_sharded_build_from_slices(world, k, m, n, b):
             x.set_tuning("absent_filter", 1)  # filter armed: its regions follow the shard's LOCAL IDs
         some = seqs[::7] + [_rand_seq(rng, 3 * k) for _ in range(50)]
         got = ixs[r].query_sequences_hash(some)
-        assert np.array_equal(got, ref[r].query_sequences_hash(some)) and (got >= 0).any()
+        assert np.array_equal(got, ref[r].query_sequences_hash(some)), r
+        assert (got >= 0).any() or s1["local_number_kmer"] < 50, r  # (a shard may own next to nothing when there are fewer groups than ranks)
     # phase errors: finish without plan, plan twice
     y = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
     y.set_shard(0, world)
