@@ -104,6 +104,21 @@ def test_strand_symmetry_and_oracle_sample(big):
     neg = rng.integers(0, 1 << 62, size=200000, dtype=np.uint64)
     neg = np.array([min(int(x), O.p_rc(int(x), k)) for x in neg[:20000]], dtype=np.uint64)
     assert np.array_equal(ix.query_kmer_hash(neg), orc.query_kmers(neg))
+    # k-mers read from the packed sequence ITSELF at random places and at its very end -- junctions of super-k-mers and buckets and
+    # the zero padding included: what the reference's scan can find although it is not a key must survive the absent-key filter
+    words = arrays["seq"]
+    total_nt = st["total_nt"]
+    starts = np.concatenate([rng.integers(0, total_nt - 4 * k, size=3000), [total_nt - 2 * k]])
+    readable = []
+    for a0 in starts.tolist():
+        w = words[a0 // 32: a0 // 32 + 8]
+        nts = ((w[:, None] >> np.arange(62, -2, -2, dtype=np.uint64)[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)
+        nts = np.concatenate([nts, np.zeros(4 * k, np.uint8)])[a0 % 32: a0 % 32 + 4 * k]
+        readable.append("".join("ACTG"[c] for c in nts.tolist()))
+    got = ix.query_sequences_hash(readable)
+    want = np.concatenate([orc.query_sequence(r) for r in readable])
+    assert np.array_equal(got, want)
+    assert (want >= 0).sum() > 0.15 * want.size and (want < 0).sum() > 1000  # keys inside super-k-mers (11 of 41 positions), absent k-mers across junctions
 
 
 def test_shards_union_equals_unsharded(big):
