@@ -168,6 +168,55 @@ def test_concurrent_callers(B, O):
     assert ix.number_query - before == expect
 
 
+def test_concurrent_large_batches_on_streams(B, O):
+    """Large device-resident batches (the partitioned pipeline: shared scratch, learnt bin regions, filter gate) from four threads, each
+    on its own stream, at the same time as sequence calls from the host API: every batch gets its own answers."""
+    import torch
+    k = 31
+    ix, orc, seqs, rng = _index(B, O, k, 9, 7, 6, 8, 19, nseq=1500)
+    ix.set_tuning("absent_filter", 1)
+    ix.set_query_binning(1)
+    pos = np.concatenate([orc.canonical_kmers(s) for s in seqs])
+    dev = torch.device("cuda", 0)
+    batches, wants = [], []
+    for t in range(4):
+        neg = np.array([min(int(x), O.p_rc(int(x), k)) for x in rng.integers(0, 1 << 62, size=20000, dtype=np.uint64)], dtype=np.uint64)
+        q = np.concatenate([pos[rng.permutation(len(pos))[: 30000 + 7919 * t]], neg])
+        q = q[rng.permutation(len(q))]
+        batches.append(torch.from_numpy(q.view(np.int64)).to(dev))
+        wants.append(orc.query_kmers(q))
+    reads = _reads(rng, seqs, k, 200)
+    want_reads = [_want(orc, [r], k) for r in reads]
+    errors = []
+
+    def device_worker(t):
+        try:
+            st = torch.cuda.Stream()
+            out = torch.empty(batches[t].numel(), dtype=torch.int64, device=dev)
+            for rep in range(12):
+                out.fill_(-7)
+                st.wait_stream(torch.cuda.current_stream())
+                ix.query_kmers_device(batches[t].data_ptr(), batches[t].numel(), out.data_ptr(), st.cuda_stream)
+                st.synchronize()
+                if not np.array_equal(out.cpu().numpy(), wants[t]):
+                    errors.append(("device", t, rep))
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    def host_worker():
+        try:
+            for i, r in enumerate(reads):
+                if not np.array_equal(ix.query_sequence_hash(r), want_reads[i]):
+                    errors.append(("host", i))
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=device_worker, args=(t,)) for t in range(4)] + [threading.Thread(target=host_worker)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[:5]
+
+
 def _file_counts(O, orc, path, k):
     good = bad = 0
     for s in O.read_fasta(str(path)):
