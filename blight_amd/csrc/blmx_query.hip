@@ -1116,7 +1116,8 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	// (55 m-mers hashed once instead of twice; for 64-bit k-mers the extra 8 B/query of traffic ate the gain) unless tuned.
 	const bool handoff = ix.tune_mini_handoff >= 0 ? ix.tune_mini_handoff != 0 : (d_minis != nullptr || ix.KW == 2);
 	// One pass into bin regions sized after the previous batch when there is one to learn from (automatic), always (1) or never (2)
-	const bool onepass_ok = ix.prm.bits_saved <= 8 && nq < (1ull << 31) && 2 * (int)ix.prm.m - 1 >= 3;
+	// (slot numbers are 32-bit: bin regions + an overflow region that can hold the whole batch = about 2.1 slots per k-mer)
+	const bool onepass_ok = ix.prm.bits_saved <= 8 && nq < 1900000000ull && 2 * (int)ix.prm.m - 1 >= 3;
 	if (onepass_ok && (ix.tune_partition == 1 || (ix.tune_partition == 0 && ix.plan_bits == onepass_bits(ix)))) {
 		// behind the filter and with 1024 bins the slot kernel is issue-bound (90 % VALU, profiles/r02_pmc_c4.json): now the 4 B per
 		// k-mer of a handed-over minimizer are cheaper than computing it again (C4: 5.71 -> 5.62 ms per step)
