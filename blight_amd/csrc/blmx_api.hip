@@ -173,6 +173,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.tune_filter_bits = env_int("BLIGHT_FILTER_BITS", 8);
 	h->ix.tune_absent_filter = env_int("BLIGHT_ABSENT_FILTER", 1);
 	h->ix.tune_filter_gate = env_int("BLIGHT_FILTER_GATE", 1);
+	h->ix.tune_pos_hint = env_int("BLIGHT_POS_HINT", 1);
 	h->ix.tune_mini_handoff = env_int("BLIGHT_MINI_HANDOFF", -1);
 	h->ix.tune_query_heads = env_int("BLIGHT_QUERY_HEADS", 1);
 	h->ix.tune_reads_mode = env_int("BLIGHT_READS_MODE", 0);
@@ -718,6 +719,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_bin_bits = value;
 	else if (k == "filter_bits")  // bits per key of the absent-key filter built at construction (0 = none); set before building
 		ix.tune_filter_bits = value < 0 ? 0 : (value > 32 ? 32 : value);
+	else if (k == "pos_hint")  // before building: 0 = position fields as wide as the reference's (no sub-window hint)
+		ix.tune_pos_hint = value != 0;
 	else if (k == "filter_gate")  // 0: large batches never switch the filter off for their successors
 		ix.tune_filter_gate = value != 0;
 	else if (k == "filter_junctions")  // test hook, before building
@@ -812,16 +815,24 @@ int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
 			dev_out(ix.seq.p, 8, (ix.st.total_nt + 31) / 32);
 			break;
 		case 3:
-			dev_out(ix.positions.p, 8, (ix.st.positions_total_size + 63) / 64);
+			if (ix.pos_hint == 0) {
+				dev_out(ix.positions.p, 8, (ix.st.positions_total_size + 63) / 64);
+			} else {  // the fields in HBM are wider than the reference's: repack to its layout
+				DevBuf logical;
+				positions_to_reference_layout(ix, logical, s);
+				dev_out(logical.p, 8, (ix.st.positions_total_size + 63) / 64);
+			}
 			break;
 		case 4:
 		case 5:
 		case 6:
 		case 9: {
 			std::vector<uint64_t> v(ng + (which == 9 ? 1 : 0));
-			for (uint32_t g = 0; g < ng; g++)
-				v[g] = which == 4 ? ix.h_groups[g].nkeys : which == 5 ? ix.h_groups[g].prefix : which == 6 ? ix.h_groups[g].posstart
-				                                                                                        : ix.h_groups[g].wbase;
+			uint64_t ref_posstart = 0;  // the reference's offsets: its own field width (nbits without the hint bits) + 8 per group
+			for (uint32_t g = 0; g < ng; g++) {
+				v[g] = which == 4 ? ix.h_groups[g].nkeys : which == 5 ? ix.h_groups[g].prefix : which == 6 ? ref_posstart : ix.h_groups[g].wbase;
+				ref_posstart += (uint64_t)(ix.h_groups[g].nbits - ix.pos_hint) * ix.h_groups[g].nkeys + 8;
+			}
 			if (which == 9)
 				v[ng] = ix.total_logical_words;
 			copy_out(v.data(), 8, v.size());
@@ -830,7 +841,7 @@ int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
 		case 7: {
 			std::vector<uint32_t> v(ng);
 			for (uint32_t g = 0; g < ng; g++)
-				v[g] = ix.h_groups[g].nbits;
+				v[g] = ix.h_groups[g].nbits - ix.pos_hint;
 			copy_out(v.data(), 4, v.size());
 			break;
 		}

@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, co
 		const Kmer<KW> x = load_kmer<KW>(keys, idx);
 		const uint64_t h = mphf_lookup_levels<KW>(v, gd, gh, x);
 		if (h != kNotFound)  // ranks are distinct: a plain 4-B store, no atomics (k_pack_positions makes the bit fields)
-			field_of_rank[gh.prefix - id_base + h] = (uint32_t)((s_pos0[j] + (idx - s_ks[j])) >> v.b);
+			field_of_rank[gh.prefix - id_base + h] = (uint32_t)((s_pos0[j] + (idx - s_ks[j])) >> (v.b - v.hint));
 	}
 }
 
@@ -1117,7 +1117,7 @@ __global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ p
 	const uint32_t mi = smini[lo];
 	const GroupDesc* gd = &v.groups[mi >> v.gshift];
 	const uint64_t pos = nt_start[lo] - v.buckets[mi].start + (idx - key_start[lo]);
-	field_of_rank[gd->prefix - id_base + trank[e]] = (uint32_t)(pos >> v.b);
+	field_of_rank[gd->prefix - id_base + trank[e]] = (uint32_t)(pos >> (v.b - v.hint));
 }
 
 // Absent-key filter, first pass: every key (also the duplicates and the ones the fallback table ranks) sets its five bits in the
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_junctions(DeviceIndexView v, 
 	const uint64_t h = mphf_lookup<KW>(v, gd, gh, x);
 	if (h == kNotFound)
 		return;
-	const uint64_t pos = read_position(v.positions, gh.posstart, gh.nbits, h, v.b);
+	const uint64_t pos = read_position(v.positions, gh.posstart, gh.nbits, h, v.hint, v.b);
 	if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bd.nt) || rel < pos || rel >= pos + (1ull << v.b))
 		return;
 	const uint64_t fh = filter_hash<KW>(x);
@@ -1653,15 +1653,23 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	// ---- host: group descriptors (blight.cpp:292-303) and BBHash level tables (bbhash.h:591-614)
 	ix.h_groups.assign(ngroups, GroupDesc{});
 	std::vector<uint64_t> h_loff((size_t)ngroups * kLevels, 0), h_line_base((size_t)ngroups + 1, 0);
-	uint64_t total_pos = 0, wbase = 0, lbase = 0, largest_mphf = 0;
+	uint64_t total_pos = 0, phys_pos = 0, wbase = 0, lbase = 0, largest_mphf = 0;
 	uint32_t largest_bucket = 0;
+	// physical position fields: the reference's nbits plus `hint` low bits (the sub-window of the key inside its 2^b window), when
+	// every group's field still fits 32 bits; the reference's own offsets (total_pos) are kept for the counters and the export
+	uint32_t hint = (ix.tune_pos_hint && b <= 8) ? (uint32_t)position_hint_bits(b) : 0u;
+	for (uint32_t g = 0; g < ngroups && hint; g++)
+		if ((int)(ceil(log2((double)(uint32_t)(h_gmax[g] + 1))) - (double)b) + (int)hint > 32)
+			hint = 0;
+	ix.pos_hint = hint;
 	for (uint32_t g = 0; g < ngroups; g++) {
 		GroupDesc& gd = ix.h_groups[g];
 		int nb = (int)(ceil(log2((double)(uint32_t)(h_gmax[g] + 1))) - (double)b);
 		if (nb < 1)
 			nb = 1;
-		gd.nbits = (uint32_t)nb;
-		gd.posstart = total_pos;
+		gd.nbits = (uint32_t)nb + hint;
+		gd.posstart = phys_pos;
+		phys_pos += (uint64_t)(nb + hint) * h_gnk[g] + 8;
 		total_pos += (uint64_t)nb * h_gnk[g] + 8;  // round_eight, blight.cpp:102-104
 		gd.prefix = h_gpre[g];
 		gd.nkeys = h_gnk[g];
@@ -2000,7 +2008,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 
 	mark("K9a fallback");
 	// ---- K9b: positions
-	ix.positions_words = total_pos / 64 + 3;
+	ix.positions_words = phys_pos / 64 + 3;
 	BLMX_HIP(ix.positions.alloc(ix.positions_words * 8, true, s));
 	ix.st.total_nt = total_nt;
 	// absent-key filter (index_device.h): tune_filter_bits per key, every key inserted by the positions pass
@@ -2307,6 +2315,41 @@ void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in
 
 namespace {
 }  // namespace
+
+// `positions` as the reference lays it out (fields of nbits - hint bits at its own offsets) from the wider fields in HBM
+__global__ __launch_bounds__(256) void k_positions_reference_layout(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ ref_posstart,
+                                                                  uint32_t hint, const uint64_t* __restrict__ phys, unsigned long long* __restrict__ out)
+{
+	const GroupDesc* gd = &groups[blockIdx.x];
+	const uint32_t nb = gd->nbits, nl = nb - hint;
+	const uint64_t n = gd->nkeys, ps = gd->posstart, ls = ref_posstart[blockIdx.x];
+	for (uint64_t r = threadIdx.x; r < n; r += blockDim.x) {
+		const uint64_t field = (uint64_t)(read_position_field(phys, ps, nb, r) >> hint);
+		const uint64_t o = ls + r * nl;
+		const uint32_t sh = (uint32_t)o & 63u;
+		if (field) {
+			atomicOr(&out[o >> 6], (unsigned long long)(field << sh));
+			if (sh + nl > 64)
+				atomicOr(&out[(o >> 6) + 1], (unsigned long long)(field >> (64 - sh)));
+		}
+	}
+}
+
+void positions_to_reference_layout(const Index& ix, DevBuf& out, hipStream_t s)
+{
+	const uint32_t ng = ix.ngroups;
+	std::vector<uint64_t> ref((size_t)ng + 1, 0);
+	for (uint32_t g = 0; g < ng; g++)
+		ref[g + 1] = ref[g] + (uint64_t)(ix.h_groups[g].nbits - ix.pos_hint) * ix.h_groups[g].nkeys + 8;
+	DevBuf d_ref;
+	BLMX_HIP(d_ref.alloc(ref.size() * 8, false, s));
+	BLMX_HIP(hipMemcpyAsync(d_ref.p, ref.data(), ref.size() * 8, hipMemcpyHostToDevice, s));
+	BLMX_HIP(out.alloc((ref[ng] / 64 + 3) * 8, true, s));
+	hipLaunchKernelGGL(k_positions_reference_layout, dim3(ng), dim3(256), 0, s, ix.groups.as<GroupDesc>(), d_ref.as<uint64_t>(), ix.pos_hint,
+	                   ix.positions.as<uint64_t>(), out.as<unsigned long long>());
+	BLMX_HIP(hipGetLastError());
+	BLMX_HIP(hipStreamSynchronize(s));
+}
 
 void init_filter_gate(Index& ix, hipStream_t s)
 {

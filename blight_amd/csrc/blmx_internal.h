@@ -52,6 +52,7 @@ static_assert(sizeof(QueryHead) == 32, "QueryHead must be 32 bytes");
 
 struct DeviceIndexView {
 	int k, m, n, b, gshift;
+	int hint;  // extra low bits of every position field (physical layout only, see read_position_field); 0 = the reference's fields
 	uint32_t nbuckets, ngroups;
 	const BucketDesc* buckets;
 	const GroupDesc* groups;
@@ -267,6 +268,7 @@ struct Index {
 	std::vector<uint32_t> h_fb_group;
 	blmx_stats_t st{};
 	uint64_t positions_words = 0, seq_words = 0, total_lines = 0, total_logical_words = 0;
+	uint32_t pos_hint = 0;  // extra low bits per position field in HBM (0 = the reference's field width)
 
 	// staging for host-buffer queries
 	DevBuf q_in, q_aux, q_out;
@@ -295,6 +297,7 @@ struct Index {
 	int tune_slot_slack_pct = 0; // one-pass partition: slots per bin = mean occupancy + this many percent (0 = default 12)
 	int tune_narrow_ids = 1;     // host-buffer results cross PCIe as 32-bit words when every ID fits (0 = always 64-bit)
 	int tune_absent_filter = 1;  // queries consult the absent-key filter (when the index was built with one)
+	int tune_pos_hint = 1;          // build: position fields keep position_hint_bits(b) more low bits (0 = the reference's fields)
 	int tune_filter_gate = 1;       // large batches with almost no absent k-mers switch the filter off for the next ones (0 = never)
 	int tune_filter_junctions = 1;  // test hook: 0 = skip the filter's second pass (the filter then loses the reference's false positives)
 	int tune_filter_bits = 8;    // bits per key of the filter built at construction (0 = build none; BLIGHT_FILTER_BITS)
@@ -328,6 +331,7 @@ struct Index {
 		v.m = (int)prm.m;
 		v.n = (int)prm.log2_mphf;
 		v.b = (int)prm.bits_saved;
+		v.hint = (int)pos_hint;
 		v.gshift = gshift;
 		v.nbuckets = nbuckets;
 		v.ngroups = ngroups;
@@ -351,6 +355,7 @@ struct Index {
 // build (blmx_build.hip)
 void make_query_heads(Index& ix);  // from ix.h_groups, after the group table is final (build and load)
 void init_filter_gate(Index& ix, hipStream_t s);  // with the filter (build and load)
+void positions_to_reference_layout(const Index& ix, DevBuf& out, hipStream_t s);  // `positions` with the reference's field width (export)
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
 // sharded build from slices, phase by phase (blmx_build.hip); hist_out holds ngroups + 1 words: key histogram, local super-k-mers
 void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out);

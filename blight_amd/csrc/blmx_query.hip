@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_query_anyb(DeviceIndexView v, const uin
 		const uint64_t h = mphf_lookup<KW>(v, gd, gh, x);
 		if (h == kNotFound)
 			break;
-		const uint64_t pos = read_position(v.positions, gh.posstart, gh.nbits, h, v.b);
+		const uint64_t pos = read_position(v.positions, gh.posstart, gh.nbits, h, v.hint, v.b);
 		if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bd.nt) || xr < x)
 			break;
 		const uint64_t P = 1ull << v.b;

@@ -583,8 +583,8 @@ void save_index(Index& ix, const char* path)
 		throw StatusError{BLMX_EIO, "Problem with files opening"};
 	FileHeader h{};
 	memcpy(h.magic, kImageMagic, 8);
-	h.version = ix.filter_bpk ? kImageVersionFilter : kImageVersion;
-	h.filter_bpk = ix.filter_bpk;
+	h.version = (ix.filter_bpk || ix.pos_hint) ? kImageVersionFilter : kImageVersion;
+	h.filter_bpk = ix.filter_bpk | (ix.pos_hint << 8);  // low byte: filter bits per key; next byte: hint bits of the position fields
 	h.abi = BLMX_ABI_VERSION;
 	h.stats_bytes = sizeof(blmx_stats_t);
 	h.group_desc_bytes = sizeof(GroupDesc);
@@ -654,7 +654,10 @@ void load_index(Index& ix, const char* path)
 	get(fh.f, &h, sizeof h);
 	if (memcmp(h.magic, kImageMagic, 8) != 0)
 		throw StatusError{BLMX_EIO, "not a Blight MI355X index file"};
-	if ((h.version != kImageVersion && h.version != kImageVersionFilter) || (h.version == kImageVersion && h.filter_bpk) || h.filter_bpk > 32 ||
+	const uint32_t img_hint = (h.filter_bpk >> 8) & 0xffu;
+	h.filter_bpk &= 0xffu;
+	if ((h.version != kImageVersion && h.version != kImageVersionFilter) || (h.version == kImageVersion && (h.filter_bpk || img_hint)) || h.filter_bpk > 32 ||
+	    img_hint > 3 || img_hint > h.bits_saved ||
 	    h.stats_bytes != sizeof(blmx_stats_t) || h.group_desc_bytes != sizeof(GroupDesc))
 		throw StatusError{BLMX_EIO, "index file written by an incompatible library version"};
 	if (h.k != ix.prm.k || h.m != ix.prm.m || h.log2_mphf != ix.prm.log2_mphf || h.bits_saved != ix.prm.bits_saved ||
@@ -724,7 +727,7 @@ void load_index(Index& ix, const char* path)
 				bits += gd.size[l];
 			}
 			const uint64_t glines = gd.nkeys ? (bits / 32 + kLineData32 - 1) / kLineData32 : 0;
-			if (gd.nbits == 0 || gd.nbits > 32 || gd.nkeys > (1ull << 40) || gd.line_base > h.total_lines || glines > h.total_lines - gd.line_base ||
+			if (gd.nbits <= img_hint || gd.nbits > 32 || gd.nkeys > (1ull << 40) || gd.line_base > h.total_lines || glines > h.total_lines - gd.line_base ||
 			    gd.posstart > h.positions_words * 64 || gd.nkeys * gd.nbits > h.positions_words * 64 - gd.posstart || gd.fb_start > h.nfb ||
 			    gd.fb_count > h.nfb - gd.fb_start)
 				bad("group table");
@@ -740,6 +743,7 @@ void load_index(Index& ix, const char* path)
 			bad("key counts");
 	}
 	make_query_heads(ix);
+	ix.pos_hint = img_hint;
 	ix.shard_rank = h.shard_rank;
 	ix.shard_world = h.shard_world;
 	ix.positions_words = h.positions_words;

@@ -218,9 +218,11 @@ __device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const 
 	return kNotFound;
 }
 
-// bool_to_int, blight.cpp:473-482: nbits-wide little-endian field at bit posstart + h*nbits, times 2^b in uint32_t.
-__device__ __forceinline__ uint32_t read_position(const uint64_t* __restrict__ positions, uint64_t posstart, uint32_t nbits,
-                                                  uint64_t h, int b)
+// bool_to_int, blight.cpp:473-482: nbits-wide little-endian field at bit posstart + h*nbits.
+// Physical layout: a field holds the key's position in its bucket >> (b - hint) -- `hint` more low bits than the reference keeps
+// (DeviceIndexView::hint, 0 = the reference's field): field >> hint is the reference's value (the 2^b window), the low `hint` bits name
+// the 2^(b-hint) sub-window inside it that holds the key itself.
+__device__ __forceinline__ uint32_t read_position_field(const uint64_t* __restrict__ positions, uint64_t posstart, uint32_t nbits, uint64_t h)
 {
 	// nbits <= 32 and a dword-aligned 8-B window starts at most 31 bits before the field: ONE global_load_dwordx2
 	// (multi-dword loads need dword alignment only) instead of two aligned 8-B words
@@ -229,8 +231,17 @@ __device__ __forceinline__ uint32_t read_position(const uint64_t* __restrict__ p
 	const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint32_t*>(positions) + (o >> 5));
 	const uint32_t s = (uint32_t)o & 31u;
 	const uint64_t v = ((uint64_t)w.x | ((uint64_t)w.y << 32)) >> s;
-	const uint32_t field = (uint32_t)(v & ((nbits >= 32) ? 0xffffffffull : ((1ull << nbits) - 1ull)));
-	return field << b;
+	return (uint32_t)(v & ((nbits >= 32) ? 0xffffffffull : ((1ull << nbits) - 1ull)));
 }
+// the reference's value: first position of the 2^b window
+__device__ __forceinline__ uint32_t read_position(const uint64_t* __restrict__ positions, uint64_t posstart, uint32_t nbits,
+                                                  uint64_t h, int hint, int b)
+{
+	return (read_position_field(positions, posstart, nbits, h) >> hint) << b;
+}
+// Extra low bits a field keeps for windows of 2^logp positions.  Only for the wide windows: at b = 8 the 256 steps of the scan are most
+// of the query kernel's instructions and the kernel is issue-bound (C5: 4.39 -> 3.82 ms); at b <= 6 the kernel waits for memory, the
+// shorter scan buys nothing (C4: 3.40 -> 3.41 ms) and the wider fields cost 3 bits per key.
+__host__ __device__ constexpr int position_hint_bits(int logp) { return logp >= 7 ? 3 : 0; }
 
 }  // namespace blmx

@@ -243,11 +243,26 @@ __device__ __forceinline__ void query_one(const DeviceIndexView& v, Kmer<KW> x, 
 	const uint64_t h = mphf_lookup<KW>(v, gd, gh, x);
 	if (h == kNotFound)  // blight.cpp:725-726
 		return;
-	const uint64_t pos = read_position(v.positions, gh.posstart, gh.nbits, h, v.b);
+	const uint32_t field = read_position_field(v.positions, gh.posstart, gh.nbits, h);
+	const uint64_t pos = (uint64_t)(field >> v.hint) << v.b;  // the reference's value: first position of the 2^b window
 	if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bnt))  // blight.cpp:729
 		return;
 	if (xr < x)  // non-canonical query: canonR == canon can never hold (blight.cpp:733-735)
 		return;
+	// The field's extra low bits name the sub-window that holds the key this rank belongs to: an indexed k-mer is found there in
+	// 2^(b - hint) steps.  Only a k-mer that is NOT there (a false positive of the filter, or one of the reference's own false
+	// positives, which sit anywhere in the window) goes through the reference's whole window; the first match of the whole
+	// window is what the positional query reports, so that one always scans all of it.
+	constexpr int kHint = position_hint_bits(LOGP);
+	if constexpr (kHint > 0 && !WANT_POS) {
+		if (v.hint == kHint) {
+			const uint64_t sub = pos + ((uint64_t)(field & ((1u << kHint) - 1u)) << (LOGP - kHint));
+			if (scan_window<KW, LOGP - kHint, false>(v.seq, bstart + sub, v.k, x, xr) >= 0) {
+				id = (int64_t)(h + gh.prefix);
+				return;
+			}
+		}
+	}
 	const int j = scan_window<KW, LOGP, WANT_POS>(v.seq, bstart + pos, v.k, x, xr);
 	if (j >= 0) {
 		id = (int64_t)(h + gh.prefix);        // blight.cpp:736

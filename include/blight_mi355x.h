@@ -271,6 +271,9 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
  *   "absent_filter"  0: queries ignore the filter (workloads in which nearly every k-mer is indexed run ~5 % faster without it);
  *                    1: use it, and wait for its background passes if they are still running (they start when the build returns and
  *                    take about as long as the build; until they are done queries run unfiltered).
+ *   "pos_hint"       before building: 0 = position fields exactly as wide as the reference's.  Default 1: at bits_to_save >= 7 a
+ *                    field keeps three more low bits of the position, so that a query finds an indexed k-mer in a 2^(b-3)
+ *                    sub-window instead of scanning the reference's 2^b window (which remains the fallback).
  *   "filter_gate"    1 (default): a large batch in which fewer than 1 in 12 answers were "absent" switches the filter off for the
  *                    batches after it (and one with more switches it on again); 0: the filter is always consulted.
  *   "partition"      large k-mer batches are ordered by minimizer prefix in front of the query kernel: 0 = exact counting sort for
