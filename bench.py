@@ -726,7 +726,7 @@ def main():
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
                        "build_kmers_per_sec": st["number_kmer"] / t_build,
                        "absent_filter": "blocked Bloom filter over the keys, %s bits/key; its passes ran %.2f s in the background after the build returned" % (
-                           os.environ.get("BLIGHT_FILTER_BITS", "8"), t_filter_bg), "largest_mphf": st["largest_mphf"], "largest_bucket": st["largest_bucket"],
+                           os.environ.get("BLIGHT_FILTER_BITS", "8, or 16 at b >= 7"), t_filter_bg), "largest_mphf": st["largest_mphf"], "largest_bucket": st["largest_bucket"],
                        "mphf_groups_lds_built": st["mphf_groups_lds_built"], "mphf_groups": st["ngroups"], "fallback_keys": st["fallback_keys"]},
             "roofline": roofline_block(args, k, kw, b, nq, stages, kern_ms, st) if not multi else
             {"bound": "hbm", "achieved": ALGO_BYTES.get(k, 145) * nq * world / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",

@@ -170,7 +170,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	// tuning knobs: seeded from the environment once per index (blmx_set_tuning changes them later)
 	h->ix.bin_policy = env_int("BLIGHT_QUERY_BINNING", 0);
 	h->ix.tune_bin_bits = env_int("BLIGHT_BIN_BITS", 0);
-	h->ix.tune_filter_bits = env_int("BLIGHT_FILTER_BITS", 8);
+	h->ix.tune_filter_bits = env_int("BLIGHT_FILTER_BITS", -1);
 	h->ix.tune_absent_filter = env_int("BLIGHT_ABSENT_FILTER", 1);
 	h->ix.tune_filter_gate = env_int("BLIGHT_FILTER_GATE", 1);
 	h->ix.tune_pos_hint = env_int("BLIGHT_POS_HINT", 1);
@@ -718,7 +718,7 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 	if (k == "bin_bits")
 		ix.tune_bin_bits = value;
 	else if (k == "filter_bits")  // bits per key of the absent-key filter built at construction (0 = none); set before building
-		ix.tune_filter_bits = value < 0 ? 0 : (value > 32 ? 32 : value);
+		ix.tune_filter_bits = value < 0 ? -1 : (value > 32 ? 32 : value);  // -1 = automatic
 	else if (k == "pos_hint")  // before building: 0 = position fields as wide as the reference's (no sub-window hint)
 		ix.tune_pos_hint = value != 0;
 	else if (k == "filter_gate")  // 0: large batches never switch the filter off for their successors

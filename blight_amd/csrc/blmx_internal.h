@@ -300,7 +300,8 @@ struct Index {
 	int tune_pos_hint = 1;          // build: position fields keep position_hint_bits(b) more low bits (0 = the reference's fields)
 	int tune_filter_gate = 1;       // large batches with almost no absent k-mers switch the filter off for the next ones (0 = never)
 	int tune_filter_junctions = 1;  // test hook: 0 = skip the filter's second pass (the filter then loses the reference's false positives)
-	int tune_filter_bits = 8;    // bits per key of the filter built at construction (0 = build none; BLIGHT_FILTER_BITS)
+	int tune_filter_bits = -1;   // bits per key of the filter built at construction (0 = build none, -1 = automatic: 8, or 16 with the
+	                             // position hint of the wide windows; BLIGHT_FILTER_BITS)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
 
 	Index()

@@ -265,7 +265,8 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
 /* Per-index tuning knobs (experiments, tests, workload hints; results never depend on them).  The environment variables
  * BLIGHT_BIN_BITS, BLIGHT_MINI_HANDOFF, BLIGHT_QUERY_HEADS, BLIGHT_READS_MODE, BLIGHT_WINDOW_KB, BLIGHT_QUERY_BINNING,
  * BLIGHT_FILTER_BITS, BLIGHT_ABSENT_FILTER seed them when the index is created.  Keys:
- *   "filter_bits"    bits per key of the absent-key filter built at construction (default 8; 0 = build none).  Set before building.
+ *   "filter_bits"    bits per key of the absent-key filter built at construction (0 = build none; default / negative = automatic: 8, and
+ *                    16 at bits_to_save >= 7).  Set before building.
  *                    The filter is a blocked Bloom filter over the keys plus the few non-keys the reference's scan can find; a k-mer
  *                    it rejects is answered -1 after one 8-byte load.  It costs filter_bits / 8 bytes of HBM per indexed k-mer.
  *   "absent_filter"  0: queries ignore the filter (workloads in which nearly every k-mer is indexed run ~5 % faster without it);
