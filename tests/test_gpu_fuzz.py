@@ -1,4 +1,4 @@
-"""A short slice of the randomised parity sweep (tests/fuzz_parity.py; 3000 configurations were swept once by hand in r01, about 9600 with the
+"""A short slice of the randomised parity sweep (tests/fuzz_parity.py; 3000 configurations were swept once by hand in r01, about 11600 with the
 absent-key filter, the one-pass partition and the sharded construction from slices in r02):
 random (k, m, n, b, k-mer width) and random inputs with low-complexity, tandem and duplicated stretches; counters, exported
 arrays, IDs (direct and partitioned pipeline), negatives, near misses and EVERY k-mer readable anywhere in the packed sequence
