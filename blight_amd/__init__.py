@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
-ABI_VERSION = 9  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
+ABI_VERSION = 10  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT, BLMX_ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 COMM_ID_BYTES = 128
 
@@ -114,7 +114,15 @@ def load_library():
     lib.blmx_build_sharded_from_device_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
     lib.blmx_shard_build_begin.argtypes = [C.c_void_p, C.c_char_p, _u64p, C.c_uint64, _u64p]
     lib.blmx_shard_build_begin_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, _u64p]
-    lib.blmx_shard_build_plan.argtypes = [C.c_void_p, _u64p, _u64p, _u64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.blmx_shard_build_plan.argtypes = [C.c_void_p, _u64p, C.c_uint32, _u64p, _u64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.blmx_shard_halo_words.argtypes = [C.c_void_p]
+    lib.blmx_shard_halo_words.restype = C.c_uint64
+    lib.blmx_shard_halo_get.argtypes = [C.c_void_p, _u64p]
+    lib.blmx_shard_halo_set.argtypes = [C.c_void_p, _u64p, C.c_uint32]
+    lib.blmx_comm_loopback_id.argtypes = [C.c_void_p]
+    lib.blmx_comm_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.blmx_comm_transport.argtypes = [C.c_void_p]
+    lib.blmx_comm_transport.restype = C.c_char_p
     lib.blmx_shard_build_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u64p, _u64p]
     lib.blmx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
@@ -406,9 +414,21 @@ class kmer_Set_Light:
             raise ValueError("global_hist must hold 2^log2_mphf + 1 words")
         sk, words = np.zeros(world, np.uint64), np.zeros(world, np.uint64)
         pm, pw = C.c_void_p(), C.c_void_p()
-        self._check(self._lib.blmx_shard_build_plan(self._h, gh.ctypes.data_as(_u64p), sk.ctypes.data_as(_u64p), words.ctypes.data_as(_u64p),
-                                                    C.byref(pm), C.byref(pw)))
+        self._check(self._lib.blmx_shard_build_plan(self._h, gh.ctypes.data_as(_u64p), world, sk.ctypes.data_as(_u64p),
+                                                    words.ctypes.data_as(_u64p), C.byref(pm), C.byref(pw)))
         return sk, words, pm.value or 0, pw.value or 0
+
+    def shard_halo_get(self):
+        """after shard_build_finish: the head of this shard's packed sequence (one record: valid nucleotides, then 2-bit words)"""
+        rec = np.zeros(int(self._lib.blmx_shard_halo_words(self._h)), dtype=np.uint64)
+        self._check(self._lib.blmx_shard_halo_get(self._h, rec.ctypes.data_as(_u64p)))
+        return rec
+
+    def shard_halo_set(self, records):
+        """records of ALL ranks in rank order (world x shard_halo_words): what follows this shard in the single index goes behind it"""
+        r = np.ascontiguousarray(records, dtype=np.uint64)
+        world = r.size // int(self._lib.blmx_shard_halo_words(self._h))
+        self._check(self._lib.blmx_shard_halo_set(self._h, r.ctypes.data_as(_u64p), world))
 
     def shard_build_finish(self, d_meta_ptr, d_words_ptr, recv_sk, recv_words):
         rs, rw = np.ascontiguousarray(recv_sk, dtype=np.uint64), np.ascontiguousarray(recv_words, dtype=np.uint64)
@@ -454,8 +474,19 @@ def comm_unique_id():
     return buf.raw
 
 
+def comm_loopback_id():
+    """an id for `world` communicators inside ONE process (one thread per rank, one GPU): the loopback transport"""
+    lib = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib.blmx_comm_loopback_id(buf)
+    if rc:
+        _raise(rc, lib.blmx_last_error(None).decode() or "blmx_comm_loopback_id failed")
+    return buf.raw
+
+
 class Comm:
-    """Native RCCL communicator of the library (one process per GPU); collective construction like ncclCommInitRank."""
+    """Native communicator of the library: RCCL (one process per GPU; collective construction like ncclCommInitRank) or, with an
+    id from comm_loopback_id(), the in-process loopback transport."""
 
     def __init__(self, unique_id, rank, world, device=0):
         self._lib = load_library()
@@ -465,6 +496,16 @@ class Comm:
         if rc:
             self._c = None
             _raise(rc, self._lib.blmx_last_error(None).decode() or "blmx_comm_create failed")
+
+    @property
+    def transport(self):
+        return self._lib.blmx_comm_transport(self._c).decode()
+
+    def set_tuning(self, key, value):
+        """"flow_words" / "pieces" (see blmx_comm_set_tuning); the same on every rank"""
+        rc = self._lib.blmx_comm_set_tuning(self._c, key.encode(), int(value))
+        if rc:
+            _raise(rc, self._lib.blmx_last_error(None).decode() or "blmx_comm_set_tuning failed")
 
     def query_kmers_sharded_device(self, index, d_kmers_ptr, nq, d_ids_ptr, stream=None):
         """collective: every rank calls it with its own batch; IDs in the caller's order"""
@@ -481,8 +522,7 @@ class Comm:
 
     def query_kmers_sharded(self, index, kmers):
         """collective, host buffers: canonical k-mers (uint64, two words per k-mer for k > 32) -> IDs"""
-        a = np.ascontiguousarray(kmers, dtype=np.uint64)
-        nq = a.size // (index.kmer_bytes // 8)
+        a, nq = _kmers_array(np.ascontiguousarray(kmers, dtype=np.uint64), index.kmer_bytes)
         ids = np.empty(nq, dtype=np.int64)
         index._check(self._lib.blmx_query_kmers_sharded(index._h, self._c, a.ctypes.data, nq, ids.ctypes.data_as(_i64p)))
         return ids

@@ -17,7 +17,7 @@ SOURCES = ["blmx_api.hip", "blmx_build.hip", "blmx_query.hip", "blmx_reads.hip",
 HEADERS = ["blmx_internal.h", "device_prims.h", "index_device.h", "query_device.h", os.path.join(ROOT, "include", "blight_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-DNDEBUG",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+         "-fno-gpu-rdc"]
 
 
 def _newer(target, deps):

@@ -596,6 +596,22 @@ int blmx_comm_create(const void* id, uint32_t rank, uint32_t world, int device, 
 
 void blmx_comm_destroy(blmx_comm* c) { comm_destroy(reinterpret_cast<Comm*>(c)); }
 
+int blmx_comm_loopback_id(void* id_out)
+{
+	if (!id_out)
+		return BLMX_EINVAL;
+	return guarded(nullptr, [&] { comm_loopback_id(id_out); });
+}
+
+int blmx_comm_set_tuning(blmx_comm* c, const char* key, int64_t value)
+{
+	if (!c || !key)
+		return BLMX_EINVAL;
+	return guarded(nullptr, [&] { comm_set_tuning(*reinterpret_cast<Comm*>(c), key, value); });
+}
+
+const char* blmx_comm_transport(const blmx_comm* c) { return c ? comm_transport(reinterpret_cast<const Comm*>(c)) : ""; }
+
 int blmx_query_kmers_sharded_device(blmx_index* h, blmx_comm* c, const void* d_kmers, uint64_t nq, int64_t* d_ids, void* stream)
 {
 	if (!h || !c || (nq && (!d_kmers || !d_ids)))
@@ -608,9 +624,19 @@ int blmx_build_sharded_from_sequences(blmx_index* h, blmx_comm* c, const char* c
 	if (!h || !c || (nseq && (!concat || !offsets)))
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
-		with_staged_sequences(h->ix, concat, offsets, nseq, [&](const uint8_t* a, const uint64_t* o, uint64_t total) {
-			build_sharded(h->ix, *reinterpret_cast<Comm*>(c), a, o, nseq, total);
-		});
+		// a rank whose staging fails (bad offsets, out of memory) still joins the collective, with a failure vote: nobody waits for it
+		bool entered = false;
+		try {
+			with_staged_sequences(h->ix, concat, offsets, nseq, [&](const uint8_t* a, const uint64_t* o, uint64_t total) {
+				entered = true;
+				build_sharded(h->ix, *reinterpret_cast<Comm*>(c), a, o, nseq, total);
+			});
+		} catch (const StatusError& e) {
+			if (entered)
+				throw;
+			build_sharded(h->ix, *reinterpret_cast<Comm*>(c), nullptr, nullptr, 0, 0, &e);
+			throw;
+		}
 	});
 }
 
@@ -679,13 +705,36 @@ int blmx_shard_build_begin_device(blmx_index* h, const void* d_concat, const uin
 	});
 }
 
-int blmx_shard_build_plan(blmx_index* h, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta, const void** d_words)
+int blmx_shard_build_plan(blmx_index* h, const uint64_t* global_hist, uint32_t world, uint64_t* send_sk, uint64_t* send_words, const void** d_meta,
+                          const void** d_words)
 {
 	if (!h || !global_hist || !send_sk || !send_words || !d_meta || !d_words)
 		return BLMX_EINVAL;
 	return guarded(h, [&] {
 		BLMX_HIP(hipSetDevice(h->ix.prm.device));
-		shard_build_plan(h->ix, global_hist, send_sk, send_words, d_meta, d_words);
+		shard_build_plan(h->ix, global_hist, world, send_sk, send_words, d_meta, d_words);
+	});
+}
+
+uint64_t blmx_shard_halo_words(const blmx_index* h) { return h ? shard_halo_words(h->ix) : 0; }
+
+int blmx_shard_halo_get(blmx_index* h, uint64_t* record_out)
+{
+	if (!h || !record_out)
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		shard_halo_get(h->ix, record_out);
+	});
+}
+
+int blmx_shard_halo_set(blmx_index* h, const uint64_t* records, uint32_t world)
+{
+	if (!h || !records)
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		shard_halo_set(h->ix, records, world);
 	});
 }
 

@@ -425,16 +425,20 @@ __global__ void k_group_tables(const uint64_t* __restrict__ b_nt, const uint64_t
 
 // ---- K5 ----------------------------------------------------------------------------------------------------------------
 // str2bool (blight.cpp:311-324): copy the nucleotides of sorted super-k-mer j to its slot of the packed sequence.
+// `clip`: nothing is written at or behind this destination position (the halo of a shard keeps only the head of what follows it).
 __global__ void k_scatter_pack(const uint64_t* __restrict__ src, const uint32_t* __restrict__ order, const uint64_t* __restrict__ sk_pos,
                                const uint64_t* __restrict__ nt_start, const uint64_t* __restrict__ len_nt, uint64_t nsk,
-                               unsigned long long* __restrict__ seq)
+                               unsigned long long* __restrict__ seq, uint64_t clip)
 {
 	const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= nsk)
 		return;
 	const uint64_t p = sk_pos[order[j]];
 	// destinations are back to back (len_nt == nullptr: the next start is this end) or carry their own lengths (segmented streams)
-	const uint64_t d = nt_start[j], e = len_nt ? d + len_nt[j] : nt_start[j + 1];
+	const uint64_t d = nt_start[j];
+	if (d >= clip)
+		return;
+	const uint64_t e = min(len_nt ? d + len_nt[j] : nt_start[j + 1], clip);
 	for (uint64_t dw = d >> 5; dw <= (e - 1) >> 5; dw++) {
 		const uint64_t a = max(d, dw * 32), z = min(e, dw * 32 + 32);
 		const int cnt = (int)(z - a);
@@ -445,6 +449,24 @@ __global__ void k_scatter_pack(const uint64_t* __restrict__ src, const uint32_t*
 		v >>= 2 * (a & 31);
 		atomicOr(&seq[dw], v);
 	}
+}
+
+// The halo of a shard: `n` nucleotides (2-bit packed, first nt most significant, starting at bit 63 of halo[0]; one readable word
+// behind them) ORed into the zeroed tail of the packed sequence at nucleotide `at`.  One thread per destination word.
+__global__ void k_put_halo(const uint64_t* __restrict__ halo, uint64_t n, uint64_t at, unsigned long long* __restrict__ seq)
+{
+	const uint64_t dw = (at >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t e = at + n;
+	if (n == 0 || dw > (e - 1) >> 5)
+		return;
+	const uint64_t a = max(at, dw * 32), z = min(e, dw * 32 + 32);
+	const int cnt = (int)(z - a);
+	const uint64_t sp = a - at;
+	uint64_t v = funnel_left(halo[sp >> 5], halo[(sp >> 5) + 1], 2 * (int)(sp & 31));
+	if (cnt < 32)
+		v &= ~0ull << (64 - 2 * cnt);
+	v >>= 2 * (a & 31);
+	atomicOr(&seq[dw], v);
 }
 
 // ---- K6 ----------------------------------------------------------------------------------------------------------------
@@ -1155,23 +1177,26 @@ __global__ __launch_bounds__(kBlock) void k_filter_keys(DeviceIndexView v, const
 // whose position window covers the place where x can be read.  One lane per k-mer that starts in the last k-1 nucleotides of a
 // super-k-mer: canonical form, its own minimizer -> the bucket a query would look in, and exactly the query's test; the few that
 // pass (a 2^b window among a bucket's positions) are added to the filter.
+// Candidates [0, junction_cand) are the junctions between super-k-mers (junction_cand = (nsk - 1) (k - 1)), the ones behind them the
+// end of the sequence; a launch with junction_cand = 0 and nt_start = nullptr runs the end junction alone (a shard whose halo -- the
+// head of the sequence that follows it in the single index -- arrives after its own build: shard_halo_set).
 template <int KW>
-__global__ __launch_bounds__(kBlock) void k_filter_junctions(DeviceIndexView v, const uint64_t* __restrict__ nt_start, uint64_t nsk,
+__global__ __launch_bounds__(kBlock) void k_filter_junctions(DeviceIndexView v, const uint64_t* __restrict__ nt_start, uint64_t junction_cand,
                                                              unsigned long long* __restrict__ filter)
 {
 	const uint64_t idx = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
 	const uint32_t per = (uint32_t)v.k - 1u;
-	const uint64_t junction_cand = (nsk - 1) * per;
 	uint64_t a;  // absolute position in the packed sequence
 	if (idx < junction_cand) {
 		const uint64_t j = idx / per + 1;
 		a = nt_start[j] - per + (uint32_t)(idx - (j - 1) * per);  // the k-mer ends inside super-k-mer j
 	} else {
 		// ... and the end of the whole sequence is a junction too: the windows of the last buckets run past it into the zero padding
-		// (the reference reads its vector<bool> out of range there; here and in the oracle those reads are defined as 'A'), so the
-		// k-mers that start in the last k-1 nucleotides or in the padding a window can reach are candidates like the others
+		// (the reference reads its vector<bool> out of range there; here and in the oracle those reads are defined as 'A') -- or, on a
+		// shard, into its halo: the nucleotides the single index has there.  The k-mers that start in the last k-1 nucleotides or
+		// behind the end where a window can still reach are candidates like the others
 		const uint64_t e = idx - junction_cand;
-		if (e >= (uint64_t)per + (1ull << v.b))
+		if (e >= (uint64_t)per + (1ull << v.b) || v.total_nt < per)
 			return;
 		a = v.total_nt - per + e;
 	}
@@ -1353,7 +1378,16 @@ struct Chopped {
 struct ShardCtx {
 	uint64_t id_base = 0, global_N = 0, global_nsk = 0;
 	uint32_t glo = 0, ghi = 0;
+	// halo: the first halo_nt nucleotides the SINGLE index holds behind this shard's last bucket (the head of the next owners' buckets),
+	// 2-bit packed in device memory; written behind the shard's own sequence so that windows that run past its last bucket read what
+	// the reference reads there (blight.cpp:729-739 scans on into the next bucket).  nullptr = none (last rank, or shard_halo_set later)
+	const uint64_t* d_halo = nullptr;
+	uint64_t halo_nt = 0;
+	bool halo_later = false;  // construction from slices: the next owners' heads only exist once every rank has finished (shard_halo_set)
 };
+
+// nucleotides of halo a shard keeps: a window starts at most k nucleotides before the end of a bucket and covers 2^b positions + k - 1
+inline uint64_t halo_length(const Index& ix) { return (1ull << ix.prm.bits_saved) + (uint64_t)ix.prm.k; }
 
 template <int KW>
 void chop_input(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, Chopped& out, PhaseMarks& mark)
@@ -1502,22 +1536,24 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	const uint32_t world = ix.shard_world, rank = ix.shard_rank;
 	ix.shard_bounds.assign((size_t)world + 1, 0);
 	ix.shard_bounds[world] = ngroups;
+	DevBuf d_halo;  // lives until build_tail has copied it behind the shard's sequence
 	if (world > 1) {
 		const std::vector<uint64_t> pre = derive_shard_bounds(ix, group_histogram(ix, chopped));
 		shard.global_N = pre[ngroups];
 		const uint32_t glo = shard.glo = ix.shard_bounds[rank];
 		const uint32_t ghi = shard.ghi = ix.shard_bounds[rank + 1];
 		shard.id_base = pre[glo];
-		DevBuf d_flags, d_cnt, d_pos2, d_last2, d_mini2;
+		// the super-k-mers of the groups [g0, g1), in input order
+		DevBuf d_flags, d_cnt;
 		BLMX_HIP(d_flags.alloc(nsk + 1, false, s));
 		BLMX_HIP(d_cnt.alloc(8, true, s));
-		BLMX_HIP(d_pos2.alloc((nsk + 1) * 8, false, s));
-		BLMX_HIP(d_last2.alloc((nsk + 1) * 8, false, s));
-		BLMX_HIP(d_mini2.alloc((nsk + 1) * 4, false, s));
-		uint64_t kept = 0;
-		if (nsk) {
-			hipLaunchKernelGGL(k_shard_flags, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_skmini.as<uint32_t>(), nsk, gshift, glo, ghi,
-			                   d_flags.as<uint8_t>());
+		auto select_groups = [&](uint32_t g0, uint32_t g1, DevBuf& d_pos2, DevBuf& d_last2, DevBuf& d_mini2) -> uint64_t {
+			BLMX_HIP(d_pos2.alloc((nsk + 1) * 8, false, s));
+			BLMX_HIP(d_last2.alloc((nsk + 1) * 8, false, s));
+			BLMX_HIP(d_mini2.alloc((nsk + 1) * 4, false, s));
+			if (!nsk)
+				return 0;
+			hipLaunchKernelGGL(k_shard_flags, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_skmini.as<uint32_t>(), nsk, gshift, g0, g1, d_flags.as<uint8_t>());
 			BLMX_HIP(hipGetLastError());
 			size_t bytes = 0;
 			BLMX_HIP(rocprim::select(nullptr, bytes, d_skpos.as<uint64_t>(), d_flags.as<uint8_t>(), d_pos2.as<uint64_t>(), d_cnt.as<uint64_t>(),
@@ -1533,14 +1569,55 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			tmp = sc.get(std::max(bytes, bytes32));
 			BLMX_HIP(rocprim::select(tmp, bytes32, d_skmini.as<uint32_t>(), d_flags.as<uint8_t>(), d_mini2.as<uint32_t>(), d_cnt.as<uint64_t>(),
 			                         (size_t)nsk, s));
-			kept = read_scalar(d_cnt.as<uint64_t>(), s);
+			return read_scalar(d_cnt.as<uint64_t>(), s);
+		};
+		// ---- halo: the head of what follows this shard in the single index = the first buckets of the groups behind ghi, laid out like
+		// build_tail lays out its own (stable minimizer sort, back to back).  The groups [ghi, gh2) with gh2 = the first boundary
+		// behind which at least halo_length keys (hence nucleotides) have been seen hold all of it.
+		const uint64_t H = halo_length(ix);
+		uint32_t gh2 = ghi;
+		while (gh2 < ngroups && pre[gh2] - pre[ghi] < H)
+			gh2++;
+		if (gh2 > ghi && pre[gh2] > pre[ghi]) {
+			DevBuf d_hpos, d_hlast, d_hmini, d_hsmini, d_horder, d_hlennt, d_hlenk, d_hstart;
+			const uint64_t hn = select_groups(ghi, gh2, d_hpos, d_hlast, d_hmini);
+			BLMX_HIP(d_halo.alloc(((H + 31) / 32 + 2) * 8, true, s));
+			BLMX_HIP(d_hsmini.alloc((hn + 1) * 4, false, s));
+			BLMX_HIP(d_horder.alloc((hn + 1) * 4, false, s));
+			BLMX_HIP(d_hlennt.alloc((hn + 1) * 8, false, s));
+			BLMX_HIP(d_hlenk.alloc((hn + 1) * 8, false, s));
+			BLMX_HIP(d_hstart.alloc((hn + 1) * 8, false, s));
+			if (hn) {
+				size_t bytes = 0;
+				rocprim::counting_iterator<uint32_t> iota(0);
+				BLMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_hmini.as<uint32_t>(), d_hsmini.as<uint32_t>(), iota, d_horder.as<uint32_t>(), (size_t)hn, 0u,
+				                                   (unsigned)(2 * ix.prm.m - 1), s));
+				void* tmp = sc.get(bytes);
+				BLMX_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_hmini.as<uint32_t>(), d_hsmini.as<uint32_t>(), iota, d_horder.as<uint32_t>(), (size_t)hn, 0u,
+				                                   (unsigned)(2 * ix.prm.m - 1), s));
+				hipLaunchKernelGGL(k_sorted_lengths, dim3(grid_for(hn + 1)), dim3(kBlock), 0, s, d_horder.as<uint32_t>(), d_hpos.as<uint64_t>(),
+				                   d_hlast.as<uint64_t>(), hn, (int)ix.prm.k, d_hlennt.as<uint64_t>(), d_hlenk.as<uint64_t>());
+				BLMX_HIP(hipGetLastError());
+				exclusive_scan_u64(sc, d_hlennt.as<uint64_t>(), d_hstart.as<uint64_t>(), hn + 1, s);
+				shard.halo_nt = std::min<uint64_t>(H, read_scalar(d_hstart.as<uint64_t>() + hn, s));
+				hipLaunchKernelGGL(k_scatter_pack, dim3(grid_for(hn)), dim3(kBlock), 0, s, chopped.src.as<uint64_t>(), d_horder.as<uint32_t>(), d_hpos.as<uint64_t>(),
+				                   d_hstart.as<uint64_t>(), (const uint64_t*)nullptr, hn, d_halo.as<unsigned long long>(), H);
+				BLMX_HIP(hipGetLastError());
+				BLMX_HIP(hipStreamSynchronize(s));  // the temporaries of this block go back to the pool
+				shard.d_halo = d_halo.as<uint64_t>();
+			}
 		}
+		DevBuf d_pos2, d_last2, d_mini2;
+		const uint64_t kept = select_groups(glo, ghi, d_pos2, d_last2, d_mini2);
 		std::swap(d_skpos.p, d_pos2.p);
 		std::swap(d_skpos.bytes, d_pos2.bytes);
+		std::swap(d_skpos.owner, d_pos2.owner);
 		std::swap(d_sklast.p, d_last2.p);
 		std::swap(d_sklast.bytes, d_last2.bytes);
+		std::swap(d_sklast.owner, d_last2.owner);
 		std::swap(d_skmini.p, d_mini2.p);
 		std::swap(d_skmini.bytes, d_mini2.bytes);
+		std::swap(d_skmini.owner, d_mini2.owner);
 		nsk = kept;
 	}
 
@@ -1715,7 +1792,16 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	BLMX_HIP(ix.seq.alloc(ix.seq_words * 8, true, s));
 	if (nsk)
 		hipLaunchKernelGGL(k_scatter_pack, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
-		                   d_skpos.as<uint64_t>(), d_ntstart.as<uint64_t>(), (const uint64_t*)nullptr, nsk, ix.seq.as<unsigned long long>());
+		                   d_skpos.as<uint64_t>(), d_ntstart.as<uint64_t>(), (const uint64_t*)nullptr, nsk, ix.seq.as<unsigned long long>(), ~0ull);
+
+	// a shard's halo behind its own sequence (inside the padding: halo_length <= 2^b + 63)
+	ix.halo_nt = 0;
+	ix.halo_done = !shard.halo_later;
+	if (shard.d_halo && shard.halo_nt) {
+		hipLaunchKernelGGL(k_put_halo, dim3(grid_for(shard.halo_nt / 32 + 2)), dim3(kBlock), 0, s, shard.d_halo, shard.halo_nt, total_nt,
+		                   ix.seq.as<unsigned long long>());
+		ix.halo_nt = shard.halo_nt;
+	}
 
 	mark("K5 scatter_pack");
 	// ---- K6: keys in (bucket, position) order
@@ -2068,7 +2154,8 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			if (ix.tune_filter_junctions) {
 				const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1) + (uint64_t)(k - 1) + (1ull << b), blocks = (cand + kBlock - 1) / kBlock;
 				const unsigned gx = (unsigned)std::min<uint64_t>(blocks, 1u << 22), gy = (unsigned)((blocks + gx - 1) / gx);
-				hipLaunchKernelGGL((k_filter_junctions<KW>), dim3(gx, gy), dim3(kBlock), 0, ix.bg_stream, v, ix.filter_pending[0].as<uint64_t>(), nsk, d_filter);
+				hipLaunchKernelGGL((k_filter_junctions<KW>), dim3(gx, gy), dim3(kBlock), 0, ix.bg_stream, v, ix.filter_pending[0].as<uint64_t>(),
+				                   (nsk - 1) * (uint64_t)(k - 1), d_filter);
 			}
 			BLMX_HIP(hipGetLastError());
 			BLMX_HIP(hipEventRecord(ix.filter_ready, ix.bg_stream));
@@ -2171,8 +2258,11 @@ void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs
 		shard_begin_impl<2>(ix, d_ascii, d_offs, nseq, total_len, hist_out);
 }
 
-void shard_build_plan(Index& ix, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta, const void** d_words)
+void shard_build_plan(Index& ix, const uint64_t* global_hist, uint32_t world_of_caller, uint64_t* send_sk, uint64_t* send_words, const void** d_meta,
+                      const void** d_words)
 {
+	if (world_of_caller != ix.shard_world)  // send_sk / send_words hold one entry per rank of the index's world
+		throw StatusError{BLMX_EINVAL, "blmx_shard_build_plan: world differs from the one given to blmx_set_shard"};
 	ShardExchange* x = ix.xb;
 	if (!x || x->phase != 1)
 		throw StatusError{BLMX_ESTATE, "blmx_shard_build_plan needs a blmx_shard_build_begin first"};
@@ -2240,7 +2330,7 @@ void shard_build_plan(Index& ix, const uint64_t* global_hist, uint64_t* send_sk,
 	if (nsk) {
 		hipLaunchKernelGGL(k_segment_offsets, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_ntscan.as<uint64_t>(), nsk, t, d_nt2.as<uint64_t>());
 		hipLaunchKernelGGL(k_scatter_pack, dim3(grid_for(nsk)), dim3(kBlock), 0, s, c.src.as<uint64_t>(), d_order.as<uint32_t>(), c.skpos.as<uint64_t>(),
-		                   d_nt2.as<uint64_t>(), d_lennt.as<uint64_t>(), nsk, x->out_words.as<unsigned long long>());
+		                   d_nt2.as<uint64_t>(), d_lennt.as<uint64_t>(), nsk, x->out_words.as<unsigned long long>(), ~0ull);
 		hipLaunchKernelGGL(k_sk_meta, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_order.as<uint32_t>(), c.skmini.as<uint32_t>(), d_lennt.as<uint64_t>(), nsk,
 		                   x->out_meta.as<uint64_t>());
 		BLMX_HIP(hipGetLastError());
@@ -2308,6 +2398,7 @@ void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in
 	x->out_words.release();
 	x->out_meta.release();
 	mark("exchange: assemble");
+	x->shard.halo_later = world > 1 && ix.shard_rank + 1 < world;
 	if (ix.KW == 1)
 		build_tail<1>(ix, c, x->shard, mark, x->t_begin);
 	else
@@ -2315,8 +2406,79 @@ void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in
 	mark("counters + query heads");
 }
 
-namespace {
-}  // namespace
+// ---- the halo of a shard built from slices ---------------------------------------------------------------------------------------
+// The reference's 2^b scan does not stop at the end of a bucket (blight.cpp:729-739): a window that starts in the last bucket of a
+// shard reads on into what the SINGLE index holds next -- the first buckets of the next owner.  After every rank has finished its
+// shard, each publishes the head of its packed sequence (shard_halo_get: [valid nucleotides, <= halo_length | packed words]), the
+// records of all ranks are gathered, and shard_halo_set copies the heads of the following ranks behind the shard's own sequence
+// (zero padding -- 'A', like the single index behind ITS end -- where nothing follows) and gives the absent-key filter the k-mers a
+// window can now read across that junction.  The whole-input build (blmx_set_shard + blmx_build_from_*) computes its halo itself.
+uint64_t shard_halo_words(const Index& ix) { return 1 + (halo_length(ix) + 31) / 32; }
+
+void shard_halo_get(Index& ix, uint64_t* rec)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	const uint64_t H = halo_length(ix), nw = (H + 31) / 32;
+	const uint64_t n = std::min<uint64_t>(ix.st.total_nt, H);
+	std::fill(rec, rec + 1 + nw, 0ull);
+	rec[0] = n;
+	const uint64_t have = (n + 31) / 32;
+	if (have) {
+		BLMX_HIP(hipMemcpyAsync(rec + 1, ix.seq.p, have * 8, hipMemcpyDeviceToHost, ix.stream));
+		BLMX_HIP(hipStreamSynchronize(ix.stream));
+		if (n & 31)  // behind the shard's own nucleotides sits its halo (or padding): not part of the head
+			rec[have] &= ~0ull << (64 - 2 * (n & 31));
+	}
+}
+
+void shard_halo_set(Index& ix, const uint64_t* recs, uint32_t world)
+{
+	if (!ix.built)
+		throw StatusError{BLMX_ESTATE, "index not built"};
+	if (world != ix.shard_world)
+		throw StatusError{BLMX_EINVAL, "halo records of another world size"};
+	if (ix.halo_done)  // the last rank, a whole-input build, or a second call
+		return;
+	const uint64_t H = halo_length(ix), rw = shard_halo_words(ix);
+	std::vector<uint64_t> halo((H + 31) / 32 + 2, 0);
+	uint64_t pos = 0;
+	for (uint32_t r = ix.shard_rank + 1; r < world && pos < H; r++) {
+		const uint64_t* rec = recs + (size_t)r * rw;
+		if (rec[0] > H)
+			throw StatusError{BLMX_EINVAL, "halo record longer than the halo"};
+		const uint64_t n = std::min<uint64_t>(rec[0], H - pos);
+		for (uint64_t i = 0; i < n; i++, pos++) {
+			const uint64_t c = (rec[1 + (i >> 5)] >> (62 - 2 * (i & 31))) & 3ull;
+			halo[pos >> 5] |= c << (62 - 2 * (pos & 31));
+		}
+	}
+	hipStream_t s = ix.stream;
+	ix.filter_wait();  // the filter's own passes are done: what follows only adds to it
+	if (pos) {
+		DevBuf d_halo;
+		BLMX_HIP(d_halo.alloc(halo.size() * 8, false, s));
+		BLMX_HIP(hipMemcpyAsync(d_halo.p, halo.data(), halo.size() * 8, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_put_halo, dim3(grid_for(pos / 32 + 2)), dim3(kBlock), 0, s, d_halo.as<uint64_t>(), pos, ix.st.total_nt,
+		                   ix.seq.as<unsigned long long>());
+		BLMX_HIP(hipGetLastError());
+		if (ix.filter_bpk && ix.st.local_number_kmer) {  // the end junction again, now with the halo behind it
+			DeviceIndexView v = ix.view();
+			v.filter = ix.filter.as<uint64_t>();
+			const uint64_t cand = (uint64_t)(ix.prm.k - 1) + (1ull << ix.prm.bits_saved);
+			if (ix.KW == 1)
+				hipLaunchKernelGGL((k_filter_junctions<1>), dim3(grid_for(cand)), dim3(kBlock), 0, s, v, (const uint64_t*)nullptr, (uint64_t)0,
+				                   ix.filter.as<unsigned long long>());
+			else
+				hipLaunchKernelGGL((k_filter_junctions<2>), dim3(grid_for(cand)), dim3(kBlock), 0, s, v, (const uint64_t*)nullptr, (uint64_t)0,
+				                   ix.filter.as<unsigned long long>());
+			BLMX_HIP(hipGetLastError());
+		}
+		BLMX_HIP(hipStreamSynchronize(s));
+	}
+	ix.halo_nt = pos;
+	ix.halo_done = true;
+}
 
 // `positions` as the reference lays it out (fields of nbits - hint bits at its own offsets) from the wider fields in HBM
 __global__ __launch_bounds__(256) void k_positions_reference_layout(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ ref_posstart,

@@ -17,9 +17,13 @@
 // single-GPU users of libblight_mi355x.so do not need it at all.
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
 #include <memory>
+#include <random>
 
 #include <rccl/rccl.h>
 
@@ -50,13 +54,24 @@ Rccl& rccl()
 {
 	static Rccl r = [] {
 		Rccl x;
-		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+		// BLIGHT_RCCL_LIB names the library to load (a test points it at a file that does not exist to see BLMX_ERCCL)
+		const char* forced = getenv("BLIGHT_RCCL_LIB");
+		std::vector<const char*> names;
+		if (forced && *forced)
+			names = {forced};
+		else
+			names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		std::string why;
+		for (const char* name : names) {
 			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
 			if (x.lib)
 				break;
+			const char* e = dlerror();  // ONE call: dlerror() clears the message it returns
+			if (why.empty())
+				why = e ? e : "not found";
 		}
 		if (!x.lib) {
-			x.err = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "not found");
+			x.err = std::string("cannot load ") + names[0] + ": " + why;
 			return x;
 		}
 #define BLMX_SYM(field, sym)                                                   \
@@ -96,27 +111,324 @@ void grow(DevBuf& b, size_t bytes, hipStream_t s)
 		BLMX_HIP(b.alloc(bytes + bytes / 8 + 256, false, s));
 }
 
+// ---- transports -----------------------------------------------------------------------------------------------------------------------
+// What the exchange needs from a communicator: grouped point-to-point flows of u64 words (the all-to-all-v) and two small
+// collectives, all enqueued on a HIP stream.  Two implementations: RCCL over xGMI (one process per GPU), and a loopback -- `world`
+// communicators inside ONE process, one caller thread each, all on the same GPU -- which moves the flows with device copies under
+// the same grouping and stream-ordering rules.  The loopback exists so that the multi-rank choreography (count transposition, piece
+// pipeline, multi-round flows, failure votes) runs on a one-GPU box; it is not a performance path.
+struct Transport {
+	virtual ~Transport() {}
+	virtual const char* name() const = 0;
+	virtual void group_start() = 0;
+	virtual void group_end() = 0;
+	virtual void send(const uint64_t* p, uint64_t n, uint32_t peer, hipStream_t s) = 0;
+	virtual void recv(uint64_t* p, uint64_t n, uint32_t peer, hipStream_t s) = 0;
+	virtual void all_gather(const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t s) = 0;  // out = world x n words, rank order
+	virtual void all_reduce_sum(uint64_t* inout, uint64_t n, hipStream_t s) = 0;
+};
+
+struct RcclTransport final : Transport {
+	ncclComm_t comm = nullptr;
+	RcclTransport(const void* id_bytes, uint32_t rank, uint32_t world)
+	{
+		ncclUniqueId id;
+		memcpy(&id, id_bytes, sizeof id);
+		BLMX_NCCL(rccl().CommInitRank(&comm, (int)world, id, (int)rank));
+	}
+	~RcclTransport() override
+	{
+		if (comm)
+			(void)rccl().CommDestroy(comm);
+	}
+	const char* name() const override { return "rccl"; }
+	void group_start() override { BLMX_NCCL(rccl().GroupStart()); }
+	void group_end() override { BLMX_NCCL(rccl().GroupEnd()); }
+	void send(const uint64_t* p, uint64_t n, uint32_t peer, hipStream_t s) override { BLMX_NCCL(rccl().Send(p, n, ncclUint64, (int)peer, comm, s)); }
+	void recv(uint64_t* p, uint64_t n, uint32_t peer, hipStream_t s) override { BLMX_NCCL(rccl().Recv(p, n, ncclUint64, (int)peer, comm, s)); }
+	void all_gather(const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t s) override { BLMX_NCCL(rccl().AllGather(in, out, n, ncclUint64, comm, s)); }
+	void all_reduce_sum(uint64_t* inout, uint64_t n, hipStream_t s) override
+	{
+		BLMX_NCCL(rccl().AllReduce(inout, inout, n, ncclUint64, ncclSum, comm, s));
+	}
+};
+
+// ---- loopback -------------------------------------------------------------------------------------------------------------------------
+constexpr char kLoopMagic[16] = {'B', 'L', 'M', 'X', '-', 'L', 'O', 'O', 'P', 'B', 'A', 'C', 'K', '-', '1', 0};
+
+__global__ void k_sum_rows(const uint64_t* __restrict__ rows, uint32_t nrows, uint64_t n, uint64_t* __restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	uint64_t a = 0;
+	for (uint32_t r = 0; r < nrows; r++)
+		a += rows[(uint64_t)r * n + i];
+	out[i] = a;
+}
+
+// Meeting point of the `world` communicators of one loopback id.  A flow is posted by its sender (source pointer + an event that
+// says "the data is there") and pulled by its receiver with a device copy on the receiver's stream; the sender's stream then waits
+// for the copy before it may touch the buffer again -- the ordering RCCL gives a send / recv pair.  Flows of one (source,
+// destination) pair match in FIFO order.  Collectives meet in numbered slots.  Every wait has a deadline: a rank that never
+// arrives (it threw before its collective) turns into BLMX_ERCCL on the others instead of a hang.
+struct LoopHub {
+	uint32_t world = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	struct Flow {
+		const uint64_t* p;
+		uint64_t n;
+		hipEvent_t ready = nullptr, done = nullptr;
+		bool consumed = false;
+	};
+	std::deque<std::shared_ptr<Flow>> q[16][16];
+	struct Coll {
+		std::vector<const uint64_t*> in;
+		std::vector<hipEvent_t> ready, done;
+		uint64_t n = 0;
+		uint32_t posted = 0, finished = 0, left = 0;
+	};
+	std::map<uint64_t, Coll> colls;
+	double timeout_s = 120.0;
+
+	template <typename Pred> void wait(std::unique_lock<std::mutex>& l, Pred pred, const char* what)
+	{
+		if (!cv.wait_for(l, std::chrono::duration<double>(timeout_s), pred))
+			throw StatusError{BLMX_ERCCL, std::string("loopback transport: a peer did not arrive (") + what + ")"};
+	}
+};
+
+std::mutex g_hub_mu;
+std::map<std::string, std::weak_ptr<LoopHub>> g_hubs;
+
+std::shared_ptr<LoopHub> loop_hub(const void* id_bytes, uint32_t world)
+{
+	const std::string key(reinterpret_cast<const char*>(id_bytes), BLMX_COMM_ID_BYTES);
+	std::lock_guard<std::mutex> l(g_hub_mu);
+	std::shared_ptr<LoopHub> h = g_hubs[key].lock();
+	if (!h) {
+		h = std::make_shared<LoopHub>();
+		h->world = world;
+		if (const char* e = getenv("BLIGHT_LOOPBACK_TIMEOUT"))
+			h->timeout_s = atof(e) > 0 ? atof(e) : h->timeout_s;
+		g_hubs[key] = h;
+	}
+	if (h->world != world)
+		throw StatusError{BLMX_EINVAL, "loopback communicators of one id must agree on the world size"};
+	return h;
+}
+
+struct LoopbackTransport final : Transport {
+	std::shared_ptr<LoopHub> hub;
+	uint32_t me, world;
+	uint64_t coll_seq = 0;
+	bool in_group = false;
+	struct Op {
+		bool is_send;
+		uint64_t* p;
+		uint64_t n;
+		uint32_t peer;
+		hipStream_t s;
+	};
+	std::vector<Op> ops;
+	std::vector<hipEvent_t> retired;  // events whose last use has been enqueued; destroyed once they have completed
+	DevBuf tmp;
+
+	LoopbackTransport(const void* id_bytes, uint32_t rank, uint32_t w) : hub(loop_hub(id_bytes, w)), me(rank), world(w) {}
+	~LoopbackTransport() override
+	{
+		for (hipEvent_t e : retired)
+			(void)hipEventDestroy(e);
+	}
+	const char* name() const override { return "loopback"; }
+
+	hipEvent_t new_event()
+	{
+		hipEvent_t e;
+		BLMX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		return e;
+	}
+	void sweep()
+	{
+		size_t keep = 0;
+		for (hipEvent_t e : retired) {
+			if (hipEventQuery(e) == hipSuccess)
+				(void)hipEventDestroy(e);
+			else
+				retired[keep++] = e;
+		}
+		retired.resize(keep);
+	}
+
+	void group_start() override
+	{
+		in_group = true;
+		ops.clear();
+	}
+	void send(const uint64_t* p, uint64_t n, uint32_t peer, hipStream_t s) override
+	{
+		ops.push_back(Op{true, const_cast<uint64_t*>(p), n, peer, s});
+		if (!in_group)
+			flush();
+	}
+	void recv(uint64_t* p, uint64_t n, uint32_t peer, hipStream_t s) override
+	{
+		ops.push_back(Op{false, p, n, peer, s});
+		if (!in_group)
+			flush();
+	}
+	void group_end() override
+	{
+		in_group = false;
+		flush();
+	}
+	// all sends are posted before any receive waits for its peer: every rank does the same, so nobody waits for a post that is
+	// stuck behind a wait
+	void flush()
+	{
+		sweep();
+		std::vector<std::pair<std::shared_ptr<LoopHub::Flow>, hipStream_t>> mine;
+		for (const Op& o : ops) {
+			if (!o.is_send)
+				continue;
+			auto f = std::make_shared<LoopHub::Flow>();
+			f->p = o.p;
+			f->n = o.n;
+			f->ready = new_event();
+			BLMX_HIP(hipEventRecord(f->ready, o.s));
+			{
+				std::lock_guard<std::mutex> l(hub->mu);
+				hub->q[me][o.peer].push_back(f);
+			}
+			hub->cv.notify_all();
+			mine.emplace_back(f, o.s);
+		}
+		for (const Op& o : ops) {
+			if (o.is_send)
+				continue;
+			std::shared_ptr<LoopHub::Flow> f;
+			{
+				std::unique_lock<std::mutex> l(hub->mu);
+				hub->wait(l, [&] { return !hub->q[o.peer][me].empty(); }, "send of a flow");
+				f = hub->q[o.peer][me].front();
+				hub->q[o.peer][me].pop_front();
+			}
+			if (f->n != o.n)
+				throw StatusError{BLMX_ERCCL, "loopback transport: send and receive disagree on the length of a flow"};
+			BLMX_HIP(hipStreamWaitEvent(o.s, f->ready, 0));
+			if (o.n)
+				BLMX_HIP(hipMemcpyAsync(o.p, f->p, o.n * 8, hipMemcpyDeviceToDevice, o.s));
+			hipEvent_t done = new_event();
+			BLMX_HIP(hipEventRecord(done, o.s));
+			{
+				std::lock_guard<std::mutex> l(hub->mu);
+				f->done = done;
+				f->consumed = true;
+			}
+			hub->cv.notify_all();
+		}
+		for (auto& fs : mine) {
+			{
+				std::unique_lock<std::mutex> l(hub->mu);
+				hub->wait(l, [&] { return fs.first->consumed; }, "receive of a flow");
+			}
+			BLMX_HIP(hipStreamWaitEvent(fs.second, fs.first->done, 0));
+			retired.push_back(fs.first->ready);
+			retired.push_back(fs.first->done);
+		}
+		ops.clear();
+	}
+
+	void all_gather(const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t s) override
+	{
+		sweep();
+		const uint64_t seq = coll_seq++;
+		hipEvent_t ready = new_event();
+		BLMX_HIP(hipEventRecord(ready, s));
+		std::vector<const uint64_t*> src;
+		std::vector<hipEvent_t> evs;
+		{
+			std::unique_lock<std::mutex> l(hub->mu);
+			LoopHub::Coll& c = hub->colls[seq];
+			if (c.in.empty()) {
+				c.in.assign(world, nullptr);
+				c.ready.assign(world, nullptr);
+				c.done.assign(world, nullptr);
+				c.n = n;
+			}
+			if (c.n != n)
+				throw StatusError{BLMX_ERCCL, "loopback transport: ranks disagree on the size of a collective"};
+			c.in[me] = in;
+			c.ready[me] = ready;
+			c.posted++;
+			hub->cv.notify_all();
+			hub->wait(l, [&] { return hub->colls[seq].posted == world; }, "collective");
+			src = hub->colls[seq].in;
+			evs = hub->colls[seq].ready;
+		}
+		for (uint32_t r = 0; r < world; r++) {
+			BLMX_HIP(hipStreamWaitEvent(s, evs[r], 0));
+			if (n)
+				BLMX_HIP(hipMemcpyAsync(out + (uint64_t)r * n, src[r], n * 8, hipMemcpyDeviceToDevice, s));
+		}
+		hipEvent_t done = new_event();
+		BLMX_HIP(hipEventRecord(done, s));
+		{
+			std::unique_lock<std::mutex> l(hub->mu);
+			LoopHub::Coll& c = hub->colls[seq];
+			c.done[me] = done;
+			c.finished++;
+			hub->cv.notify_all();
+			hub->wait(l, [&] { return hub->colls[seq].finished == world; }, "end of a collective");
+			evs = hub->colls[seq].done;
+			if (++hub->colls[seq].left == world)
+				hub->colls.erase(seq);
+		}
+		for (uint32_t r = 0; r < world; r++)  // nobody overwrites its contribution before everybody has copied it
+			BLMX_HIP(hipStreamWaitEvent(s, evs[r], 0));
+		retired.push_back(ready);
+		retired.push_back(done);
+	}
+
+	void all_reduce_sum(uint64_t* inout, uint64_t n, hipStream_t s) override
+	{
+		if ((size_t)world * n * 8 + 16 > tmp.bytes) {
+			BLMX_HIP(hipStreamSynchronize(s));
+			BLMX_HIP(tmp.alloc((size_t)world * n * 8 + 16, false, s));
+		}
+		all_gather(inout, tmp.as<uint64_t>(), n, s);
+		if (n)
+			hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tmp.as<uint64_t>(), world, n, inout);
+		BLMX_HIP(hipGetLastError());
+	}
+};
+
 }  // namespace
 
 struct Comm {
-	ncclComm_t comm = nullptr;
+	std::unique_ptr<Transport> tp;
 	uint32_t rank = 0, world = 1;
 	int device = 0;
+	// A pairwise flow larger than flow_words u64 words is cut into rounds (both ends of a flow know its length, so they cut it alike;
+	// ranks whose flows are shorter simply take part in fewer rounds).  See kFlowWords.
+	uint64_t flow_words;
+	int pieces = 0;            // pieces of a query batch (software pipeline); 0 = BLIGHT_DIST_CHUNKS or 2.  The same on every rank.
 	hipStream_t cs = nullptr;  // the exchange runs on this stream, next to the caller's compute stream
 	hipEvent_t ev_part[kMaxPieces] = {}, ev_k[kMaxPieces] = {}, ev_q[kMaxPieces] = {}, ev_i[kMaxPieces] = {};
 	DevBuf sorted[kMaxPieces], inv[kMaxPieces], recv_k[kMaxPieces], ids_remote[kMaxPieces], ids_sorted[kMaxPieces];
-	DevBuf counts, all_counts;
+	DevBuf counts, all_counts, small;
 	Pinned h_counts;
 	std::mutex mu;
 	~Comm()
 	{
 		(void)hipSetDevice(device);
+		(void)hipDeviceSynchronize();
 		for (auto* arr : {ev_part, ev_k, ev_q, ev_i})
 			for (int i = 0; i < kMaxPieces; i++)
 				if (arr[i])
 					(void)hipEventDestroy(arr[i]);
-		if (comm)
-			(void)rccl().CommDestroy(comm);
+		tp.reset();
 		if (cs)
 			(void)hipStreamDestroy(cs);
 	}
@@ -130,6 +442,26 @@ void comm_unique_id(void* id_out)
 	memcpy(id_out, &id, sizeof id);
 }
 
+void comm_loopback_id(void* id_out)
+{
+	char* o = reinterpret_cast<char*>(id_out);
+	memset(o, 0, BLMX_COMM_ID_BYTES);
+	memcpy(o, kLoopMagic, sizeof kLoopMagic);
+	std::random_device rd;
+	static std::atomic<uint64_t> serial{0};
+	const uint64_t a = ((uint64_t)rd() << 32) ^ rd(), b = serial.fetch_add(1) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+	memcpy(o + 16, &a, 8);
+	memcpy(o + 24, &b, 8);
+}
+
+// All-to-all-v flows are cut into rounds of at most 256 MiB.  History: in round 2 the C4-size world-1 rehearsal of the construction
+// from slices sent its two flows (1.9 GB of meta words, 2.4 GB of packed nucleotides, self flow on RCCL 2.26) as ONE ncclSend /
+// ncclRecv pair each and the shard differed from the whole-input build; with 1 GB it did not.  tools/rccl_flow_probe.cpp repeats that
+// flow on its own (pattern in, compare out, by size) -- see DESIGN.md section 6 for what it found.  Whatever the cause, nothing here
+// depends on one huge message: 256-MiB rounds keep every message far below 2^31 bytes, and blmx_comm_set_tuning("flow_words")
+// shrinks the rounds so that the tests walk through the multi-round branch with ragged last rounds.
+constexpr uint64_t kFlowWords = 1ull << 25;
+
 Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int device)
 {
 	if (world == 0 || world > 16 || rank >= world)
@@ -139,9 +471,11 @@ Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int devic
 	c->rank = rank;
 	c->world = world;
 	c->device = device;
-	ncclUniqueId id;
-	memcpy(&id, id_bytes, sizeof id);
-	BLMX_NCCL(rccl().CommInitRank(&c->comm, (int)world, id, (int)rank));
+	c->flow_words = kFlowWords;
+	if (memcmp(id_bytes, kLoopMagic, sizeof kLoopMagic) == 0)
+		c->tp.reset(new LoopbackTransport(id_bytes, rank, world));
+	else
+		c->tp.reset(new RcclTransport(id_bytes, rank, world));
 	BLMX_HIP(hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking));
 	for (auto* arr : {c->ev_part, c->ev_k, c->ev_q, c->ev_i})
 		for (int i = 0; i < kMaxPieces; i++)
@@ -151,78 +485,144 @@ Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int devic
 
 void comm_destroy(Comm* c) { delete c; }
 
-// all-to-all-v as grouped point-to-point transfers; counts in elements of `words` uint64 each.  A pairwise flow larger than
-// kFlowWords is cut into rounds (both ends of a flow know its length, so they cut it alike; ranks whose flows are shorter simply
-// take part in fewer rounds): one 1.7-GB ncclSend/ncclRecv pair delivered wrong data here (RCCL 2.26/2.27, self flow), 1 GB was fine.
-constexpr uint64_t kFlowWords = 1ull << 25;  // 256 MiB
+const char* comm_transport(const Comm* c) { return c->tp->name(); }
 
+void comm_set_tuning(Comm& c, const char* key, int64_t value)
+{
+	const std::string k(key);
+	if (k == "flow_words") {
+		if (value < 1)
+			throw StatusError{BLMX_EINVAL, "flow_words must be positive"};
+		c.flow_words = (uint64_t)value;
+	} else if (k == "pieces") {
+		c.pieces = value < 0 ? 0 : (value > kMaxPieces ? kMaxPieces : (int)value);
+	} else {
+		throw StatusError{BLMX_EINVAL, "unknown communicator tuning key"};
+	}
+}
+
+// all-to-all-v as grouped point-to-point transfers; counts in elements of `words` uint64 each
 static void all_to_all_v(Comm& c, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t words, hipStream_t s)
 {
-	Rccl& R = rccl();
+	Transport& T = *c.tp;
+	const uint64_t fw = c.flow_words;
 	uint64_t so[17], ro[17], rounds = 0;
 	so[0] = ro[0] = 0;
 	for (uint32_t r = 0; r < c.world; r++) {
 		so[r + 1] = so[r] + send_cnt[r] * words;
 		ro[r + 1] = ro[r] + recv_cnt[r] * words;
-		rounds = std::max(rounds, (std::max(send_cnt[r], recv_cnt[r]) * words + kFlowWords - 1) / kFlowWords);
+		rounds = std::max(rounds, (std::max(send_cnt[r], recv_cnt[r]) * words + fw - 1) / fw);
 	}
 	for (uint64_t j = 0; j < rounds; j++) {
-		const uint64_t off = j * kFlowWords;
-		BLMX_NCCL(R.GroupStart());
+		const uint64_t off = j * fw;
+		T.group_start();
 		for (uint32_t r = 0; r < c.world; r++) {
 			const uint64_t sn = send_cnt[r] * words, rn = recv_cnt[r] * words;
 			if (off < sn)
-				BLMX_NCCL(R.Send((const uint64_t*)send + so[r] + off, std::min(kFlowWords, sn - off), ncclUint64, (int)r, c.comm, s));
+				T.send((const uint64_t*)send + so[r] + off, std::min(fw, sn - off), r, s);
 			if (off < rn)
-				BLMX_NCCL(R.Recv((uint64_t*)recv + ro[r] + off, std::min(kFlowWords, rn - off), ncclUint64, (int)r, c.comm, s));
+				T.recv((uint64_t*)recv + ro[r] + off, std::min(fw, rn - off), r, s);
 		}
-		BLMX_NCCL(R.GroupEnd());
+		T.group_end();
 	}
 }
 
+// a few host words summed / gathered over the ranks (failure votes, counts, halo records): staged through a small device buffer
+static void all_reduce_host(Comm& c, uint64_t* v, size_t n, hipStream_t s)
+{
+	grow(c.small, n * 8 + 16, s);
+	BLMX_HIP(hipMemcpyAsync(c.small.p, v, n * 8, hipMemcpyHostToDevice, s));
+	c.tp->all_reduce_sum(c.small.as<uint64_t>(), n, s);
+	BLMX_HIP(hipMemcpyAsync(v, c.small.p, n * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+}
+static void all_gather_host(Comm& c, const uint64_t* mine, size_t n, uint64_t* all, hipStream_t s)
+{
+	grow(c.small, (size_t)(c.world + 1) * n * 8 + 16, s);
+	uint64_t* d_mine = c.small.as<uint64_t>();
+	uint64_t* d_all = d_mine + n;
+	BLMX_HIP(hipMemcpyAsync(d_mine, mine, n * 8, hipMemcpyHostToDevice, s));
+	c.tp->all_gather(d_mine, d_all, n, s);
+	BLMX_HIP(hipMemcpyAsync(all, d_all, (size_t)c.world * n * 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+}
+
+// what must hold before a rank may join a collective on (ix, c): returned, not thrown, so that the caller can still take part and
+// fail together with the others instead of leaving them waiting
+static StatusError precondition(const Index& ix, const Comm& c, bool want_built)
+{
+	if (want_built && !ix.built)
+		return StatusError{BLMX_ESTATE, "index not built"};
+	if (!want_built && ix.built)
+		return StatusError{BLMX_ESTATE, "index already built"};
+	if (ix.shard_world != c.world || ix.shard_rank != c.rank)
+		return StatusError{BLMX_EINVAL, "the index was sharded for another rank / world than this communicator"};
+	if ((int)ix.prm.device != c.device)
+		return StatusError{BLMX_EINVAL, "index and communicator live on different devices"};
+	return StatusError{BLMX_OK, ""};
+}
+
 // IDs of nq canonical k-mers in HBM, every k-mer answered by the rank that owns its MPHF group; collective: every rank of the
-// communicator calls it (with its own batch, possibly empty) in the same order.
+// communicator calls it (with its own batch, possibly empty) in the same order.  A rank that cannot take part (index not built,
+// sharded for another world) still joins the count exchange with a flag, and all ranks fail together.
 void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s)
 {
-	if (!ix.built)
-		throw StatusError{BLMX_ESTATE, "index not built"};
-	if (ix.shard_world != c.world || ix.shard_rank != c.rank)
-		throw StatusError{BLMX_EINVAL, "the index was sharded for another rank / world than this communicator"};
-	if ((int)ix.prm.device != c.device)
-		throw StatusError{BLMX_EINVAL, "index and communicator live on different devices"};
 	std::lock_guard<std::mutex> lock(c.mu);
 	BLMX_HIP(hipSetDevice(c.device));
-	Rccl& R = rccl();
+	StatusError local = precondition(ix, c, true);
+	if (local.code == BLMX_OK && nq >= 0xffffffffull)
+		local = StatusError{BLMX_ELIMIT, "a partitioned batch holds fewer than 2^32 - 1 k-mers"};
 	const uint32_t world = c.world, me = c.rank;
 	const char* e = getenv("BLIGHT_DIST_CHUNKS");
-	int pieces = e ? atoi(e) : 2;  // must be the same on every rank
+	int pieces = c.pieces ? c.pieces : (e ? atoi(e) : 2);  // must be the same on every rank
 	pieces = pieces < 1 ? 1 : (pieces > kMaxPieces ? kMaxPieces : pieces);
 	const size_t kw = (size_t)ix.KW;
 	uint64_t cut[kMaxPieces + 1];
 	for (int p = 0; p <= pieces; p++)
-		cut[p] = nq * (uint64_t)p / (uint64_t)pieces;
-	// ---- partition every piece; the per-owner counts of all pieces are exchanged in one all-gather
-	grow(c.counts, (size_t)pieces * world * 8, s);
-	grow(c.all_counts, (size_t)pieces * world * world * 8, s);
-	c.h_counts.ensure((size_t)pieces * world * world * 8);
-	for (int p = 0; p < pieces; p++) {
-		const uint64_t n = cut[p + 1] - cut[p];
-		grow(c.sorted[p], n * 8 * kw + 16, s);
-		grow(c.inv[p], n * 4 + 16, s);
-		launch_partition(ix, (const uint64_t*)d_kmers + cut[p] * kw, n, c.sorted[p].p, c.inv[p].as<uint32_t>(), c.counts.as<uint64_t>() + (size_t)p * world, s);
-		BLMX_HIP(hipEventRecord(c.ev_part[p], s));
+		cut[p] = local.code == BLMX_OK ? nq * (uint64_t)p / (uint64_t)pieces : 0;
+	// ---- partition every piece; the per-owner counts of all pieces (+ one "cannot take part" flag) are exchanged in one all-gather
+	const size_t per_rank = (size_t)pieces * world + 1;
+	grow(c.counts, per_rank * 8, s);
+	grow(c.all_counts, per_rank * world * 8, s);
+	c.h_counts.ensure(per_rank * world * 8);
+	BLMX_HIP(hipMemsetAsync(c.counts.p, 0, per_rank * 8, s));
+	if (local.code != BLMX_OK) {
+		const uint64_t one = 1;
+		BLMX_HIP(hipMemcpyAsync(c.counts.as<uint64_t>() + per_rank - 1, &one, 8, hipMemcpyHostToDevice, s));
+		BLMX_HIP(hipStreamSynchronize(s));  // `one` lives on this frame
+	} else {
+		for (int p = 0; p < pieces; p++) {
+			const uint64_t n = cut[p + 1] - cut[p];
+			grow(c.sorted[p], n * 8 * kw + 16, s);
+			grow(c.inv[p], n * 4 + 16, s);
+			launch_partition(ix, (const uint64_t*)d_kmers + cut[p] * kw, n, c.sorted[p].p, c.inv[p].as<uint32_t>(), c.counts.as<uint64_t>() + (size_t)p * world, s);
+			BLMX_HIP(hipEventRecord(c.ev_part[p], s));
+		}
 	}
-	BLMX_NCCL(R.AllGather(c.counts.p, c.all_counts.p, (size_t)pieces * world, ncclUint64, c.comm, s));
-	BLMX_HIP(hipMemcpyAsync(c.h_counts.p, c.all_counts.p, (size_t)pieces * world * world * 8, hipMemcpyDeviceToHost, s));
+	c.tp->all_gather(c.counts.as<uint64_t>(), c.all_counts.as<uint64_t>(), per_rank, s);
+	BLMX_HIP(hipMemcpyAsync(c.h_counts.p, c.all_counts.p, per_rank * world * 8, hipMemcpyDeviceToHost, s));
 	BLMX_HIP(hipStreamSynchronize(s));
-	const uint64_t* all = c.h_counts.as<uint64_t>();  // all[(r * pieces + p) * world + d] = k-mers rank r sends to rank d in piece p
+	const uint64_t* all = c.h_counts.as<uint64_t>();  // all[r * per_rank + p * world + d] = k-mers rank r sends to rank d in piece p
+	for (uint32_t r = 0; r < world; r++)
+		if (all[(size_t)r * per_rank + per_rank - 1]) {
+			if (local.code != BLMX_OK)
+				throw local;
+			throw StatusError{BLMX_ERCCL, "sharded query: another rank could not take part"};
+		}
 	uint64_t send_cnt[kMaxPieces][16], recv_cnt[kMaxPieces][16], recv_total[kMaxPieces];
 	for (int p = 0; p < pieces; p++) {
 		recv_total[p] = 0;
 		for (uint32_t r = 0; r < world; r++) {
-			send_cnt[p][r] = all[((size_t)me * pieces + p) * world + r];
-			recv_cnt[p][r] = all[((size_t)r * pieces + p) * world + me];
+			send_cnt[p][r] = all[(size_t)me * per_rank + (size_t)p * world + r];
+			recv_cnt[p][r] = all[(size_t)r * per_rank + (size_t)p * world + me];
 			recv_total[p] += recv_cnt[p][r];
+		}
+		for (uint32_t d = 0; d < world; d++) {  // every rank sees the same matrix: all of them give up together
+			uint64_t to_d = 0;
+			for (uint32_t r = 0; r < world; r++)
+				to_d += all[(size_t)r * per_rank + (size_t)p * world + d];
+			if (to_d >= 0xffffffffull)
+				throw StatusError{BLMX_ELIMIT, "an owner receives fewer than 2^32 - 1 k-mers per piece"};
 		}
 		grow(c.recv_k[p], recv_total[p] * 8 * kw + 16, s);
 		grow(c.ids_remote[p], recv_total[p] * 8 + 16, s);
@@ -256,18 +656,13 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, i
 // Sharded construction from slices: every rank passes ITS OWN consecutive piece of the input (rank order = input order).  Collective.
 // Steps: chop locally -> all-reduce of the per-group key histograms (every rank derives the same key-balanced boundaries) ->
 // all-gather of the per-destination counts -> all-to-all-v of the super-k-mers (meta words, then packed nucleotides) -> the owner
-// finishes its shard.  A rank whose input is invalid still takes part in every collective and all ranks fail together.
+// finishes its shard -> all-gather of the heads of the shards' sequences: every shard keeps, behind its own sequence, what the single
+// index holds there (shard_halo_set).  A rank whose input is invalid -- or whose index / communicator do not fit -- still takes
+// part in the first all-reduce with a failure flag, and all ranks fail together.
 void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, const StatusError* already_failed)
 {
-	if (ix.built)
-		throw StatusError{BLMX_ESTATE, "index already built"};
-	if (ix.shard_world != c.world || ix.shard_rank != c.rank)
-		throw StatusError{BLMX_EINVAL, "the index was sharded for another rank / world than this communicator"};
-	if ((int)ix.prm.device != c.device)
-		throw StatusError{BLMX_EINVAL, "index and communicator live on different devices"};
 	std::lock_guard<std::mutex> lock(c.mu);
 	BLMX_HIP(hipSetDevice(c.device));
-	Rccl& R = rccl();
 	hipStream_t s = ix.stream;
 	const uint32_t world = c.world, me = c.rank, ngroups = ix.ngroups;
 	const size_t nh = (size_t)ngroups + 2;  // histogram, super-k-mer count, failed ranks
@@ -282,23 +677,20 @@ void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d
 		t_last = now;
 	};
 	std::vector<uint64_t> hist(nh, 0);
-	StatusError local{BLMX_OK, ""};
-	try {
-		if (already_failed)  // e.g. this rank could not open its input: it still takes part, so that nobody waits for it
-			throw *already_failed;
-		shard_build_begin(ix, d_ascii, d_offs, nseq, total_len, hist.data());
-	} catch (const StatusError& e) {
-		local = e;
+	StatusError local = already_failed ? *already_failed : precondition(ix, c, false);  // e.g. this rank could not open its input: it still takes part
+	if (local.code == BLMX_OK) {
+		try {
+			shard_build_begin(ix, d_ascii, d_offs, nseq, total_len, hist.data());
+		} catch (const StatusError& e) {
+			local = e;
+		}
+	}
+	if (local.code != BLMX_OK) {
 		std::fill(hist.begin(), hist.end(), 0);
 		hist[nh - 1] = 1;
 	}
 	mark("exchange: chop slice");
-	DevBuf d_hist;
-	BLMX_HIP(d_hist.alloc(nh * 8, false, s));
-	BLMX_HIP(hipMemcpyAsync(d_hist.p, hist.data(), nh * 8, hipMemcpyHostToDevice, s));
-	BLMX_NCCL(R.AllReduce(d_hist.p, d_hist.p, nh, ncclUint64, ncclSum, c.comm, s));
-	BLMX_HIP(hipMemcpyAsync(hist.data(), d_hist.p, nh * 8, hipMemcpyDeviceToHost, s));
-	BLMX_HIP(hipStreamSynchronize(s));
+	all_reduce_host(c, hist.data(), nh, s);
 	if (hist[nh - 1]) {
 		shard_build_abort(ix);
 		if (local.code != BLMX_OK)
@@ -308,20 +700,14 @@ void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d
 	mark("exchange: all-reduce");
 	uint64_t send_sk[16], send_words[16], recv_sk[16], recv_words[16];
 	const void *d_meta = nullptr, *d_words = nullptr;
-	shard_build_plan(ix, hist.data(), send_sk, send_words, &d_meta, &d_words);
+	shard_build_plan(ix, hist.data(), world, send_sk, send_words, &d_meta, &d_words);
 	mark("exchange: pack outgoing");
 	std::vector<uint64_t> mine(2 * (size_t)world), all(2 * (size_t)world * world);
 	for (uint32_t r = 0; r < world; r++) {
 		mine[r] = send_sk[r];
 		mine[world + r] = send_words[r];
 	}
-	DevBuf d_mine, d_all;
-	BLMX_HIP(d_mine.alloc(mine.size() * 8, false, s));
-	BLMX_HIP(d_all.alloc(all.size() * 8, false, s));
-	BLMX_HIP(hipMemcpyAsync(d_mine.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, s));
-	BLMX_NCCL(R.AllGather(d_mine.p, d_all.p, mine.size(), ncclUint64, c.comm, s));
-	BLMX_HIP(hipMemcpyAsync(all.data(), d_all.p, all.size() * 8, hipMemcpyDeviceToHost, s));
-	BLMX_HIP(hipStreamSynchronize(s));
+	all_gather_host(c, mine.data(), mine.size(), all.data(), s);
 	uint64_t in_sk = 0, in_words = 0;
 	for (uint32_t r = 0; r < world; r++) {
 		recv_sk[r] = all[(size_t)r * 2 * world + me];
@@ -336,25 +722,52 @@ void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d
 	all_to_all_v(c, d_words, send_words, d_in_words.p, recv_words, 1, s);
 	BLMX_HIP(hipStreamSynchronize(s));
 	mark("exchange: all-to-all-v");
-	shard_build_finish(ix, d_in_meta.p, d_in_words.p, recv_sk, recv_words);
-	ix.built = true;
+	// From here on a local failure (out of memory in the owner's build) cannot be hidden from the others: the halo all-gather below
+	// carries a failure word, so nobody waits for a rank that has given up.
+	StatusError tail{BLMX_OK, ""};
+	try {
+		shard_build_finish(ix, d_in_meta.p, d_in_words.p, recv_sk, recv_words);
+		ix.built = true;
+	} catch (const StatusError& e2) {
+		tail = e2;
+	}
+	const uint64_t rw = shard_halo_words(ix);
+	std::vector<uint64_t> rec(rw + 1, 0), recs((size_t)world * (rw + 1), 0);
+	if (tail.code == BLMX_OK)
+		shard_halo_get(ix, rec.data());
+	rec[rw] = tail.code != BLMX_OK;
+	all_gather_host(c, rec.data(), rw + 1, recs.data(), s);
+	bool any_failed = false;
+	std::vector<uint64_t> packed((size_t)world * rw);
+	for (uint32_t r = 0; r < world; r++) {
+		any_failed |= recs[(size_t)r * (rw + 1) + rw] != 0;
+		memcpy(&packed[(size_t)r * rw], &recs[(size_t)r * (rw + 1)], rw * 8);
+	}
+	if (tail.code != BLMX_OK)
+		throw tail;
+	if (any_failed) {
+		ix.built = false;
+		throw StatusError{BLMX_ERCCL, "sharded build: another rank could not finish its shard"};
+	}
+	shard_halo_set(ix, packed.data(), world);
+	mark("exchange: halo");
 }
 
 // every rank reads the file (the reader's pair rule needs the lines from the start) and keeps the rank-th consecutive part of its
 // sequences: rank r of w takes sequences [nseq * r / w, nseq * (r + 1) / w)
 void build_sharded_from_fasta(Index& ix, Comm& c, const char* path)
 {
-	if (ix.built)
-		throw StatusError{BLMX_ESTATE, "index already built"};
 	BLMX_HIP(hipSetDevice(c.device));
 	DevBuf d_ascii, d_offs;
 	std::vector<uint64_t> offs(1, 0);
 	uint64_t total = 0;
-	StatusError local{BLMX_OK, ""};
-	try {
-		load_fasta_to_device(ix, path, d_ascii, offs, total);
-	} catch (const StatusError& e) {
-		local = e;
+	StatusError local = precondition(ix, c, false);
+	if (local.code == BLMX_OK) {
+		try {
+			load_fasta_to_device(ix, path, d_ascii, offs, total);
+		} catch (const StatusError& e) {
+			local = e;
+		}
 	}
 	if (local.code != BLMX_OK) {
 		build_sharded(ix, c, nullptr, nullptr, 0, 0, &local);  // throws `local` after the all-reduce

@@ -557,11 +557,13 @@ void query_sequences_device(Index& ix, const uint8_t* d_chars, const uint64_t* d
 void query_sequences_sharded_device(Index& ix, Comm& c, const uint8_t* d_chars, const uint64_t* d_offs, uint64_t nseq, uint64_t total, uint64_t nk,
                                     int64_t* d_ids, int* d_err, hipStream_t s)
 {
-	if (!ix.built)
-		throw StatusError{BLMX_ESTATE, "index not built"};
-	if (total >= 0xffffffc0ull)
-		throw StatusError{BLMX_ELIMIT, "a device-resident batch holds fewer than 2^32 characters"};
 	BLMX_HIP(hipSetDevice(ix.prm.device));
+	// a rank whose own batch cannot be taken still joins the collective (with no k-mers, or -- index not built -- with the failure
+	// flag of query_kmers_sharded), so that the others do not wait for it; it reports its error afterwards
+	if (!ix.built || total >= 0xffffffc0ull) {
+		query_kmers_sharded(ix, c, nullptr, 0, d_ids, s);
+		throw StatusError{BLMX_ELIMIT, "a device-resident batch holds fewer than 2^32 characters"};
+	}
 	HostFront& hf = host_front(ix);
 	std::lock_guard<std::mutex> lock(hf.dev_mu);
 	if (!hf.dev_done)
@@ -590,8 +592,10 @@ void query_sequences_sharded_host(Index& ix, Comm& c, const char* concat, const 
 {
 	BLMX_HIP(hipSetDevice(ix.prm.device));
 	const uint64_t total = nseq ? offsets[nseq] : 0;
-	if (nseq && offsets[0] != 0)
+	if (nseq && offsets[0] != 0) {  // (collective: take part with an empty batch, then report)
+		query_kmers_sharded(ix, c, nullptr, 0, nullptr, ix.stream);
 		throw StatusError{BLMX_EINVAL, "offsets[0] must be 0"};
+	}
 	const uint64_t k = ix.prm.k;
 	uint64_t nk = 0;
 	for (uint64_t i = 0; i < nseq; i++) {

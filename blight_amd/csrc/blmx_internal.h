@@ -269,6 +269,10 @@ struct Index {
 	blmx_stats_t st{};
 	uint64_t positions_words = 0, seq_words = 0, total_lines = 0, total_logical_words = 0;
 	uint32_t pos_hint = 0;  // extra low bits per position field in HBM (0 = the reference's field width)
+	// shards: nucleotides of the NEXT owners' first buckets kept behind this shard's sequence (what the single index holds there);
+	// halo_done = false between blmx_shard_build_finish and blmx_shard_halo_set (windows at the shard's end still see padding)
+	uint64_t halo_nt = 0;
+	bool halo_done = true;
 
 	// staging for host-buffer queries
 	DevBuf q_in, q_aux, q_out;
@@ -360,9 +364,13 @@ void positions_to_reference_layout(const Index& ix, DevBuf& out, hipStream_t s);
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
 // sharded build from slices, phase by phase (blmx_build.hip); hist_out holds ngroups + 1 words: key histogram, local super-k-mers
 void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out);
-void shard_build_plan(Index& ix, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta, const void** d_words);
+void shard_build_plan(Index& ix, const uint64_t* global_hist, uint32_t world, uint64_t* send_sk, uint64_t* send_words, const void** d_meta,
+                      const void** d_words);
 void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in, const uint64_t* recv_sk, const uint64_t* recv_words);
 void shard_build_abort(Index& ix);
+uint64_t shard_halo_words(const Index& ix);  // u64 words of one halo record
+void shard_halo_get(Index& ix, uint64_t* rec);
+void shard_halo_set(Index& ix, const uint64_t* recs, uint32_t world);
 
 // query (blmx_query.hip).  mode: 0 = IDs (query_kmer_hash / query_get_hash), 1 = positions (query_get_pos_unitig),
 // 2 = membership byte.  d_minis == nullptr -> minimizers are computed on the device.
@@ -417,6 +425,9 @@ struct Comm;
 void comm_unique_id(void* id_out);
 Comm* comm_create(const void* id_bytes, uint32_t rank, uint32_t world, int device);
 void comm_destroy(Comm* c);
+void comm_loopback_id(void* id_out);
+void comm_set_tuning(Comm& c, const char* key, int64_t value);
+const char* comm_transport(const Comm* c);
 void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len,
                    const StatusError* already_failed = nullptr);
 void build_sharded_from_fasta(Index& ix, Comm& c, const char* path);

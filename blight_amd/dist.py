@@ -182,6 +182,13 @@ class DeviceSliceOps:
         torch.cuda.synchronize()
         self.ix.shard_build_finish(meta_in.data_ptr(), words_in.data_ptr(), recv_sk, recv_words)
 
+    def halo_get(self):
+        """the head of this shard's packed sequence (int64 view of the library's record)"""
+        return torch.from_numpy(self.ix.shard_halo_get().view("int64").copy())
+
+    def halo_set(self, records):
+        self.ix.shard_halo_set(records.cpu().numpy().view("uint64"))
+
 
 class SlicedBuilder:
     """build(seqs): every rank passes ITS OWN consecutive slice of the input (rank order = input order).  One all-reduce (per-group
@@ -219,6 +226,13 @@ class SlicedBuilder:
         self._a2a(meta_in, meta, recv_sk, send_sk)
         self._a2a(words_in, packed, recv_words, send_words)
         self.ops.finish(meta_in, words_in, recv_sk, recv_words)
+        # halo: every shard keeps, behind its own sequence, the head of what follows it in the single index (the reference's scan
+        # runs on past the end of a bucket, blight.cpp:729-739) -- one small all-gather of the shards' heads
+        if hasattr(self.ops, "halo_get"):
+            mine = self.ops.halo_get().to(self.cdev)
+            recs = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(recs, mine, group=self.group)
+            self.ops.halo_set(torch.cat([r.cpu() for r in recs]))
 
 
 # ---- the native exchange (RCCL inside libblight_mi355x.so) behind the same two method names --------------------------------------

@@ -228,6 +228,15 @@ public:
 				throw std::runtime_error(blmx_last_error(nullptr));
 			return id;
 		}
+		// an id for `world` communicators inside ONE process (one thread per rank, all on one GPU): the loopback transport, for
+		// rehearsing the multi-rank path on a one-GPU box
+		static id_t loopback_id()
+		{
+			id_t id;
+			if (blmx_comm_loopback_id(id.data()) != BLMX_OK)
+				throw std::runtime_error(blmx_last_error(nullptr));
+			return id;
+		}
 		communicator(const id_t& id, uint32_t rank_, uint32_t world_, int device = 0) : rank(rank_), world(world_)
 		{
 			if (blmx_comm_create(id.data(), rank, world, device, &_c) != BLMX_OK)
@@ -237,6 +246,7 @@ public:
 		communicator& operator=(const communicator&) = delete;
 		~communicator() { blmx_comm_destroy(_c); }
 		blmx_comm* handle() const { return _c; }
+		std::string transport() const { return blmx_comm_transport(_c); }
 		const uint32_t rank, world;
 
 	private:

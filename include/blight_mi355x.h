@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
  * so a stale caller binary is detected instead of corrupting memory. */
-#define BLMX_ABI_VERSION 9
+#define BLMX_ABI_VERSION 10
 
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
@@ -182,6 +182,9 @@ int blmx_canonicalize_device(blmx_index* ix, void* d_kmers, uint64_t nq, void* s
  * every rank is given the SAME input, chops it, and derives the same key-balanced group boundaries, so no build-time
  * exchange is needed and IDs stay global.  world <= 16 (the partitioned exchange splits its bins at up to 15 boundaries).
  * blmx_shard_bounds returns the world+1 group boundaries.
+ * Answers are those of the single index for EVERY k-mer, including the reference's own false positives: its 2^b scan runs past the
+ * end of a bucket into the next one (blight.cpp:729-739), so every shard keeps a halo behind its sequence -- the first 2^b + k
+ * nucleotides the single index holds behind the shard's last bucket (the head of the next owners' first buckets).
  * Routing helpers (device pointers): count -> destination rank of every k-mer + per-destination counts; scatter -> k-mers
  * grouped by destination (+ the permutation); unpermute -> out[order[i]] = vals[i]. */
 int blmx_set_shard(blmx_index* ix, uint32_t rank, uint32_t world);
@@ -219,6 +222,18 @@ int blmx_gather_ids_device(blmx_index* ix, const int64_t* d_ids_ordered, const u
 typedef struct blmx_comm blmx_comm;
 #define BLMX_COMM_ID_BYTES 128
 int blmx_comm_unique_id(void* id_out);
+/* An id for the LOOPBACK transport: blmx_comm_create with such an id makes `world` communicators that live in ONE process -- one
+ * caller thread per rank, all on the same GPU -- and move every flow with device copies under the same grouping and stream
+ * ordering as RCCL.  For rehearsing and testing the multi-rank choreography on a one-GPU box (tests, tools/shard_query
+ * --transport loopback); not a performance path.  Collectives block until every rank of the id has arrived (BLMX_ERCCL after
+ * BLIGHT_LOOPBACK_TIMEOUT seconds, default 120). */
+int blmx_comm_loopback_id(void* id_out);
+/* "rccl" or "loopback" */
+const char* blmx_comm_transport(const blmx_comm* c);
+/* Communicator knobs; set the same value on every rank.  "flow_words": pairwise flows of the all-to-all-v are cut into rounds of at
+ * most this many 8-byte words (default 2^25 = 256 MiB).  "pieces": pieces of a query batch that run as a software pipeline
+ * (1..4; 0 = the environment's BLIGHT_DIST_CHUNKS, or 2). */
+int blmx_comm_set_tuning(blmx_comm* c, const char* key, int64_t value);
 int blmx_comm_create(const void* id, uint32_t rank, uint32_t world, int device, blmx_comm** out);
 void blmx_comm_destroy(blmx_comm* c);
 int blmx_query_kmers_sharded_device(blmx_index* ix, blmx_comm* c, const void* d_canon_kmers, uint64_t nq, int64_t* d_ids_out, void* stream);
@@ -239,12 +254,20 @@ int blmx_query_sequences_sharded_device(blmx_index* ix, blmx_comm* c, const void
  * The three phases are also exported for callers with their own transport (and for the single-GPU virtual-rank tests):
  *   blmx_shard_build_begin[_device]  chop the slice; hist_out[2^log2_mphf + 1] = this slice's keys per MPHF group, then its
  *                                    super-k-mer count.  The caller sums hist_out over all ranks (element-wise).
- *   blmx_shard_build_plan            global_hist = that sum.  Derives the shard boundaries, orders the slice's super-k-mers by
+ *   blmx_shard_build_plan            global_hist = that sum; world = the one given to blmx_set_shard (checked).  Derives the shard boundaries, orders the slice's super-k-mers by
  *                                    owner and packs them: send_sk[world] super-k-mers / send_words[world] u64 words go to each
  *                                    rank, taken consecutively from *d_meta (one u64 per super-k-mer) and *d_words (2-bit
  *                                    nucleotides; every destination's part starts on a word).  The buffers stay valid until finish.
  *   blmx_shard_build_finish          d_meta_in / d_words_in = what this rank received, concatenated in SOURCE-RANK order;
- *                                    recv_sk[world] / recv_words[world] = the counts per source.  Builds the shard. */
+ *                                    recv_sk[world] / recv_words[world] = the counts per source.  Builds the shard.
+ *   blmx_shard_halo_get / _set       after EVERY rank has finished: each rank publishes the head of its packed sequence
+ *                                    (blmx_shard_halo_words() u64 words: valid nucleotides, then 2-bit packed words), the caller
+ *                                    gathers the records of all ranks in rank order, and blmx_shard_halo_set(records, world) copies
+ *                                    what follows this shard in the single index behind its own sequence (and adds the k-mers a
+ *                                    window can now read there to the absent-key filter; waits for the filter's background passes).
+ *                                    Until then windows that run past the shard's last bucket see padding: answers are those of the
+ *                                    single index except for its false positives across the cut.  No-op on the last rank and on
+ *                                    whole-input builds.  The native collectives do all of this themselves. */
 int blmx_build_sharded_from_sequences(blmx_index* ix, blmx_comm* c, const char* concat, const uint64_t* offsets, uint64_t nseq);
 /* every rank names the SAME file and keeps the rank-th consecutive part of its sequences ([nseq*rank/world, nseq*(rank+1)/world)) */
 int blmx_build_sharded_from_fasta(blmx_index* ix, blmx_comm* c, const char* path);
@@ -253,9 +276,12 @@ int blmx_build_sharded_from_device_sequences(blmx_index* ix, blmx_comm* c, const
 int blmx_shard_build_begin(blmx_index* ix, const char* concat, const uint64_t* offsets, uint64_t nseq, uint64_t* hist_out);
 int blmx_shard_build_begin_device(blmx_index* ix, const void* d_concat, const uint64_t* d_offsets, uint64_t nseq, uint64_t total_len,
                                   uint64_t* hist_out);
-int blmx_shard_build_plan(blmx_index* ix, const uint64_t* global_hist, uint64_t* send_sk, uint64_t* send_words, const void** d_meta,
-                          const void** d_words);
+int blmx_shard_build_plan(blmx_index* ix, const uint64_t* global_hist, uint32_t world, uint64_t* send_sk, uint64_t* send_words,
+                          const void** d_meta, const void** d_words);
 int blmx_shard_build_finish(blmx_index* ix, const void* d_meta_in, const void* d_words_in, const uint64_t* recv_sk, const uint64_t* recv_words);
+uint64_t blmx_shard_halo_words(const blmx_index* ix);
+int blmx_shard_halo_get(blmx_index* ix, uint64_t* record_out);
+int blmx_shard_halo_set(blmx_index* ix, const uint64_t* records, uint32_t world);
 
 /* Batch-query strategy of blmx_query_kmers / blmx_query_kmers_device: 0 = automatic (large batches on large indexes are first
  * partitioned by the top bits of their minimizer so that concurrently running blocks share a slice of the index in

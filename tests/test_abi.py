@@ -81,3 +81,28 @@ def test_product_never_references_the_oracle():
         if re.search(r"(liborc|blight_oracle)", open(os.path.join(ROOT, "include", f)).read()):
             bad.append(f)
     assert not bad, bad
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(tmp_path):
+    """ADVICE r02: the loader's error text used dlerror() twice (the second call returns NULL -> std::string + NULL).  With the library
+    name pointed at a file that does not exist, blmx_comm_unique_id must return BLMX_ERCCL and leave a message -- on any host, GPU or
+    not (no device is touched before the library is loaded)."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['BLIGHT_NO_TORCH'] = '1'\n"
+        "os.environ['BLIGHT_RCCL_LIB'] = %r\n"
+        "import blight_amd as B\n"
+        "lib = B.load_library()\n"
+        "buf = C.create_string_buffer(B.COMM_ID_BYTES)\n"
+        "rc = lib.blmx_comm_unique_id(buf)\n"
+        "msg = lib.blmx_last_error(None).decode()\n"
+        "assert rc == B.BLMX_ERCCL, rc\n"
+        "assert 'librccl_missing' in msg and len(msg) > 20, msg\n"
+        "lb = C.create_string_buffer(B.COMM_ID_BYTES)\n"
+        "assert lib.blmx_comm_loopback_id(lb) == 0 and lb.raw[:13] == b'BLMX-LOOPBACK'\n"
+        "print('ERCCL-OK')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "librccl_missing.so")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ERCCL-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

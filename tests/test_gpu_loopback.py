@@ -1,0 +1,176 @@
+"""The native multi-GPU path (blmx_comm.hip: construction from slices, halo exchange, the query exchange with its piece pipeline and
+multi-round all-to-all-v, failure votes) with MORE THAN ONE RANK on a one-GPU box: the library's loopback transport -- `world`
+communicators in this process, one thread per rank, all on the test box's GPU; flows are device copies under the same grouping and
+stream ordering as RCCL.  IDs must equal the single index's (and the oracle's) for every rank's batch."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+os.environ.setdefault("BLIGHT_LOOPBACK_TIMEOUT", "90")
+
+
+def _rand_seq(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+
+def run_ranks(world, fn):
+    """fn(rank) on `world` threads; returns the results, re-raises the first exception (after every thread has ended)"""
+    res, err = [None] * world, [None] * world
+
+    def wrap(r):
+        try:
+            res[r] = fn(r)
+        except BaseException as e:  # noqa: BLE001 - reported below
+            err[r] = e
+
+    th = [threading.Thread(target=wrap, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return res, err
+
+
+@pytest.mark.parametrize("world,k,m,n,b", [(2, 31, 9, 7, 6), (3, 31, 7, 5, 4), (8, 31, 9, 9, 6), (3, 63, 9, 7, 8)])
+def test_native_exchange_on_the_loopback_transport(world, k, m, n, b):
+    import torch
+    import blight_amd as B
+    import shard_util as S
+    from oracle import oracle as O
+    rng = np.random.default_rng(world * 13 + k)
+    seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 80))) for _ in range(4000)]
+    seqs += ["A" * (k + 40), seqs[5]]
+    kb = 8 if k <= 32 else 16
+    full = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+    full.construct_index_from_sequences(seqs)
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    # queries: every k-mer readable in the single index's packed sequence (false positives at the shard cuts included), the indexed
+    # k-mers once more, random ones; shuffled
+    rq, _ = S.readable_kmers(full, k, kb, b)
+    pos = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs[:1500]])
+    neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(30000)]
+    neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
+    q = np.concatenate([rq, pos, neg])
+    q = np.ascontiguousarray(q[rng.permutation(len(q))])
+    want = orc.query_kmers(q.reshape(-1) if kb == 8 else q)
+    assert np.array_equal(full.query_kmer_hash(q.reshape(-1)), want)
+    # uneven slices of the input and of the query batch; with three or more ranks one rank gets no sequences and one no queries
+    cuts = sorted(int(x) for x in rng.integers(0, len(seqs), world - 1))
+    qcuts = sorted(int(x) for x in rng.integers(0, len(q), world - 1))
+    if world >= 3:
+        cuts[1] = cuts[0]
+        qcuts[-1] = len(q)
+    cuts = [0] + cuts + [len(seqs)]
+    qcuts = [0] + qcuts + [len(q)]
+    ref = []
+    for r in range(world):
+        a = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+        a.set_shard(r, world)
+        a.construct_index_from_sequences(seqs)
+        ref.append(a)
+    dev = torch.device("cuda", 0)
+    d_q = [torch.from_numpy(q[qcuts[r]:qcuts[r + 1]].view(np.int64).copy()).to(dev) for r in range(world)]
+    d_ids = [torch.full((max(1, qcuts[r + 1] - qcuts[r]),), -7, dtype=torch.int64, device=dev) for r in range(world)]
+    streams = [torch.cuda.Stream(dev) for _ in range(world)]
+    torch.cuda.synchronize()
+    uid = B.comm_loopback_id()
+    comms, ixs = [None] * world, [None] * world
+
+    def build(r):
+        comms[r] = B.Comm(uid, r, world, device=0)
+        assert comms[r].transport == "loopback"
+        ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+        ix.set_shard(r, world)
+        comms[r].build_sharded_from_sequences(ix, seqs[cuts[r]:cuts[r + 1]])
+        ixs[r] = ix
+
+    _, err = run_ranks(world, build)
+    assert not any(err), err
+    for r in range(world):
+        for name in B.EXPORT:
+            assert np.array_equal(ixs[r].export(name), ref[r].export(name)), (r, name)
+        s1, s2 = ixs[r].stats(), ref[r].stats()
+        assert not [f for f in s1 if f not in ("build_seconds", "number_query") and s1[f] != s2[f]], [(r, f, s1[f], s2[f]) for f in s1 if s1[f] != s2[f]]
+        ixs[r].set_tuning("absent_filter", 1)
+
+    # ---- the query exchange: 1..4 pieces, whole flows and flows cut into many ragged rounds
+    for pieces, flow_words in ((2, 1 << 25), (1, 997), (3, 4099), (4, 1 << 25)):
+        for c in comms:
+            c.set_tuning("pieces", pieces)
+            c.set_tuning("flow_words", flow_words)
+
+        def query(r):
+            n_r = qcuts[r + 1] - qcuts[r]
+            comms[r].query_kmers_sharded_device(ixs[r], d_q[r].data_ptr(), n_r, d_ids[r].data_ptr(), streams[r].cuda_stream)
+            streams[r].synchronize()
+            return d_ids[r][:n_r].cpu().numpy()
+
+        got, err = run_ranks(world, query)
+        assert not any(err), err
+        for r in range(world):
+            assert np.array_equal(got[r], want[qcuts[r]:qcuts[r + 1]]), (pieces, flow_words, r, int((got[r] != want[qcuts[r]:qcuts[r + 1]]).sum()))
+
+    # ---- host-buffer collectives: k-mers, and whole sequences through this rank's read front end
+    reads = seqs[:200] + [_rand_seq(rng, 200) for _ in range(40)] + ["ACG"]
+    rwant = [orc.query_sequence(s) if len(s) >= k else np.zeros(0, np.int64) for s in reads]
+
+    def host_calls(r):
+        a = comms[r].query_kmers_sharded(ixs[r], q[qcuts[r]:qcuts[r + 1]].reshape(-1))
+        mine = reads[r::world]
+        b_ = comms[r].query_sequences_sharded(ixs[r], mine)
+        return a, b_
+
+    got, err = run_ranks(world, host_calls)
+    assert not any(err), err
+    for r in range(world):
+        assert np.array_equal(got[r][0], want[qcuts[r]:qcuts[r + 1]]), r
+        assert np.array_equal(got[r][1], np.concatenate(rwant[r::world])), r
+
+    # ---- failures are collective: one rank's input is rejected / one rank's index is not built -> nobody hangs, everybody fails
+    fresh = [B.kmer_Set_Light(k, m, n, min(n, 3), 1, b) for _ in range(world)]
+
+    def bad_build(r):
+        fresh[r].set_shard(r, world)
+        comms[r].build_sharded_from_sequences(fresh[r], seqs[cuts[r]:cuts[r + 1]] + (["ACGT"] if r == world - 1 else []))
+
+    _, err = run_ranks(world, bad_build)
+    assert all(isinstance(e, B.BlightError) for e in err), err
+    assert err[world - 1].code == B.BLMX_ESHORT and all(e.code == B.BLMX_ERCCL for e in err[:-1])
+
+    def bad_query(r):
+        ix = fresh[r] if r == 0 else ixs[r]     # rank 0 brings an index that was never built
+        n_r = qcuts[r + 1] - qcuts[r]
+        comms[r].query_kmers_sharded_device(ix, d_q[r].data_ptr(), n_r, d_ids[r].data_ptr(), streams[r].cuda_stream)
+
+    _, err = run_ranks(world, bad_query)
+    assert all(isinstance(e, B.BlightError) for e in err), err
+    assert err[0].code == B.BLMX_ESTATE and all(e.code == B.BLMX_ERCCL for e in err[1:])
+
+    # ... and the communicators are still usable afterwards
+    def again(r):
+        comms[r].build_sharded_from_sequences(fresh[r], seqs[cuts[r]:cuts[r + 1]])
+        n_r = qcuts[r + 1] - qcuts[r]
+        comms[r].query_kmers_sharded_device(fresh[r], d_q[r].data_ptr(), n_r, d_ids[r].data_ptr(), streams[r].cuda_stream)
+        streams[r].synchronize()
+        return d_ids[r][:n_r].cpu().numpy()
+
+    got, err = run_ranks(world, again)
+    assert not any(err), err
+    for r in range(world):
+        assert np.array_equal(got[r], want[qcuts[r]:qcuts[r + 1]]), r
+    torch.cuda.synchronize()
+    for c in comms:
+        c.close()
+
+
+def test_loopback_ranks_must_agree_on_the_world():
+    import blight_amd as B
+    uid = B.comm_loopback_id()
+    a = B.Comm(uid, 0, 2)
+    with pytest.raises(ValueError):
+        B.Comm(uid, 1, 3)
+    a.close()

@@ -319,54 +319,28 @@ def test_sharded_build_from_slices(world, k, m, n, b):
     the native collective blmx_build_sharded_from_sequences runs the same three phases around RCCL): `world` virtual ranks on one
     GPU, the all-reduce is a numpy sum and the all-to-all-v a set of device copies.  Every array of every shard must equal the
     whole-input sharded build (which equals the unsharded index up to the shard's group range: test_virtual_shards)."""
-    import ctypes as C
-    import torch
     import blight_amd as B
+    import shard_util as S
+    from oracle import oracle as O
     rng = np.random.default_rng(world * 11 + k)
     seqs = [_rand_seq(rng, k - 1 + int(rng.geometric(1 / 80))) for _ in range(3000)]
     longest = max(seqs[:40], key=len)
     seqs += ["A" * (k + 40), "AC" * (k + 3), seqs[5], longest[min(3, len(longest) - k):]]  # duplicates and low complexity: fallback keys, shared buckets
-    hip = C.CDLL([l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0])
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     # uneven consecutive slices; with three or more ranks one of them gets nothing
     cuts = sorted(int(x) for x in rng.integers(0, len(seqs), world - 1))
     if world >= 3:
         cuts[1] = cuts[0]
     cuts = [0] + cuts + [len(seqs)]
-    ref, ixs, hists = [], [], []
+    ref = []
     for r in range(world):
         a = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
         a.set_shard(r, world)
         a.construct_index_from_sequences(seqs)
         ref.append(a)
-        x = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
-        x.set_shard(r, world)
-        hists.append(x.shard_build_begin(seqs[cuts[r]:cuts[r + 1]]))
-        ixs.append(x)
-    gh = np.sum(hists, axis=0, dtype=np.uint64)
+    ixs, gh = S.build_from_slices(B, seqs, cuts, (k, m, n, b))
     assert int(gh[-1]) == ref[0].stats()["number_super_kmer"]
-    plans = [x.shard_build_plan(gh, world) for x in ixs]
-    dev = torch.device("cuda", 0)
-    incoming = []
-    for d in range(world):
-        recv_sk = np.array([plans[r][0][d] for r in range(world)], dtype=np.uint64)
-        recv_w = np.array([plans[r][1][d] for r in range(world)], dtype=np.uint64)
-        meta = torch.zeros(int(recv_sk.sum()) + 1, dtype=torch.int64, device=dev)
-        words = torch.zeros(int(recv_w.sum()) + 1, dtype=torch.int64, device=dev)
-        om = ow = 0
-        for r in range(world):
-            sk, w, pm, pw = plans[r]
-            sm, sw = int(sk[:d].sum()), int(w[:d].sum())
-            if recv_sk[r]:
-                assert hip.hipMemcpy(meta.data_ptr() + 8 * om, pm + 8 * sm, 8 * int(recv_sk[r]), 3) == 0
-            if recv_w[r]:
-                assert hip.hipMemcpy(words.data_ptr() + 8 * ow, pw + 8 * sw, 8 * int(recv_w[r]), 3) == 0
-            om += int(recv_sk[r])
-            ow += int(recv_w[r])
-        incoming.append((meta, words, recv_sk, recv_w))
-    torch.cuda.synchronize()
-    for d, (meta, words, recv_sk, recv_w) in enumerate(incoming):     # the outgoing buffers of a rank live until ITS finish
-        ixs[d].shard_build_finish(meta.data_ptr(), words.data_ptr(), recv_sk, recv_w)
+    with pytest.raises(ValueError):
+        ixs[0].shard_build_plan(gh, world + 1)       # the caller's world must be the index's (its arrays are sized by it)
     for r in range(world):
         assert np.array_equal(ixs[r].shard_bounds(), ref[r].shard_bounds())
         for name in B.EXPORT:
@@ -379,6 +353,18 @@ def test_sharded_build_from_slices(world, k, m, n, b):
         got = ixs[r].query_sequences_hash(some)
         assert np.array_equal(got, ref[r].query_sequences_hash(some)), r
         assert (got >= 0).any() or s1["local_number_kmer"] < 50, r  # (a shard may own next to nothing when there are fewer groups than ranks)
+    # EVERY k-mer readable anywhere in the SINGLE index's packed sequence (junctions of super-k-mers, of buckets -- also the ones
+    # that are shard cuts now -- and the padding behind the end): both kinds of shards answer like the single index and the oracle
+    full = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+    full.construct_index_from_sequences(seqs)
+    kb = full.kmer_bytes
+    q, _ = S.readable_kmers(full, k, kb, b)
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    want = orc.query_kmers(q.reshape(-1) if kb == 8 else q)
+    assert np.array_equal(full.query_kmer_hash(q.reshape(-1)), want)
+    for shards in (ixs, ref):
+        got = S.answers_through_shards(shards, q)
+        assert np.array_equal(got, want), int((got != want).sum())
     # phase errors: finish without plan, plan twice
     y = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
     y.set_shard(0, world)
