@@ -454,11 +454,14 @@ void comm_loopback_id(void* id_out)
 	memcpy(o + 24, &b, 8);
 }
 
-// All-to-all-v flows are cut into rounds of at most 256 MiB.  History: in round 2 the C4-size world-1 rehearsal of the construction
-// from slices sent its two flows (1.9 GB of meta words, 2.4 GB of packed nucleotides, self flow on RCCL 2.26) as ONE ncclSend /
-// ncclRecv pair each and the shard differed from the whole-input build; with 1 GB it did not.  tools/rccl_flow_probe.cpp repeats that
-// flow on its own (pattern in, compare out, by size) -- see DESIGN.md section 6 for what it found.  Whatever the cause, nothing here
-// depends on one huge message: 256-MiB rounds keep every message far below 2^31 bytes, and blmx_comm_set_tuning("flow_words")
+// All-to-all-v flows are cut into rounds of at most 256 MiB.  Root cause of round 2's "one 1.7-GB flow delivered wrong data": it is
+// not our offset arithmetic.  tools/rccl_flow_probe.hip (no code of this library: one grouped ncclSend / ncclRecv pair of a rank to
+// ITSELF, pattern in, compare on the device) shows on RCCL 2.27.7 / ROCm 7.2 that a self flow of MORE THAN 2^30 BYTES arrives only
+// in its first half -- 1 GiB: intact; 1.5 GB: every word from byte 750,256,128 on is untouched; 1.9 GB, 2^31 - 8, 2^31, 2.4 GB,
+// 3 GiB, 4 GiB + 64: the same, always from (about) the middle -- while the same bytes sent as 256-MiB rounds arrive intact at every
+// size (profiles/r03_rccl_flow_probe.jsonl).  The world-1 rehearsal of the construction from slices at C4 size sent 1.9 GB of meta
+// words and 2.4 GB of packed nucleotides to itself as one message each: that is this.  Whether flows between DIFFERENT ranks are
+// affected cannot be seen on a one-GPU box, so nothing here ever sends a message above 256 MiB; blmx_comm_set_tuning("flow_words")
 // shrinks the rounds so that the tests walk through the multi-round branch with ragged last rounds.
 constexpr uint64_t kFlowWords = 1ull << 25;
 

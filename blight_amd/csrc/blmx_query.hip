@@ -634,10 +634,20 @@ __global__ void k_plan_learn_offs(const uint32_t* __restrict__ offs, uint32_t nb
 	}
 }
 
+// What the gather needs to find a query's answer again (k_gather_runs): the tile-local position of the query in bin order (lpos,
+// 2 B per query) and, per (tile, bin), the run's first slot inside the bin, its first overflow slot and its length (RunTable,
+// 12 B per run = 1.5 B per query) -- instead of a 4-B slot number per query that the gather then chases one lane at a time.
+struct RunTable {
+	uint32_t* gbase;  // [tile * kNB + bin]
+	uint32_t* obase;
+	uint32_t* count;
+};
+
 template <int KW>
 __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, const SlotPlan* __restrict__ sp, const uint64_t* __restrict__ kmers,
                                                              const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
-                                                             uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint32_t* __restrict__ inv)
+                                                             uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint16_t* __restrict__ lpos,
+                                                             RunTable rt)
 {
 	constexpr int kTile = BinTile<KW>::value;
 	constexpr int kPer = kTile / kBinThreads;
@@ -697,6 +707,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		}
 		s_gbase[t] = g;
 		s_obase[t] = ob;
+		{
+			const size_t ri = (size_t)blockIdx.x * kNB + t;
+			rt.gbase[ri] = g;
+			rt.obase[ri] = ob;
+			rt.count[ri] = c;
+		}
 		__syncthreads();
 		uint32_t wbase = 0;
 		for (uint32_t w = 0; w < wave; w++)
@@ -721,8 +737,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 				s_keys[2 * ls + 1] = x[e].hi;
 			}
 			s_mini[ls] = mini[e];
-			const uint64_t dst = slot_of(b, rank[e]);
-			inv[i] = dst < all_slots ? (uint32_t)dst : 0xffffffffu;
+			lpos[i] = (uint16_t)ls;
 		}
 	}
 	__syncthreads();
@@ -836,6 +851,75 @@ __global__ __launch_bounds__(kBinThreads) void k_gather_ids(const void* __restri
 		const uint64_t i = base + (uint64_t)it * kBinThreads + threadIdx.x;
 		if (i < nq)
 			out[i] = v[it];
+	}
+}
+
+// The gather behind the one-pass partition.  One workgroup per partition tile: one thread per bin expands the tile's run table into
+// the slot of every tile-local sorted position (LDS), the lanes then fetch the IDs of CONSECUTIVE sorted positions -- consecutive
+// slots inside a run: 64 lanes touch ~8 lines instead of 64 -- into LDS, and out[i] = ids_tile[lpos[i]] goes out fully coalesced.
+// (k_gather_ids chased a 4-B slot number per query with one random 4-B load per lane: 0.76 ms per 1e8 at C4, request-bound.)
+template <int TILE, bool NARROW>
+__global__ __launch_bounds__(kBinThreads) void k_gather_runs(const SlotPlan* __restrict__ sp, RunTable rt, const uint16_t* __restrict__ lpos,
+                                                             const void* __restrict__ ids, uint64_t nq, int64_t* __restrict__ out)
+{
+	constexpr int kNB = 1 << kBinBitsMax;
+	constexpr int kPer = TILE / kBinThreads;
+	__shared__ uint32_t s_slot[TILE];  // slot of every sorted position, then (NARROW) its ID
+	__shared__ uint32_t s_hi[NARROW ? 1 : TILE];
+	__shared__ uint32_t s_wsum[kBinThreads / 64];
+	static_assert(kBinThreads == kNB, "one bin per thread");
+	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const uint64_t base = (uint64_t)blockIdx.x * TILE;
+	const uint32_t count = (uint32_t)min((uint64_t)TILE, nq - base);
+	const uint32_t nb = sp->nbins, ovf_at = sp->main_slots, all_slots = sp->main_slots + sp->ovf_cap;
+	// tile-local start of every bin's run
+	const size_t ri = (size_t)blockIdx.x * kNB + t;
+	const uint32_t c = t < nb ? rt.count[ri] : 0u;
+	uint32_t v = c;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t u = __shfl_up(v, o);
+		if ((int)lane >= o)
+			v += u;
+	}
+	if (lane == 63)
+		s_wsum[wave] = v;
+	__syncthreads();
+	uint32_t wbase = 0;
+	for (uint32_t w = 0; w < wave; w++)
+		wbase += s_wsum[w];
+	const uint32_t lstart = wbase + v - c;
+	if (c) {
+		const uint32_t g = rt.gbase[ri], ob = rt.obase[ri], rb = sp->base[t], capb = sp->base[t + 1] - rb;
+		for (uint32_t r = 0; r < c; r++) {
+			const uint32_t gs = g + r;
+			const uint64_t sl = gs < capb ? (uint64_t)rb + gs : (uint64_t)ovf_at + ob + (gs - max(g, capb));
+			s_slot[lstart + r] = sl < all_slots ? (uint32_t)sl : 0xffffffffu;
+		}
+	}
+	__syncthreads();
+	for (uint32_t sidx = t; sidx < count; sidx += kBinThreads) {
+		const uint32_t sl = s_slot[sidx];
+		if constexpr (NARROW) {
+			s_slot[sidx] = sl == 0xffffffffu ? 0xffffffffu : reinterpret_cast<const uint32_t*>(ids)[sl];
+		} else {
+			const int64_t w = sl == 0xffffffffu ? -1 : reinterpret_cast<const int64_t*>(ids)[sl];
+			s_slot[sidx] = (uint32_t)w;
+			s_hi[sidx] = (uint32_t)((uint64_t)w >> 32);
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int it = 0; it < kPer; it++) {
+		const uint64_t i = base + (uint64_t)it * kBinThreads + t;
+		if (i < nq) {
+			const uint32_t p = lpos[i];
+			if constexpr (NARROW) {
+				const uint32_t w = s_slot[p];
+				out[i] = w == 0xffffffffu ? -1 : (int64_t)w;
+			} else {
+				out[i] = (int64_t)((uint64_t)s_slot[p] | ((uint64_t)s_hi[p] << 32));
+			}
+		}
 	}
 }
 
@@ -1043,7 +1127,14 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	const uint32_t nblk = (uint32_t)((nq + tile - 1) / tile);
 	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
 	ensure_buf(ix.b_sorted, slots * 8 * (size_t)ix.KW, s);
-	ensure_buf(ix.b_inv, nq * 4, s);
+	// lpos (2 B per query) followed by the run table (3 x 4 B per (tile, bin))
+	const size_t lpos_bytes = (nq * 2 + 255) & ~(size_t)255, runs = (size_t)nblk << kBinBitsMax;
+	ensure_buf(ix.b_inv, lpos_bytes + runs * 12, s);
+	uint16_t* d_lpos = ix.b_inv.as<uint16_t>();
+	RunTable rt;
+	rt.gbase = reinterpret_cast<uint32_t*>(ix.b_inv.as<char>() + lpos_bytes);
+	rt.obase = rt.gbase + runs;
+	rt.count = rt.obase + runs;
 	ensure_buf(ix.b_ids, slots * 8, s);
 	ensure_buf(ix.b_offs, ((size_t)nbins + 1) * 4, s);
 	ensure_buf(ix.b_plan, sizeof(SlotPlan), s);
@@ -1061,10 +1152,10 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	ix.prof_mark(3, s);
 	if (ix.KW == 1)
 		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
-		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, ix.b_inv.as<uint32_t>());
+		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt);
 	else
 		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
-		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, ix.b_inv.as<uint32_t>());
+		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt);
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(4, s);
 	if (ix.KW == 1)
@@ -1073,7 +1164,18 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 		launch_query_slots_kw<2>(ix, d_plan, (uint32_t)(max_main >> 8), ovf_blocks, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.p, narrow, s);
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(5, s);
-	gather_ids(ix, ix.b_ids.p, ix.b_inv.as<uint32_t>(), nq, d_out, tile, narrow, s);
+	if (ix.KW == 1) {
+		if (narrow)
+			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, true>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
+		else
+			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, false>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
+	} else {
+		if (narrow)
+			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, true>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
+		else
+			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, false>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
+	}
+	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(6, s);
 	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>());
 	ix.plan_bits = tbits;

@@ -139,7 +139,15 @@ def make_cut_case(O, k, kb, m, n, b, nseq, world, seed):
     only_across = np.ones(len(q), bool)
     np.logical_and.at(only_across, inverse.reshape(-1), straddles)
     cut_fp = only_across & ~is_key & (want >= 0)
-    return seqs, orc, q, want, is_key, cut_fp, bounds
+    # ... and, of those, the ones a shard WITHOUT its halo cannot read either: behind its end it sees padding ('A' = code 0), so a
+    # k-mer whose nucleotides behind the cut are all 'A' reads the same with and without the halo
+    needs_halo = np.zeros(len(allk), bool)
+    for c in cuts:
+        for st in range(max(0, c - k + 1), c):
+            needs_halo[st] = nts[c:st + k].any()
+    strict = np.ones(len(q), bool)
+    np.logical_and.at(strict, inverse.reshape(-1), needs_halo)
+    return seqs, orc, q, want, is_key, cut_fp, cut_fp & strict, bounds
 
 
 CUT_CASES = [(31, 8, 7, 5, 6, 400, 2, 1), (31, 8, 7, 5, 6, 400, 3, 1), (31, 8, 7, 5, 6, 400, 8, 1), (21, 8, 5, 3, 8, 300, 2, 8), (21, 8, 5, 3, 8, 300, 8, 1),

@@ -20,8 +20,8 @@ def test_canonical_kmers_helper_equals_the_oracle():
 @pytest.mark.parametrize("k,kb,m,n,b,nseq,world,seed", S.CUT_CASES)
 def test_cases_hold_a_false_positive_across_a_shard_cut(k, kb, m, n, b, nseq, world, seed):
     from oracle import oracle as O
-    seqs, orc, q, want, is_key, cut_fp, bounds = S.make_cut_case(O, k, kb, m, n, b, nseq, world, seed)
+    seqs, orc, q, want, is_key, cut_fp, cut_fp_strict, bounds = S.make_cut_case(O, k, kb, m, n, b, nseq, world, seed)
     assert (want[is_key] >= 0).all()
     assert is_key.sum() == len(np.unique(np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs]), axis=0))
-    assert cut_fp.sum() > 0
+    assert cut_fp.sum() > 0 and cut_fp_strict.sum() > 0
     assert len(bounds) == world + 1
