@@ -616,7 +616,7 @@ int blmx_query_kmers_sharded_device(blmx_index* h, blmx_comm* c, const void* d_k
 {
 	if (!h || !c || (nq && (!d_kmers || !d_ids)))
 		return BLMX_EINVAL;
-	return guarded(h, [&] { query_kmers_sharded(h->ix, *reinterpret_cast<Comm*>(c), d_kmers, nq, d_ids, reinterpret_cast<hipStream_t>(stream)); });
+	return guarded(h, [&] { query_kmers_sharded(h->ix, *reinterpret_cast<Comm*>(c), d_kmers, nullptr, nq, d_ids, reinterpret_cast<hipStream_t>(stream)); });
 }
 
 int blmx_build_sharded_from_sequences(blmx_index* h, blmx_comm* c, const char* concat, const uint64_t* offsets, uint64_t nseq)
@@ -793,6 +793,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_narrow_ids = value;
 	else if (k == "window_kb")
 		ix.tune_window_kb = value;
+	else if (k == "slot_piece_min")
+		ix.tune_slot_piece_min = value;
 	else if (k == "query_binning")
 		ix.bin_policy = value < 0 ? -1 : (value > 0 ? 1 : 0);
 	else

@@ -416,9 +416,10 @@ struct Comm {
 	int pieces = 0;            // pieces of a query batch (software pipeline); 0 = BLIGHT_DIST_CHUNKS or 2.  The same on every rank.
 	hipStream_t cs = nullptr;  // the exchange runs on this stream, next to the caller's compute stream
 	hipEvent_t ev_part[kMaxPieces] = {}, ev_k[kMaxPieces] = {}, ev_q[kMaxPieces] = {}, ev_i[kMaxPieces] = {};
-	DevBuf sorted[kMaxPieces], inv[kMaxPieces], recv_k[kMaxPieces], ids_remote[kMaxPieces], ids_sorted[kMaxPieces];
-	DevBuf counts, all_counts, small;
-	Pinned h_counts;
+	DevBuf sorted[kMaxPieces], inv[kMaxPieces], recv_k[kMaxPieces], recv_m[kMaxPieces], recv_h[kMaxPieces], ids_remote[kMaxPieces], ids_sorted[kMaxPieces];
+	SlotPiece sp[kMaxPieces];  // a piece in the slot format (one-pass partition into bin regions)
+	DevBuf counts, small;
+	Pinned h_dense;
 	std::mutex mu;
 	~Comm()
 	{
@@ -530,6 +531,33 @@ static void all_to_all_v(Comm& c, const void* send, const uint64_t* send_cnt, vo
 	}
 }
 
+// the same with explicit offsets (in u64 words; nullptr = packed in rank order) and counts in u64 words: slot ranges travel from
+// where they lie in the slot arrays, and the IDs come back into them
+static void all_to_all_v_words(Comm& c, const void* send, const uint64_t* send_off, const uint64_t* send_words, void* recv, const uint64_t* recv_off,
+                               const uint64_t* recv_words, hipStream_t s)
+{
+	Transport& T = *c.tp;
+	const uint64_t fw = c.flow_words;
+	uint64_t so[17], ro[17], rounds = 0;
+	so[0] = ro[0] = 0;
+	for (uint32_t r = 0; r < c.world; r++) {
+		so[r + 1] = so[r] + send_words[r];
+		ro[r + 1] = ro[r] + recv_words[r];
+		rounds = std::max(rounds, (std::max(send_words[r], recv_words[r]) + fw - 1) / fw);
+	}
+	for (uint64_t j = 0; j < rounds; j++) {
+		const uint64_t off = j * fw;
+		T.group_start();
+		for (uint32_t r = 0; r < c.world; r++) {
+			if (off < send_words[r])
+				T.send((const uint64_t*)send + (send_off ? send_off[r] : so[r]) + off, std::min(fw, send_words[r] - off), r, s);
+			if (off < recv_words[r])
+				T.recv((uint64_t*)recv + (recv_off ? recv_off[r] : ro[r]) + off, std::min(fw, recv_words[r] - off), r, s);
+		}
+		T.group_end();
+	}
+}
+
 // a few host words summed / gathered over the ranks (failure votes, counts, halo records): staged through a small device buffer
 static void all_reduce_host(Comm& c, uint64_t* v, size_t n, hipStream_t s)
 {
@@ -568,7 +596,15 @@ static StatusError precondition(const Index& ix, const Comm& c, bool want_built)
 // IDs of nq canonical k-mers in HBM, every k-mer answered by the rank that owns its MPHF group; collective: every rank of the
 // communicator calls it (with its own batch, possibly empty) in the same order.  A rank that cannot take part (index not built,
 // sharded for another world) still joins the count exchange with a flag, and all ranks fail together.
-void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s)
+//
+// Every piece of the batch leaves its sender in one of two formats, chosen by the sender alone and announced with the counts:
+//   slots  the single-GPU pipeline's one-pass partition (bin regions sized after the previous batch, bins split at the shard
+//          boundaries): owner r gets the slot range of its bins as it is -- k-mers, their minimizers, one header word per bin -- and
+//          returns one ID word per slot (4 B when every ID fits); what this rank owns itself is answered in place, without a flow;
+//   dense  the exact counting sort (first batch of an index, small pieces, a piece whose regions overflowed): per-owner segments
+//          without gaps, 8-byte IDs back.
+// d_minis (may be null): the minimizers of the k-mers when the caller has them (the read front end).
+void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_ids, hipStream_t s)
 {
 	std::lock_guard<std::mutex> lock(c.mu);
 	BLMX_HIP(hipSetDevice(c.device));
@@ -583,75 +619,188 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, i
 	uint64_t cut[kMaxPieces + 1];
 	for (int p = 0; p <= pieces; p++)
 		cut[p] = local.code == BLMX_OK ? nq * (uint64_t)p / (uint64_t)pieces : 0;
-	// ---- partition every piece; the per-owner counts of all pieces (+ one "cannot take part" flag) are exchanged in one all-gather
-	const size_t per_rank = (size_t)pieces * world + 1;
-	grow(c.counts, per_rank * 8, s);
-	grow(c.all_counts, per_rank * world * 8, s);
-	c.h_counts.ensure(per_rank * world * 8);
-	BLMX_HIP(hipMemsetAsync(c.counts.p, 0, per_rank * 8, s));
-	if (local.code != BLMX_OK) {
-		const uint64_t one = 1;
-		BLMX_HIP(hipMemcpyAsync(c.counts.as<uint64_t>() + per_rank - 1, &one, 8, hipMemcpyHostToDevice, s));
-		BLMX_HIP(hipStreamSynchronize(s));  // `one` lives on this frame
-	} else {
+	// ---- partition every piece
+	bool slots_fmt[kMaxPieces] = {};
+	grow(c.counts, (size_t)pieces * world * 8, s);
+	c.h_dense.ensure((size_t)pieces * world * 8);
+	auto partition_dense = [&](int p) {
+		const uint64_t n = cut[p + 1] - cut[p];
+		grow(c.sorted[p], n * 8 * kw + 16, s);
+		grow(c.inv[p], n * 4 + 16, s);
+		launch_partition(ix, (const uint64_t*)d_kmers + cut[p] * kw, n, c.sorted[p].p, c.inv[p].as<uint32_t>(), c.counts.as<uint64_t>() + (size_t)p * world, s);
+		BLMX_HIP(hipMemcpyAsync(c.h_dense.as<uint64_t>() + (size_t)p * world, c.counts.as<uint64_t>() + (size_t)p * world, 8 * (size_t)world, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipEventRecord(c.ev_part[p], s));
+	};
+	if (local.code == BLMX_OK) {
 		for (int p = 0; p < pieces; p++) {
 			const uint64_t n = cut[p + 1] - cut[p];
-			grow(c.sorted[p], n * 8 * kw + 16, s);
-			grow(c.inv[p], n * 4 + 16, s);
-			launch_partition(ix, (const uint64_t*)d_kmers + cut[p] * kw, n, c.sorted[p].p, c.inv[p].as<uint32_t>(), c.counts.as<uint64_t>() + (size_t)p * world, s);
-			BLMX_HIP(hipEventRecord(c.ev_part[p], s));
+			slots_fmt[p] = slot_piece_possible(ix, n);
+			if (slots_fmt[p]) {
+				slot_piece_partition(ix, c.sp[p], (const uint64_t*)d_kmers + cut[p] * kw, d_minis ? d_minis + cut[p] : nullptr, n, s);
+				BLMX_HIP(hipEventRecord(c.ev_part[p], s));
+			} else {
+				partition_dense(p);
+			}
 		}
+		BLMX_HIP(hipStreamSynchronize(s));
+		bool again = false;
+		for (int p = 0; p < pieces; p++)
+			if (slots_fmt[p] && c.sp[p].overflow()) {  // the regions did not hold this piece (a batch unlike its predecessor): exact partition instead
+				slots_fmt[p] = false;
+				partition_dense(p);
+				again = true;
+			}
+		if (again)
+			BLMX_HIP(hipStreamSynchronize(s));
 	}
-	c.tp->all_gather(c.counts.as<uint64_t>(), c.all_counts.as<uint64_t>(), per_rank, s);
-	BLMX_HIP(hipMemcpyAsync(c.h_counts.p, c.all_counts.p, per_rank * world * 8, hipMemcpyDeviceToHost, s));
-	BLMX_HIP(hipStreamSynchronize(s));
-	const uint64_t* all = c.h_counts.as<uint64_t>();  // all[r * per_rank + p * world + d] = k-mers rank r sends to rank d in piece p
+	// ---- formats and per-owner counts of all pieces (+ one "cannot take part" flag) in one all-gather
+	const size_t per_piece = (size_t)world + 1, per_rank = (size_t)pieces * per_piece + 1;
+	std::vector<uint64_t> mine(per_rank, 0), all(per_rank * world, 0);
+	for (int p = 0; p < pieces && local.code == BLMX_OK; p++) {
+		mine[(size_t)p * per_piece] = slots_fmt[p] ? 1 : 0;
+		for (uint32_t r = 0; r < world; r++)
+			mine[(size_t)p * per_piece + 1 + r] = slots_fmt[p] ? (uint64_t)(c.sp[p].seg()[r + 1] - c.sp[p].seg()[r]) : c.h_dense.as<uint64_t>()[(size_t)p * world + r];
+	}
+	mine[per_rank - 1] = local.code != BLMX_OK;
+	all_gather_host(c, mine.data(), per_rank, all.data(), s);
 	for (uint32_t r = 0; r < world; r++)
 		if (all[(size_t)r * per_rank + per_rank - 1]) {
 			if (local.code != BLMX_OK)
 				throw local;
 			throw StatusError{BLMX_ERCCL, "sharded query: another rank could not take part"};
 		}
-	uint64_t send_cnt[kMaxPieces][16], recv_cnt[kMaxPieces][16], recv_total[kMaxPieces];
+	auto fmt_of = [&](uint32_t r, int p) { return all[(size_t)r * per_rank + (size_t)p * per_piece] != 0; };
+	auto cnt_of = [&](uint32_t r, int p, uint32_t d) { return all[(size_t)r * per_rank + (size_t)p * per_piece + 1 + d]; };
+	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
+	const size_t idw = narrow ? 1 : 2;  // 32-bit words per slot of a returned slot range
+	struct Flows {
+		uint64_t ks[16], kr[16], ms[16], mr[16], hs[16], hr[16], is[16], ir[16];  // k-mers / minimizers / headers out and in, IDs back out and in (counts)
+		uint64_t recv_k_words, recv_m_words, recv_h_words, ids_words;
+	} F[kMaxPieces];
+	// header words a sender has for owner d: one per bin of d plus the end of its last region; the bin geometry follows from the shard
+	// boundaries and the index parameters, so it is the same on every rank (also on one that sends densely itself)
+	const uint32_t my_nb = slot_owner_bins(ix, me);
 	for (int p = 0; p < pieces; p++) {
-		recv_total[p] = 0;
-		for (uint32_t r = 0; r < world; r++) {
-			send_cnt[p][r] = all[(size_t)me * per_rank + (size_t)p * world + r];
-			recv_cnt[p][r] = all[(size_t)r * per_rank + (size_t)p * world + me];
-			recv_total[p] += recv_cnt[p][r];
-		}
-		for (uint32_t d = 0; d < world; d++) {  // every rank sees the same matrix: all of them give up together
-			uint64_t to_d = 0;
+		for (uint32_t d = 0; d < world; d++) {
+			uint64_t to_d = 0;  // every rank sees the same matrix: all of them give up together
 			for (uint32_t r = 0; r < world; r++)
-				to_d += all[(size_t)r * per_rank + (size_t)p * world + d];
+				to_d += cnt_of(r, p, d);
 			if (to_d >= 0xffffffffull)
-				throw StatusError{BLMX_ELIMIT, "an owner receives fewer than 2^32 - 1 k-mers per piece"};
+				throw StatusError{BLMX_ELIMIT, "an owner receives fewer than 2^32 - 1 k-mers (or slots) per piece"};
 		}
-		grow(c.recv_k[p], recv_total[p] * 8 * kw + 16, s);
-		grow(c.ids_remote[p], recv_total[p] * 8 + 16, s);
-		grow(c.ids_sorted[p], (cut[p + 1] - cut[p]) * 8 + 16, s);
+	}
+	for (int p = 0; p < pieces; p++) {
+		Flows& f = F[p];
+		f.recv_k_words = f.recv_m_words = f.recv_h_words = f.ids_words = 0;
+		for (uint32_t r = 0; r < world; r++) {
+			const bool out_slots = slots_fmt[p], in_slots = fmt_of(r, p);
+			const uint64_t out_n = cnt_of(me, p, r), in_n = cnt_of(r, p, me);
+			const bool self = r == me;
+			// out: what I send to owner r
+			f.ks[r] = (out_slots && self) ? 0 : out_n;                               // k-mers (slots or dense), KW words each
+			f.ms[r] = (out_slots && !self) ? out_n / 2 : 0;                          // minimizers, two per word
+			f.hs[r] = (out_slots && !self) ? (uint64_t)slot_owner_bins(ix, r) + 1 : 0;
+			f.ir[r] = out_slots ? (self ? 0 : out_n * idw / 2) : out_n;              // IDs that come back from owner r (words)
+			// in: what sender r holds for me
+			f.kr[r] = (in_slots && self) ? 0 : in_n;
+			f.mr[r] = (in_slots && !self) ? in_n / 2 : 0;
+			f.hr[r] = (in_slots && !self) ? (uint64_t)my_nb + 1 : 0;
+			f.is[r] = in_slots ? (self ? 0 : in_n * idw / 2) : in_n;
+			f.recv_k_words += f.kr[r] * kw;
+			f.recv_m_words += f.mr[r];
+			f.recv_h_words += f.hr[r];
+			f.ids_words += f.is[r];
+		}
+		grow(c.recv_k[p], f.recv_k_words * 8 + 16, s);
+		grow(c.recv_m[p], f.recv_m_words * 8 + 16, s);
+		grow(c.recv_h[p], f.recv_h_words * 8 + 16, s);
+		grow(c.ids_remote[p], f.ids_words * 8 + 16, s);
+		if (!slots_fmt[p])
+			grow(c.ids_sorted[p], (cut[p + 1] - cut[p]) * 8 + 16, s);
 	}
 	BLMX_HIP(hipStreamSynchronize(s));  // buffers that grew must exist before the other stream touches them
 	// ---- the pipeline: collectives are issued in the same order on every rank (k-mers 0, k-mers 1, IDs 0, k-mers 2, IDs 1, ...)
 	auto send_kmers = [&](int p) {
+		const Flows& f = F[p];
 		BLMX_HIP(hipStreamWaitEvent(c.cs, c.ev_part[p], 0));
-		all_to_all_v(c, c.sorted[p].p, send_cnt[p], c.recv_k[p].p, recv_cnt[p], kw, c.cs);
+		uint64_t kso[16], ksw[16], krw[16], mso[16], hso[16];
+		for (uint32_t r = 0; r < world; r++) {
+			ksw[r] = f.ks[r] * kw;
+			krw[r] = f.kr[r] * kw;
+			kso[r] = mso[r] = hso[r] = 0;
+			if (slots_fmt[p]) {  // the slot range of owner r lies where the partition put it (my own range does not travel)
+				kso[r] = (uint64_t)c.sp[p].seg()[r] * kw;
+				mso[r] = (uint64_t)c.sp[p].seg()[r] / 2;
+				hso[r] = c.sp[p].first_bin[r];
+			}
+		}
+		if (slots_fmt[p]) {
+			all_to_all_v_words(c, c.sp[p].slots.p, kso, ksw, c.recv_k[p].p, nullptr, krw, c.cs);
+			all_to_all_v_words(c, c.sp[p].minis.p, mso, f.ms, c.recv_m[p].p, nullptr, f.mr, c.cs);
+			all_to_all_v_words(c, c.sp[p].hdr.p, hso, f.hs, c.recv_h[p].p, nullptr, f.hr, c.cs);
+		} else {
+			all_to_all_v_words(c, c.sorted[p].p, nullptr, ksw, c.recv_k[p].p, nullptr, krw, c.cs);
+			all_to_all_v_words(c, nullptr, nullptr, f.ms, c.recv_m[p].p, nullptr, f.mr, c.cs);  // (f.ms / f.hs are all zero for a dense sender)
+			all_to_all_v_words(c, nullptr, nullptr, f.hs, c.recv_h[p].p, nullptr, f.hr, c.cs);
+		}
 		BLMX_HIP(hipEventRecord(c.ev_k[p], c.cs));
 	};
 	send_kmers(0);
 	for (int p = 0; p < pieces; p++) {
+		const Flows& f = F[p];
 		if (p + 1 < pieces)
 			send_kmers(p + 1);  // the next piece travels while this one is answered
 		BLMX_HIP(hipStreamWaitEvent(s, c.ev_k[p], 0));
-		launch_query_partitioned(ix, c.recv_k[p].p, recv_total[p], c.ids_remote[p].as<int64_t>(), s);
+		// the owner's side: slot ranges (mine in place, the others' from the receive buffers) in one launch, dense segments one by one
+		ForeignSlots fsrc[16];
+		uint32_t nsrc = 0;
+		uint64_t ko = 0, mo = 0, ho = 0, io = 0;  // word offsets of source r in the receive buffers / in the IDs that go back
+		for (uint32_t r = 0; r < world; r++) {
+			const uint64_t in_n = cnt_of(r, p, me);
+			if (fmt_of(r, p)) {
+				ForeignSlots fs;
+				if (r == me) {
+					const uint32_t s0 = c.sp[p].seg()[me];
+					fs.slots = c.sp[p].slots.as<uint64_t>() + (size_t)s0 * kw;
+					fs.minis = c.sp[p].minis.as<uint32_t>() + s0;
+					fs.ids = c.sp[p].ids.as<char>() + (size_t)s0 * 4 * idw;
+					fs.hdr = c.sp[p].hdr.as<uint64_t>() + c.sp[p].first_bin[me];
+				} else {
+					fs.slots = c.recv_k[p].as<uint64_t>() + ko;
+					fs.minis = reinterpret_cast<const uint32_t*>(c.recv_m[p].as<uint64_t>() + mo);
+					fs.ids = c.ids_remote[p].as<uint64_t>() + io;
+					fs.hdr = c.recv_h[p].as<uint64_t>() + ho;
+				}
+				fs.nslots = (uint32_t)in_n;
+				fs.nb = my_nb;
+				fsrc[nsrc++] = fs;
+			} else if (in_n) {
+				launch_query_partitioned(ix, c.recv_k[p].as<uint64_t>() + ko, in_n, reinterpret_cast<int64_t*>(c.ids_remote[p].as<uint64_t>() + io), s);
+			}
+			ko += f.kr[r] * kw;
+			mo += f.mr[r];
+			ho += f.hr[r];
+			io += f.is[r];
+		}
+		launch_query_foreign_slots(ix, fsrc, nsrc, narrow, s);
 		BLMX_HIP(hipEventRecord(c.ev_q[p], s));
 		BLMX_HIP(hipStreamWaitEvent(c.cs, c.ev_q[p], 0));
-		all_to_all_v(c, c.ids_remote[p].p, recv_cnt[p], c.ids_sorted[p].p, send_cnt[p], 1, c.cs);
+		if (slots_fmt[p]) {  // the IDs of owner r's range come back into the range itself
+			uint64_t ioff[16];
+			for (uint32_t r = 0; r < world; r++)
+				ioff[r] = (uint64_t)c.sp[p].seg()[r] * idw / 2;
+			all_to_all_v_words(c, c.ids_remote[p].p, nullptr, f.is, c.sp[p].ids.p, ioff, f.ir, c.cs);
+		} else {
+			all_to_all_v_words(c, c.ids_remote[p].p, nullptr, f.is, c.ids_sorted[p].p, nullptr, f.ir, c.cs);
+		}
 		BLMX_HIP(hipEventRecord(c.ev_i[p], c.cs));
 	}
 	for (int p = 0; p < pieces; p++) {
 		BLMX_HIP(hipStreamWaitEvent(s, c.ev_i[p], 0));
-		launch_gather_ids(ix, c.ids_sorted[p].as<int64_t>(), c.inv[p].as<uint32_t>(), cut[p + 1] - cut[p], d_ids + cut[p], s);
+		if (slots_fmt[p])
+			slot_piece_gather(ix, c.sp[p], d_ids + cut[p], s);
+		else
+			launch_gather_ids(ix, c.ids_sorted[p].as<int64_t>(), c.inv[p].as<uint32_t>(), cut[p + 1] - cut[p], d_ids + cut[p], s);
 	}
 	ix.number_query.fetch_add(nq, std::memory_order_relaxed);
 }
@@ -798,7 +947,7 @@ void query_kmers_sharded_host(Index& ix, Comm& c, const void* kmers, uint64_t nq
 	grow(ix.q_out, nq * 8 + 16, s);
 	if (nq)
 		BLMX_HIP(hipMemcpyAsync(ix.q_in.p, kmers, nq * kb, hipMemcpyHostToDevice, s));
-	query_kmers_sharded(ix, c, ix.q_in.p, nq, ix.q_out.as<int64_t>(), s);
+	query_kmers_sharded(ix, c, ix.q_in.p, nullptr, nq, ix.q_out.as<int64_t>(), s);
 	if (nq)
 		BLMX_HIP(hipMemcpyAsync(ids_out, ix.q_out.p, nq * 8, hipMemcpyDeviceToHost, s));
 	BLMX_HIP(hipStreamSynchronize(s));

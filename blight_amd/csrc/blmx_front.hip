@@ -561,7 +561,7 @@ void query_sequences_sharded_device(Index& ix, Comm& c, const uint8_t* d_chars, 
 	// a rank whose own batch cannot be taken still joins the collective (with no k-mers, or -- index not built -- with the failure
 	// flag of query_kmers_sharded), so that the others do not wait for it; it reports its error afterwards
 	if (!ix.built || total >= 0xffffffc0ull) {
-		query_kmers_sharded(ix, c, nullptr, 0, d_ids, s);
+		query_kmers_sharded(ix, c, nullptr, nullptr, 0, d_ids, s);
 		throw StatusError{BLMX_ELIMIT, "a device-resident batch holds fewer than 2^32 characters"};
 	}
 	HostFront& hf = host_front(ix);
@@ -581,7 +581,7 @@ void query_sequences_sharded_device(Index& ix, Comm& c, const uint8_t* d_chars, 
 		front_valid_concat(ix, hf.dev_fs, d_offs, nseq + 1, 0, total, total, s);
 		launch_read_front(ix, &hf.dev_fs, d_chars, total, total, nullptr, nullptr, 0, hf.dev_kmers.p, hf.dev_minis.as<uint32_t>(), d_err, s);
 	}
-	query_kmers_sharded(ix, c, hf.dev_kmers.p, nk, d_ids, s);  // every rank takes part, also with an empty batch
+	query_kmers_sharded(ix, c, hf.dev_kmers.p, hf.dev_minis.as<uint32_t>(), nk, d_ids, s);  // every rank takes part, also with an empty batch
 	BLMX_HIP(hipEventRecord(hf.dev_done, s));
 	hf.dev_last = s;
 	hf.dev_used = true;
@@ -593,7 +593,7 @@ void query_sequences_sharded_host(Index& ix, Comm& c, const char* concat, const 
 	BLMX_HIP(hipSetDevice(ix.prm.device));
 	const uint64_t total = nseq ? offsets[nseq] : 0;
 	if (nseq && offsets[0] != 0) {  // (collective: take part with an empty batch, then report)
-		query_kmers_sharded(ix, c, nullptr, 0, nullptr, ix.stream);
+		query_kmers_sharded(ix, c, nullptr, nullptr, 0, nullptr, ix.stream);
 		throw StatusError{BLMX_EINVAL, "offsets[0] must be 0"};
 	}
 	const uint64_t k = ix.prm.k;

@@ -277,8 +277,10 @@ struct Index {
 	// staging for host-buffer queries
 	DevBuf q_in, q_aux, q_out;
 	// scratch of the locality-binned batch query (grow-only; guarded by bin_mu)
-	DevBuf b_bins, b_minis, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp, b_plan, b_frac;
+	DevBuf b_bins, b_minis, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp, b_plan, b_frac, b_pstats;
 	int plan_bits = -1;  // bin count (log2) the learnt shares in b_frac belong to, -1 = nothing learnt yet
+	uint32_t plan_nbins_sharded = 0;  // the same for the sharded exchange (bins split at the shard boundaries): bins of b_frac_sharded
+	DevBuf b_frac_sharded;
 	std::mutex bin_mu;
 	hipEvent_t bin_done = nullptr;       // recorded after each binned pipeline: a call on another stream waits for it
 	hipStream_t bin_last_stream = nullptr;
@@ -307,6 +309,7 @@ struct Index {
 	int tune_filter_bits = -1;   // bits per key of the filter built at construction (0 = build none, -1 = automatic: 8, or 16 with the
 	                             // position hint of the wide windows; BLIGHT_FILTER_BITS)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
+	int tune_slot_piece_min = 0; // sharded exchange: pieces of at least this many k-mers travel as bin regions (0 = default 2^19; tests lower it)
 
 	Index()
 	{
@@ -387,6 +390,34 @@ void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorte
 void launch_query_partitioned(Index& ix, const void* d_sorted_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s);
 void launch_gather_ids(Index& ix, const int64_t* d_ids_sorted, const uint32_t* d_inv, uint64_t nq, int64_t* d_out, hipStream_t s);
 void launch_kmer_groups(const Index& ix, const void* d_kmers, uint64_t nq, uint32_t* d_groups, hipStream_t s);
+// ---- the one-pass partition as the sender's side of the sharded exchange (blmx_query.hip).  A piece of a batch is partitioned into
+// bin regions (slots) exactly like a single-GPU batch; the bins are split at the shard boundaries, so the regions of owner r's bins
+// are ONE contiguous slot range [seg[r], seg[r + 1]) that travels as it is (k-mers, their minimizers, and a header word per bin:
+// first slot | slots used); the owner answers the used slots of every bin (launch_query_foreign_slots) and the IDs come back into the
+// same slot range, narrow (4 B) when every ID fits; k_gather_runs then brings them into the caller's order.
+struct SlotPiece {
+	DevBuf slots, minis, ids, lpos, plan, cursors, hdr, info;
+	Pinned h_info;         // after a stream synchronisation: [0] k-mers in the overflow region, [1 + r] = seg[r] for r = 0 .. world
+	uint64_t nq = 0, max_main = 0;
+	uint32_t nbins = 0, nblk = 0, tile = 0, world = 1;
+	bool narrow = false;
+	uint32_t first_bin[17] = {};
+	size_t lpos_bytes = 0, runs = 0;
+	const uint32_t* seg() const { return h_info.as<uint32_t>() + 1; }
+	uint32_t overflow() const { return h_info.as<uint32_t>()[0]; }
+};
+bool slot_piece_possible(const Index& ix, uint64_t n);
+uint32_t slot_owner_bins(const Index& ix, uint32_t owner);  // bins of the sharded partition that belong to `owner` (the same on every rank)
+void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const uint32_t* d_minis, uint64_t n, hipStream_t s);
+struct ForeignSlots {       // what an owner answers: the slot range one sender holds for it
+	const uint64_t* slots;  // k-mers (KW words each), slot 0 = the sender's slot seg[me]
+	const uint32_t* minis;
+	void* ids;              // out: one word per slot (4 B narrow / 8 B)
+	const uint64_t* hdr;    // nb + 1 words: low half = first slot of the bin's region (sender's numbering), high half = slots used
+	uint32_t nslots, nb;
+};
+void launch_query_foreign_slots(Index& ix, const ForeignSlots* src, uint32_t nsrc, bool narrow, hipStream_t s);
+void slot_piece_gather(Index& ix, SlotPiece& sp, int64_t* d_out, hipStream_t s);
 // same with the minimizers already known (read front end): the partition pass reads them instead of hashing 23 m-mers per
 // k-mer, and they travel with the k-mers to the query kernel
 void launch_query_ids_with_minis(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, hipStream_t s);
@@ -436,7 +467,7 @@ void query_sequences_sharded_device(Index& ix, Comm& c, const uint8_t* d_chars, 
                                     int64_t* d_ids, int* d_err, hipStream_t s);
 void query_sequences_sharded_host(Index& ix, Comm& c, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
 void load_fasta_to_device(Index& ix, const char* path, DevBuf& d_ascii, std::vector<uint64_t>& offs, uint64_t& total_out);
-void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, uint64_t nq, int64_t* d_ids, hipStream_t s);
+void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_ids, hipStream_t s);
 // streaming front end (blmx_stream.hip)
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous);
 void build_from_fasta_streamed(Index& ix, const char* path);

@@ -619,11 +619,20 @@ __global__ __launch_bounds__(1 << kBinBitsMax) void k_plan_make(const float* __r
 		cursors[nbins] = 0;  // the overflow cursor (with 1024 bins there is no thread number nbins)
 }
 // what the capacities of the next batch are made from: this batch's k-mers per bin
-__global__ void k_plan_learn(const uint32_t* __restrict__ cursors, uint64_t nq, uint32_t nbins, float* __restrict__ frac)
+// stats (may be null): [0] one-pass batches, [1] their k-mers, [2] k-mers that went through the overflow region, [3] the largest
+// overflow of a batch -- what blmx_partition_stats reports (a learnt plan applied to a batch it was not learnt from overflows a little)
+__global__ void k_plan_learn(const uint32_t* __restrict__ cursors, uint64_t nq, uint32_t nbins, float* __restrict__ frac, unsigned long long* __restrict__ stats)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t < nbins)
+	if (t < nbins && nq)
 		frac[t] = (float)((double)cursors[t] / (double)nq);
+	if (t == 0 && stats) {
+		const unsigned long long ovf = cursors[nbins];
+		stats[0] += 1;
+		stats[1] += nq;
+		stats[2] += ovf;
+		stats[3] = max(stats[3], ovf);
+	}
 }
 __global__ void k_plan_learn_offs(const uint32_t* __restrict__ offs, uint32_t nblk, uint64_t nq, uint32_t nbins, float* __restrict__ frac)
 {
@@ -930,13 +939,16 @@ static void ensure_buf(DevBuf& b, size_t bytes, hipStream_t s)
 }
 
 // per-owner k-mer counts of a partitioned batch: owner r holds bins [first_bin[r], first_bin[r + 1])
-__global__ void k_rank_counts(const uint32_t* __restrict__ offs, uint32_t nblk, uint32_t nbins, uint64_t nq, uint32_t world,
-                              const uint32_t* __restrict__ first_bin, uint64_t* __restrict__ counts)
+struct OwnerBins {
+	uint32_t fb[18];
+};
+__global__ void k_rank_counts(const uint32_t* __restrict__ offs, uint32_t nblk, uint32_t nbins, uint64_t nq, uint32_t world, OwnerBins first_bin,
+                              uint64_t* __restrict__ counts)
 {
 	const uint32_t r = threadIdx.x;
 	if (r >= world)
 		return;
-	const uint32_t b0 = first_bin[r], b1 = first_bin[r + 1];
+	const uint32_t b0 = first_bin.fb[r], b1 = first_bin.fb[r + 1];
 	const uint64_t a = b0 >= nbins ? nq : offs[(uint64_t)b0 * nblk], z = b1 >= nbins ? nq : offs[(uint64_t)b1 * nblk];
 	counts[r] = z - a;
 }
@@ -1177,7 +1189,9 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	}
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(6, s);
-	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>());
+	if (!ix.b_pstats.p)
+		BLMX_HIP(ix.b_pstats.alloc(64, true, s));
+	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>(), ix.b_pstats.as<unsigned long long>());
 	ix.plan_bits = tbits;
 	update_filter_gate(ix, d_out, nq, s);
 	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 2) {  // bin occupancy of this batch (synchronises)
@@ -1194,6 +1208,227 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 		fprintf(stderr, "[blmx partition] nq %llu bins %u learnt %d main slots %u (bound %llu) min %u max %u overflow %u\n", (unsigned long long)nq, nbins,
 		        (int)learnt, hp.main_slots, (unsigned long long)max_main, mn, mx, h[nbins]);
 	}
+}
+
+// ---- the one-pass partition as the sender's side of the sharded exchange (SlotPiece, blmx_internal.h) -------------------------------
+// pieces below this size go through the exact partition and travel densely: the regions' slack (256 slots per bin and more) would
+// outweigh them
+constexpr uint64_t kMinSlotPiece = 1ull << 19;
+
+bool slot_piece_possible(const Index& ix, uint64_t n)
+{
+	const int mbits = 2 * (int)ix.prm.m - 1;
+	const uint64_t least = ix.tune_slot_piece_min > 0 ? (uint64_t)ix.tune_slot_piece_min : kMinSlotPiece;
+	return ix.tune_partition != 2 && ix.prm.bits_saved <= 8 && mbits >= 4 && n >= least && n < 1900000000ull && ix.plan_nbins_sharded != 0 &&
+	       ix.shard_world <= 16;
+}
+
+struct FirstBins {
+	uint32_t world;
+	uint32_t fb[17];
+};
+// header words of every bin + what the host needs before the flows can be sized (one workgroup, one thread per bin)
+__global__ __launch_bounds__(1 << kBinBitsMax) void k_slot_info(const SlotPlan* __restrict__ sp, const uint32_t* __restrict__ cursors, FirstBins f,
+                                                              uint64_t* __restrict__ hdr, uint32_t* __restrict__ info)
+{
+	const uint32_t t = threadIdx.x, nb = sp->nbins;
+	if (t < nb) {
+		const uint32_t rb = sp->base[t], cap = sp->base[t + 1] - rb;
+		hdr[t] = (uint64_t)rb | ((uint64_t)min(cursors[t], cap) << 32);
+	}
+	if (t == 0) {
+		hdr[nb] = sp->base[nb];
+		info[0] = cursors[nb];
+	}
+	if (t <= f.world)
+		info[1 + t] = sp->base[min(f.fb[t], nb)];
+}
+
+static BinMap sharded_bin_map(const Index& ix, int& tbits)
+{
+	const int mbits = 2 * (int)ix.prm.m - 1;
+	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsOnepass;
+	tbits = std::max(3, std::min(mbits, want_bits));
+	const uint32_t nbound = ix.shard_world > 1 ? ix.shard_world - 1 : 0;
+	while (tbits > 1 && (1u << tbits) + nbound > (1u << kBinBitsMax))  // the kernels hold at most 2^kBinBitsMax bins
+		tbits--;
+	BinMap bm;
+	bm.shift = mbits - tbits;
+	bm.nbound = 0;
+	for (uint32_t r = 1; r < ix.shard_world; r++)
+		bm.bound[bm.nbound++] = ix.shard_bounds[r] << ix.gshift;
+	return bm;
+}
+
+uint32_t slot_owner_bins(const Index& ix, uint32_t owner)
+{
+	int tbits;
+	const BinMap bm = sharded_bin_map(ix, tbits);
+	const uint32_t nbins = (1u << tbits) + bm.nbound, world = ix.shard_world;
+	const uint32_t lo = owner == 0 ? 0u : bm.bin_of(bm.bound[owner - 1]);
+	const uint32_t hi = owner + 1 >= world ? nbins : bm.bin_of(bm.bound[owner]);
+	return hi - lo;
+}
+
+void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const uint32_t* d_minis, uint64_t n, hipStream_t s)
+{
+	int tbits;
+	const BinMap bm = sharded_bin_map(ix, tbits);
+	const uint32_t nbins = (1u << tbits) + bm.nbound, world = ix.shard_world;
+	const bool learnt = ix.plan_nbins_sharded == nbins;
+	const uint32_t pct = ix.tune_slot_slack_pct > 0 ? (uint32_t)ix.tune_slot_slack_pct : (learnt ? 6u : 12u);
+	sp.nq = n;
+	sp.nbins = nbins;
+	sp.world = world;
+	sp.max_main = ((n + n * pct / 100 + (uint64_t)nbins * 512 + 2047) / 2048) * 2048;
+	const uint64_t slots = sp.max_main + n;
+	sp.tile = (uint32_t)(ix.KW == 1 ? BinTile<1>::value : BinTile<2>::value);
+	sp.nblk = (uint32_t)((n + sp.tile - 1) / sp.tile);
+	sp.narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
+	sp.lpos_bytes = (n * 2 + 255) & ~(size_t)255;
+	sp.runs = (size_t)sp.nblk << kBinBitsMax;
+	sp.first_bin[0] = 0;
+	for (uint32_t r = 1; r < world; r++)
+		sp.first_bin[r] = bm.bin_of(bm.bound[r - 1]);
+	sp.first_bin[world] = nbins;
+	ensure_buf(sp.slots, slots * 8 * (size_t)ix.KW, s);
+	ensure_buf(sp.minis, slots * 4, s);
+	ensure_buf(sp.ids, slots * 8, s);
+	ensure_buf(sp.lpos, sp.lpos_bytes + sp.runs * 12, s);
+	ensure_buf(sp.plan, sizeof(SlotPlan), s);
+	ensure_buf(sp.cursors, ((size_t)nbins + 1) * 4, s);
+	ensure_buf(sp.hdr, ((size_t)nbins + 2) * 8, s);
+	ensure_buf(sp.info, 128, s);
+	sp.h_info.ensure(128);
+	RunTable rt;
+	rt.gbase = reinterpret_cast<uint32_t*>(sp.lpos.as<char>() + sp.lpos_bytes);
+	rt.obase = rt.gbase + sp.runs;
+	rt.count = rt.obase + sp.runs;
+	hipLaunchKernelGGL(k_plan_make, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac_sharded.as<float>() : nullptr, n, nbins, pct, (uint32_t)sp.max_main,
+	                   (uint32_t)n, 1024u, sp.plan.as<SlotPlan>(), sp.cursors.as<uint32_t>());
+	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(sp.nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
+		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
+	else
+		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(sp.nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
+		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
+	FirstBins f;
+	f.world = world;
+	for (uint32_t r = 0; r <= world; r++)
+		f.fb[r] = sp.first_bin[r];
+	hipLaunchKernelGGL(k_slot_info, dim3(1), dim3(1 << kBinBitsMax), 0, s, sp.plan.as<SlotPlan>(), sp.cursors.as<uint32_t>(), f, sp.hdr.as<uint64_t>(),
+	                   sp.info.as<uint32_t>());
+	BLMX_HIP(hipGetLastError());
+	BLMX_HIP(hipMemcpyAsync(sp.h_info.p, sp.info.p, 4 * (size_t)(world + 2), hipMemcpyDeviceToHost, s));
+}
+
+// The owner's kernel: every source is a slot range with gaps (the unused tails of the bin regions); a workgroup finds its source,
+// then the bin whose region holds its 256 slots (binary search over the source's header words, uniform: scalar loads) and answers the
+// slots that are in use.  XCD-major over the concatenated ranges like k_query_slots.
+struct ForeignTable {
+	uint32_t nsrc, nblocks;
+	uint32_t first_block[17];
+	ForeignSlots src[16];
+};
+template <int KW, int LOGP>
+__global__ __launch_bounds__(256) void k_query_foreign_slots(DeviceIndexView v, ForeignTable ft, int narrow)
+{
+	const uint32_t per = gridDim.x >> 3;
+	const uint32_t blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+	if (blk >= ft.nblocks)
+		return;
+	uint32_t si = 0;
+	while (si + 1 < ft.nsrc && blk >= ft.first_block[si + 1])
+		si++;
+	const ForeignSlots& fs = ft.src[si];
+	const uint32_t first = (blk - ft.first_block[si]) << 8;  // slot inside the range
+	const uint32_t origin = (uint32_t)fs.hdr[0];             // the sender's number of the range's first slot
+	uint32_t lo = 0, hi = fs.nb;
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if ((uint32_t)fs.hdr[mid] - origin <= first)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const uint64_t h = fs.hdr[lo];
+	const uint32_t rb = (uint32_t)h - origin, used = (uint32_t)(h >> 32);
+	const uint32_t slot = first + threadIdx.x;
+	if (slot < rb + used && slot < fs.nslots)
+		query_slot<KW, LOGP>(gated_view(v), fs.slots, fs.minis, fs.ids, narrow != 0, slot);
+}
+
+void launch_query_foreign_slots(Index& ix, const ForeignSlots* src, uint32_t nsrc, bool narrow, hipStream_t s)
+{
+	ForeignTable ft{};
+	uint32_t nblocks = 0;
+	for (uint32_t i = 0; i < nsrc && ft.nsrc < 16; i++) {
+		if (src[i].nslots == 0 || src[i].nb == 0)
+			continue;
+		ft.first_block[ft.nsrc] = nblocks;
+		ft.src[ft.nsrc++] = src[i];
+		nblocks += (src[i].nslots + 255) >> 8;
+	}
+	ft.first_block[ft.nsrc] = nblocks;
+	ft.nblocks = nblocks;
+	if (nblocks == 0)
+		return;
+	const DeviceIndexView v = ix.view();
+	const unsigned grid = (nblocks + 7u) & ~7u;
+#define BLMX_QF(LP)                                                                                                            \
+	case LP:                                                                                                                   \
+		if (ix.KW == 1)                                                                                                        \
+			hipLaunchKernelGGL((k_query_foreign_slots<1, LP>), dim3(grid), dim3(256), 0, s, v, ft, (int)narrow);               \
+		else                                                                                                                   \
+			hipLaunchKernelGGL((k_query_foreign_slots<2, LP>), dim3(grid), dim3(256), 0, s, v, ft, (int)narrow);               \
+		break;
+	switch (v.b) {
+		BLMX_QF(0)
+		BLMX_QF(1)
+		BLMX_QF(2)
+		BLMX_QF(3)
+		BLMX_QF(4)
+		BLMX_QF(5)
+		BLMX_QF(6)
+		BLMX_QF(7)
+		BLMX_QF(8)
+	default:
+		throw StatusError{BLMX_EINVAL, "internal: the slot pipeline needs bits_to_save <= 8"};
+	}
+#undef BLMX_QF
+	BLMX_HIP(hipGetLastError());
+}
+
+// IDs of the piece (they sit in sp.ids, slot by slot, wherever they were answered) -> the caller's order; this batch's shares become
+// the next plan; the filter gate follows this batch's answers
+void slot_piece_gather(Index& ix, SlotPiece& sp, int64_t* d_out, hipStream_t s)
+{
+	RunTable rt;
+	rt.gbase = reinterpret_cast<uint32_t*>(sp.lpos.as<char>() + sp.lpos_bytes);
+	rt.obase = rt.gbase + sp.runs;
+	rt.count = rt.obase + sp.runs;
+	const SlotPlan* d_plan = sp.plan.as<SlotPlan>();
+	const uint16_t* d_lpos = sp.lpos.as<uint16_t>();
+	if (ix.KW == 1) {
+		if (sp.narrow)
+			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, true>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+		else
+			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, false>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+	} else {
+		if (sp.narrow)
+			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, true>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+		else
+			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, false>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+	}
+	BLMX_HIP(hipGetLastError());
+	ensure_buf(ix.b_frac_sharded, sizeof(float) << kBinBitsMax, s);
+	if (!ix.b_pstats.p)
+		BLMX_HIP(ix.b_pstats.alloc(64, true, s));
+	hipLaunchKernelGGL(k_plan_learn, dim3((sp.nbins + 255) / 256), dim3(256), 0, s, sp.cursors.as<uint32_t>(), sp.nq, sp.nbins, ix.b_frac_sharded.as<float>(),
+	                   ix.b_pstats.as<unsigned long long>());
+	ix.plan_nbins_sharded = sp.nbins;
+	update_filter_gate(ix, d_out, sp.nq, s);
 }
 
 // d_minis: minimizers of the k-mers when the caller already has them (read front end), else nullptr
@@ -1275,21 +1510,23 @@ void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorte
 	}
 	std::lock_guard<std::mutex> lock(ix.bin_mu);
 	partition_begin(ix, s);
-	const PartitionPlan pl = partition_batch(ix, d_kmers, nullptr, nq, true, d_sorted, nullptr, d_inv, s);
+	// the same bins as the one-pass partition of the sharded exchange, which learns its region sizes from this pass
+	const PartitionPlan pl = partition_batch(ix, d_kmers, nullptr, nq, true, d_sorted, nullptr, d_inv, s, ix.tune_partition == 2 ? kBinBitsDefault : kBinBitsOnepass);
 	ix.staged_tile = pl.tile;
 	if (d_rank_counts) {
-		uint32_t first_bin[18];
-		first_bin[0] = 0;
+		OwnerBins ob{};  // the bins of owner r start at bin_of(its first minimizer); by value: nothing of this frame is read later
+		ob.fb[0] = 0;
 		for (uint32_t r = 1; r < world; r++)
-			first_bin[r] = pl.bm.bin_of(pl.bm.bound[r - 1]);
-		first_bin[world] = pl.nbins;
-		ensure_buf(ix.b_tmp, 4096, s);
-		// the bins of owner r start at bin_of(its first minimizer); staged through the (now idle) scan scratch
-		BLMX_HIP(hipMemcpyAsync(ix.b_tmp.p, first_bin, 4 * (size_t)(world + 1), hipMemcpyHostToDevice, s));
-		hipLaunchKernelGGL(k_rank_counts, dim3(1), dim3(64), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, pl.nbins, nq, world,
-		                   ix.b_tmp.as<uint32_t>(), d_rank_counts);
+			ob.fb[r] = pl.bm.bin_of(pl.bm.bound[r - 1]);
+		ob.fb[world] = pl.nbins;
+		hipLaunchKernelGGL(k_rank_counts, dim3(1), dim3(64), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, pl.nbins, nq, world, ob, d_rank_counts);
 		BLMX_HIP(hipGetLastError());
-		BLMX_HIP(hipStreamSynchronize(s));  // first_bin lives on this stack frame
+	}
+	if (ix.tune_partition != 2 && ix.prm.bits_saved <= 8) {  // what the one-pass partition of the next sharded batch sizes its regions after
+		ensure_buf(ix.b_frac_sharded, sizeof(float) << kBinBitsMax, s);
+		hipLaunchKernelGGL(k_plan_learn_offs, dim3((pl.nbins + 255) / 256), dim3(256), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, nq, pl.nbins,
+		                   ix.b_frac_sharded.as<float>());
+		ix.plan_nbins_sharded = pl.nbins;
 	}
 	partition_end(ix, s);
 }

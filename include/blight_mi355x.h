@@ -311,6 +311,9 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
  *   "query_heads"    0: query kernels read the full group descriptor instead of the compact head
  *   "reads_mode"     sequence / file queries: 0 automatic, 1 front end fused with the query body, 2 front end -> partitioned pipeline
  *   "window_kb"      KiB of characters per front-end window
+ *   "slot_piece_min" sharded exchange: pieces of a batch with at least this many k-mers travel as the one-pass partition's bin regions
+ *                    (k-mers + minimizers out, 4-byte IDs back); smaller ones, and the first batch of an index, as dense per-owner
+ *                    segments (0 = default 2^19).  The same on every rank is not required: the format travels with the counts.
  *   "narrow_ids"     0: host-buffer results cross PCIe as 64-bit words even when every ID fits 32 bits
  *   "query_binning"  as blmx_set_query_binning
  *   "filter_junctions"  test hook: 0 skips the filter's second pass (the filter then loses the reference's false positives) */

@@ -97,11 +97,14 @@ def test_native_exchange_on_the_loopback_transport(world, k, m, n, b):
         assert not [f for f in s1 if f not in ("build_seconds", "number_query") and s1[f] != s2[f]], [(r, f, s1[f], s2[f]) for f in s1 if s1[f] != s2[f]]
         ixs[r].set_tuning("absent_filter", 1)
 
-    # ---- the query exchange: 1..4 pieces, whole flows and flows cut into many ragged rounds
-    for pieces, flow_words in ((2, 1 << 25), (1, 997), (3, 4099), (4, 1 << 25)):
-        for c in comms:
+    # ---- the query exchange: 1..4 pieces, whole flows and flows cut into many ragged rounds; pieces that travel densely (the exact
+    # partition: the first batch of an index, small pieces) and as bin regions of the one-pass partition (slot_piece_min lowered so that
+    # these small batches qualify; rank 0 keeps the default, i.e. sends densely while the others send regions: formats mix)
+    for pieces, flow_words, slot_min in ((2, 1 << 25, 0), (1, 997, 2000), (3, 4099, 2000), (4, 1 << 25, 2000), (2, 1 << 25, 2000)):
+        for r, c in enumerate(comms):
             c.set_tuning("pieces", pieces)
             c.set_tuning("flow_words", flow_words)
+            ixs[r].set_tuning("slot_piece_min", slot_min if (r > 0 or pieces == 2) else 0)
 
         def query(r):
             n_r = qcuts[r + 1] - qcuts[r]
@@ -113,6 +116,28 @@ def test_native_exchange_on_the_loopback_transport(world, k, m, n, b):
         assert not any(err), err
         for r in range(world):
             assert np.array_equal(got[r], want[qcuts[r]:qcuts[r + 1]]), (pieces, flow_words, r, int((got[r] != want[qcuts[r]:qcuts[r + 1]]).sum()))
+
+    # ---- a batch unlike its predecessor (one k-mer, many times): the learnt regions overflow, that piece falls back to the exact
+    # partition on its sender alone; the batch after it goes through the regions again
+    nrep = 60000
+    first = [min(qcuts[r], len(q) - 1) for r in range(world)]
+    d_rep = [torch.from_numpy(np.tile(q[first[r]:first[r] + 1], (nrep, 1)).view(np.int64).copy()).to(dev) for r in range(world)]
+    d_rep_ids = [torch.full((nrep,), -7, dtype=torch.int64, device=dev) for _ in range(world)]
+    torch.cuda.synchronize()
+
+    def repeated(r):
+        comms[r].query_kmers_sharded_device(ixs[r], d_rep[r].data_ptr(), nrep, d_rep_ids[r].data_ptr(), streams[r].cuda_stream)
+        streams[r].synchronize()
+        return d_rep_ids[r].cpu().numpy()
+
+    got, err = run_ranks(world, repeated)
+    assert not any(err), err
+    for r in range(world):
+        assert (got[r] == want[first[r]]).all(), r
+    got, err = run_ranks(world, query)
+    assert not any(err), err
+    for r in range(world):
+        assert np.array_equal(got[r], want[qcuts[r]:qcuts[r + 1]]), r
 
     # ---- host-buffer collectives: k-mers, and whole sequences through this rank's read front end
     reads = seqs[:200] + [_rand_seq(rng, 200) for _ in range(40)] + ["ACG"]
