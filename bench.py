@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads of the sequence front-end leg (0 = skip)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-buffer / file / per-read-call measurements")
+    ap.add_argument("--batches", type=int, default=4, help="independently seeded query batches rotated through the timed loop")
+    ap.add_argument("--no-fasta-leg", action="store_true", help="skip construct_index(file) on files written to tmpfs")
     return ap.parse_args()
 
 
@@ -315,18 +317,35 @@ def stage_profile(ix, fn, reps=5):
 
 
 def roofline_block(args, k, kw, b, nq, stages, step_ms, st):
-    """`roofline` of the JSON line: the dominant kernel (k_query) + the whole pipeline + what the PMC summary adds"""
+    """`roofline` of the JSON line: the kernel that takes the largest share of a step (by HIP events on the launching stream), with ITS
+    algorithmic bytes; the query kernel with the reference's bytes next to it whichever dominates; the whole pipeline; and
+    what the PMC summary adds (counter traffic and its fraction of the peak)."""
     algo = ALGO_BYTES.get(k, 145)
+    kin = 8 * kw
+    # algorithmic bytes per k-mer of the passes around the query kernel: k-mer in + k-mer, minimizer, 2-B tile position and 1.5 B of run
+    # table out (partition); tile position, run table and a 4-B ID in, 8-B ID out (gather)
+    stage_info = {
+        "k_query": ("k_query_slots<%d,%d>" % (kw, b), algo, "the query body on the partitioned batch (bucket, filter, MPHF probes, position, 2^b window): latency-bound gathers"),
+        "k_bin_scatter": ("k_bin_onepass<%d>" % kw, 2 * kin + 4 + 3.5, "one-pass partition: %d m-mer hashes per k-mer, tile sort in LDS -- VALU-issue-bound, not HBM-bound" % (k - 9 + 1)),
+        "k_gather_ids": ("k_gather_runs<%d>" % (8192 // kw), 3.5 + 4 + 8, "IDs back into the caller's order through LDS"),
+    }
+    timed = {a: v for a, v in stages.items() if a in stage_info and v > 0}
+    dom = max(timed, key=timed.get) if timed else "k_query"
+    dom_ms = timed.get(dom, step_ms)
+    dname, dbytes, dwhat = stage_info[dom]
     kq_ms = stages.get("k_query", 0.0) or step_ms
-    achieved = algo * nq / (kq_ms * 1e-3) / 1e9
+    achieved = dbytes * nq / (dom_ms * 1e-3) / 1e9
+    kq_ach = algo * nq / (kq_ms * 1e-3) / 1e9
     pipe_ach = algo * nq / (step_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-           "kernel": "k_query_slots<%d,%d> (dominant kernel of the pipeline; the first batch of an index runs k_query<%d,%d,false> behind the "
-                     "exact partition)" % (kw, b, kw, b), "kernel_ms": kq_ms,
-           "algorithmic_bytes_per_query": algo, "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
+           "kernel": "%s: %s (the stage with the largest share of a step: %.3f of %.3f ms)" % (dname, dwhat, dom_ms, step_ms), "kernel_ms": dom_ms,
+           "algorithmic_bytes_per_query": dbytes, "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
            "per_kernel_ms": {a: round(v, 4) for a, v in stages.items()},
-           "pipeline": {"kernels": "k_plan_make + k_bin_onepass [stage k_bin_scatter] + k_query_slots [stage k_query] + k_gather_ids + k_plan_learn "
-                                   "(what `value` times; stages k_bin_hist / scan are empty once the bin shares are learnt)", "ms": step_ms,
+           "query_kernel": {"kernel": "k_query_slots<%d,%d>" % (kw, b), "kernel_ms": kq_ms, "algorithmic_bytes_per_query": algo, "achieved": kq_ach,
+                            "frac": kq_ach / HBM_PEAK_GBS, "note": "the reference's bytes per query (SURVEY 8d) over the query kernel's time; the absent-key "
+                            "filter makes the kernel move fewer bytes than that: see traffic_frac"},
+           "pipeline": {"kernels": "k_plan_make + k_bin_onepass [stage k_bin_scatter] + k_query_slots [stage k_query] + k_gather_runs [stage k_gather_ids] + "
+                                   "k_plan_learn (what `value` times; stages k_bin_hist / scan are empty once the bin shares are learnt)", "ms": step_ms,
                         "achieved": pipe_ach, "frac": pipe_ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": pipe_ach / HBM_COPY_GBS}}
     pmc = load_pmc(args.workload)
     if pmc and not args.skew and not args.kmers and not args.queries and args.present == 0.5:
@@ -334,12 +353,20 @@ def roofline_block(args, k, kw, b, nq, stages, step_ms, st):
         out["pmc"] = {"file": pmc["file"], "source_digest_matches": pmc.get("source_digest") == source_digest()}
         cands = [(v.get("trace_avg_ns", 0.0) * v.get("trace_calls", 1), name) for name, v in kern.items() if name.startswith("k_query")]
         kq = kern[max(cands)[1]] if cands else None
+        dk = [v for name, v in kern.items() if name.startswith(dname.split("<")[0])]
+        if dk:  # counter traffic of the dominant kernel: coalesced streams count at half their bytes in FETCH_SIZE on gfx950
+            corr = 2.0 if dom == "k_bin_scatter" else 1.0
+            out["traffic"] = dk[0]["fetch_bytes"] * corr + dk[0]["write_bytes"]
+            out["traffic_frac"] = out["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if kq:
             out["pmc"]["kernel"] = max(cands)[1]
             # FETCH_SIZE counts a coalesced 16-B-per-lane stream at half its bytes on gfx950 (MI355X_MICROARCH.md) and random
             # 64-B lines exactly (tools/gather_ceiling): k_query's traffic is divergent line accesses -> no correction
-            out["traffic"] = kq["fetch_bytes"] + kq["write_bytes"]
+            out["query_kernel"]["traffic"] = kq["fetch_bytes"] + kq["write_bytes"]
+            out["query_kernel"]["traffic_frac"] = out["query_kernel"]["traffic"] / (kq_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["pmc"]["k_query_hbm_lines_per_query"] = kq["fetch_bytes"] / 64.0 / nq
+            if kq.get("l2_read_requests"):
+                out["pmc"]["k_query_l1_to_l2_requests_per_query"] = kq["l2_read_requests"] / nq
             if kq.get("valu_insts"):
                 # VALU issue: wave-instructions x 4 cycles (measured integer rate, profiles/r01_valu_rate.jsonl: 3.1-4.65e13
                 # lane-ops/s chip-wide) over the SIMD cycles of the kernel
@@ -352,7 +379,7 @@ def roofline_block(args, k, kw, b, nq, stages, step_ms, st):
                 out["frac_of_gather_ceiling"] = kq["fetch_bytes"] / 64.0 / (kq_ms * 1e-3) / ceil
         tot = 0.0
         for name, v in kern.items():  # the partition passes read wide coalesced streams: FETCH_SIZE counts those at half their bytes
-            if not name.startswith(("k_bin_onepass", "k_query_slots", "k_gather_ids", "k_plan_")):
+            if not name.startswith(("k_bin_onepass", "k_query_slots", "k_gather_runs", "k_plan_")):
                 continue  # kernels of the first (exact) batch are not part of a steady-state step
             tot += v["fetch_bytes"] * (2.0 if name.startswith(("k_bin_hist", "k_bin_scatter", "k_bin_onepass")) else 1.0) + v["write_bytes"]
         out["pipeline"]["traffic"] = tot
@@ -450,6 +477,101 @@ def reads_leg(torch, B, ix, dev, ascii_, total, k, args, orc):
     return out
 
 
+def write_fasta(torch, dev, ascii_, offs, nu, path):
+    """the first `nu` unitigs as 2-line FASTA records (">\n<sequence>\n": the reference's reader skips the header line, blight.cpp:212-229),
+    assembled on the device chunk by chunk and written to `path`; returns the file size"""
+    import numpy as np
+    nl, gt = 10, 62
+    size = 0
+    step = 1 << 21  # unitigs per chunk (~230 MB of text)
+    with open(path, "wb") as f:
+        for u0 in range(0, nu, step):
+            u1 = min(nu, u0 + step)
+            o = offs[u0:u1 + 1]
+            base = int(o[0].item())
+            L = int(o[-1].item()) - base
+            out = torch.empty(L + 3 * (u1 - u0), device=dev, dtype=torch.uint8)
+            rel = (o - base)                                         # start of every unitig inside the chunk's text
+            idx = torch.arange(u1 - u0, device=dev, dtype=torch.int64)
+            d0 = rel[:-1] + 3 * idx                                  # where the record of unitig i starts in the output
+            j = torch.arange(L, device=dev, dtype=torch.int64)
+            u = torch.searchsorted(rel, j, right=True) - 1
+            out[j + 3 * u + 2] = ascii_[base:base + L]
+            out[d0] = gt
+            out[d0 + 1] = nl
+            out[rel[1:] + 3 * idx + 2] = nl
+            del j, u
+            a = out.cpu().numpy()
+            a.tofile(f)
+            size += a.size
+            del out
+    return size
+
+
+def fasta_leg(torch, B, dev, ascii_, offs, k, m, n, b, kw, args):
+    """construct_index(file) (reference blight.cpp:108-125 is the reference's ONLY construction entry): plain files of the
+    C3-size prefix of the input and of the whole input on tmpfs, plus the prefix gzip-compressed; the finished index must equal the one
+    built from the same unitigs resident in HBM (counters, per-group tables, IDs of a sample of its k-mers)."""
+    import subprocess
+    import numpy as np
+    nu_all = offs.numel() - 1
+    nu_c3 = min(nu_all, WORKLOADS["C3"][4] // 80)
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    tmpdir = tempfile.mkdtemp(prefix="blight_fa_", dir=tmp)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"where": tmp}
+    cases = [("c3_size_plain", nu_c3, False), ("c3_size_gzip", nu_c3, True)]
+    if nu_all > nu_c3:
+        cases.append(("whole_input_plain", nu_all, False))
+    refs = {}
+    try:
+        for name, nu, gz in cases:
+            path = os.path.join(tmpdir, "u%d.fa" % nu)
+            if not os.path.exists(path):
+                write_fasta(torch, dev, ascii_, offs, nu, path)
+            fpath = path
+            if gz:
+                subprocess.check_call(["gzip", "-1", "-k", "-f", path])
+                fpath = path + ".gz"
+            if nu not in refs:  # the same unitigs built from HBM
+                r = B.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=dev.index or 0)
+                t0 = time.perf_counter()
+                r.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), nu, int(offs[nu].item()))
+                t_dev = time.perf_counter() - t0
+                r.set_tuning("absent_filter", 1)
+                total_n = int(offs[nu].item())
+                sq, _ = synth_queries(torch, r, dev, ascii_, offs[:nu + 1], total_n, k, 1_000_000, 99, kw, 1.0)
+                sid = torch.empty(sq.shape[0], device=dev, dtype=torch.int64)
+                r.query_kmers_device(sq.data_ptr(), sq.shape[0], sid.data_ptr(), stream)
+                torch.cuda.synchronize()
+                refs[nu] = (r.stats(), {a: r.export(a) for a in ("g_nkeys", "g_prefix", "g_posstart", "bucket_nt")}, sq, sid, t_dev)
+                r.close()
+            rst, rarr, sq, sid, t_dev = refs[nu]
+            f = B.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=dev.index or 0)
+            t0 = time.perf_counter()
+            f.construct_index(fpath)
+            secs = time.perf_counter() - t0
+            f.set_tuning("absent_filter", 1)
+            fst = f.stats()
+            got = torch.empty_like(sid)
+            f.query_kmers_device(sq.data_ptr(), sq.shape[0], got.data_ptr(), stream)
+            torch.cuda.synchronize()
+            same = all(fst[x] == rst[x] for x in ("number_kmer", "number_super_kmer", "total_nt", "largest_mphf", "positions_total_size", "fallback_keys")) and \
+                all(np.array_equal(f.export(a), rarr[a]) for a in rarr) and bool(torch.equal(got, sid)) and bool((sid >= 0).all().item())
+            fbytes = os.path.getsize(fpath)
+            out[name] = {"file_bytes": fbytes, "unitigs": nu, "kmers": fst["number_kmer"], "seconds": secs, "file_GB_per_s": fbytes / secs / 1e9,
+                         "text_GB_per_s": os.path.getsize(path) / secs / 1e9, "kmers_per_s": fst["number_kmer"] / secs,
+                         "same_unitigs_from_hbm_seconds": t_dev, "equal_to_build_from_hbm": bool(same)}
+            f.close()
+            if gz:
+                os.unlink(fpath)
+    finally:
+        for fn in os.listdir(tmpdir):
+            os.unlink(os.path.join(tmpdir, fn))
+        os.rmdir(tmpdir)
+    return out
+
+
 def host_kmer_legs(torch, ix, q, ids, kw):
     """blmx_query_kmers / blmx_query_membership on host arrays: PCIe and the host copies included"""
     import numpy as np
@@ -535,9 +657,9 @@ def main():
     t0 = time.time()
     ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
     t_build = time.time() - t0
-    t0 = time.time()
     ix.set_tuning("absent_filter", 1)  # the filter's passes run in the background after the build: the timed steps start with it armed
-    t_filter_bg = time.time() - t0
+    t_build_armed = time.time() - t0   # build + the filter's background passes: the state the timed queries run on
+    t_filter_bg = t_build_armed - t_build
     st = ix.stats()
     if rank == 0:
         log("workload %s%s: %d k-mers, %d super-k-mers, %d unitigs, %.2f GB index, gen %.1f s, build %.2f s (%.1f M k-mers/s)" % (
@@ -545,8 +667,14 @@ def main():
             t_gen, t_build, st["number_kmer"] / t_build / 1e6))
 
     # ---- queries (per rank, resident in HBM)
-    q, is_pos = synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank, kw, args.present)
-    ids = torch.empty(nq, device=dev, dtype=torch.int64)
+    # several independently seeded batches rotate through the warm-up and the timed loop: the one-pass partition sizes its bin regions
+    # after the PREVIOUS batch and the filter gate follows the previous batch's answers, so neither is ever applied to the batch it was
+    # learnt from
+    nbatch = max(1, args.batches)
+    batches = [synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank + 1000 * j, kw, args.present) for j in range(nbatch)]
+    q, is_pos = batches[0]
+    ids_all = [torch.empty(nq, device=dev, dtype=torch.int64) for _ in range(nbatch)]
+    ids = ids_all[0]
     torch.cuda.synchronize()
 
     querier = None   # torch.distributed exchange (blight_amd/dist.py): fallback of the native one
@@ -599,39 +727,68 @@ def main():
             effective_mode = "sharded (native RCCL exchange behind the C ABI)"
     sharded = comm is not None or querier is not None
     slice_leg = comm is not None and not args.no_slice_build
-    keep_input = (sharded and not args.no_replicas_leg) or slice_leg or (not multi and args.reads > 0)
+    keep_input = (sharded and not args.no_replicas_leg) or slice_leg or not multi  # single GPU: the excursion, reads and FASTA legs draw from it
     if not keep_input:
         del ascii_
 
     if comm is not None:
-        def step():  # partition -> all-to-all-v (RCCL/xGMI) -> owner's k_query -> all-to-all-v back -> gather
-            comm.query_kmers_sharded_device(ix, q.data_ptr(), nq, ids.data_ptr(), stream)
+        def step(j=0):  # partition -> all-to-all-v (RCCL/xGMI) -> owner's query kernel -> all-to-all-v back -> gather
+            comm.query_kmers_sharded_device(ix, batches[j][0].data_ptr(), nq, ids_all[j].data_ptr(), stream)
     elif querier is not None:
-        def step():
-            nonlocal ids
-            ids = querier.query(q)
+        def step(j=0):
+            ids_all[j] = querier.query(batches[j][0])
     else:
-        def step():
-            ix.query_kmers_device(q.data_ptr(), nq, ids.data_ptr(), stream)
+        def step(j=0):
+            ix.query_kmers_device(batches[j][0].data_ptr(), nq, ids_all[j].data_ptr(), stream)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i % nbatch)
     torch.cuda.synchronize()
+    ix.partition_stats(reset=True)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
+    evs[0].record()
+    for i in range(args.steps):
+        step((args.warmup + i) % nbatch)  # a batch other than the one before it
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    kern_ms = evs[0].elapsed_time(evs[-1]) / args.steps
+    step_ms_list = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    pstats = ix.partition_stats()
+    for j in range(nbatch):  # every batch answered at least once (their IDs are checked below), outside the timed region
+        step(j)
+    torch.cuda.synchronize()
+    ids = ids_all[0]
+    # ---- excursion (single GPU): a batch with no indexed k-mer, then one with only indexed k-mers, each followed by a headline batch
+    # that is timed alone: the filter gate and the learnt plan were set by a batch of a different kind
+    excursion = None
+    if not multi:
+        excursion = {}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        scratch_ids = torch.empty(nq, device=dev, dtype=torch.int64)
+        for name, frac in (("after_a_batch_without_indexed_kmers", 0.0), ("after_a_batch_of_indexed_kmers_only", 1.0)):
+            qx, _ = synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 13 + int(frac) + 7, kw, frac)
+            e0.record()
+            ix.query_kmers_device(qx.data_ptr(), nq, scratch_ids.data_ptr(), stream)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_x = e0.elapsed_time(e1)
+            e0.record()
+            step(1 % nbatch)
+            e1.record()
+            torch.cuda.synchronize()
+            excursion[name] = {"that_batch_ms": ms_x, "next_headline_batch_ms": e0.elapsed_time(e1)}
+            del qx
+        step(0)  # back to steady state (and ids_all[0] holds batch 0 again)
+        torch.cuda.synchronize()
+        del scratch_ids
     if multi:
         tt = torch.tensor([dt], device=("cpu" if rehearsal else dev), dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -699,12 +856,17 @@ def main():
                     "ids_equal_to_sharded": bool(same.item())}
         full.close()
 
-    # ---- sanity: every indexed query found, no random query found, IDs in range
-    found = ids >= 0
-    n_pos_found = int((found & is_pos).sum().item())
-    n_neg_found = int((found & ~is_pos).sum().item())
-    n_pos = int(is_pos.sum().item())
-    ok = n_pos_found == n_pos and int(ids.max().item()) < st["number_kmer"]
+    # ---- sanity, every batch: every indexed query found, no random query found, IDs in range
+    n_pos_found = n_neg_found = n_pos = 0
+    ok = True
+    for j in range(nbatch):
+        found = ids_all[j] >= 0
+        pj = batches[j][1]
+        n_pos_found += int((found & pj).sum().item())
+        n_neg_found += int((found & ~pj).sum().item())
+        n_pos += int(pj.sum().item())
+        ok = ok and int(ids_all[j].max().item()) < st["number_kmer"]
+    ok = ok and n_pos_found == n_pos
     if slice_build is not None:
         ok = ok and slice_build["ids_equal_to_whole_input_build"]
     if multi:
@@ -723,8 +885,13 @@ def main():
                                    "%g%% indexed / %g%% random" % (args.workload, " skewed (every tenth unitig from {A,C})" if args.skew else "",
                                                                     st["number_kmer"], k, k, m, n, b, nq, 100 * args.present, 100 * (1 - args.present)),
                        "parallelism": "1 GPU" if not multi else ("%s x%d" % (effective_mode, world)),
-                       "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"], "build_seconds": t_build,
-                       "build_kmers_per_sec": st["number_kmer"] / t_build,
+                       "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"],
+                       "build_seconds": t_build, "build_seconds_filter_armed": t_build_armed,
+                       "build_kmers_per_sec": st["number_kmer"] / t_build_armed,
+                       "build_note": "build_seconds: until construct_index returned (queries are answered from then on, unfiltered); "
+                                     "build_seconds_filter_armed: until the absent-key filter's background passes were done too -- the state the "
+                                     "timed queries run on; build_kmers_per_sec is derived from the latter",
+                       "query_batches": "%d independently seeded batches rotate through warm-up and timed steps" % nbatch,
                        "absent_filter": "blocked Bloom filter over the keys, %s bits/key; its passes ran %.2f s in the background after the build returned" % (
                            os.environ.get("BLIGHT_FILTER_BITS", "8, or 16 at b >= 7"), t_filter_bg), "largest_mphf": st["largest_mphf"], "largest_bucket": st["largest_bucket"],
                        "mphf_groups_lds_built": st["mphf_groups_lds_built"], "mphf_groups": st["ngroups"], "fallback_keys": st["fallback_keys"]},
@@ -733,8 +900,16 @@ def main():
              "frac": ALGO_BYTES.get(k, 145) * nq / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
              "kernel": "whole sharded step (partition, exchange, k_query, exchange, gather) against the aggregate HBM peak"},
             "checks": {"indexed_queries_found": n_pos_found, "indexed_queries": n_pos, "random_queries_found": n_neg_found,
-                       "ok": bool(ok)},
+                       "batches_checked": nbatch, "ok": bool(ok)},
+            "ms_per_step_each": [round(x, 4) for x in step_ms_list],
+            "partition": {"what": "one-pass partition of the timed steps: k-mers that did not fit their bin's region (sized after the previous, "
+                                  "different batch) and went through the overflow region", "batches": pstats["batches"], "kmers": pstats["kmers"],
+                          "overflow_kmers": pstats["overflow_kmers"], "max_overflow_of_a_batch": pstats["max_overflow_of_a_batch"]},
         }
+        if excursion is not None:
+            out["excursion"] = excursion
+        if args.mode == "sharded" and multi and not sharded:
+            out["sharded_fallback"] = effective_mode
         orc = None
         out["cpu_baseline"] = None
         if not multi and args.cpu_seconds > 0:
@@ -763,6 +938,11 @@ def main():
                     out["host_buffers"] = {"failed": repr(e)}
         if orc is not None:
             orc.close()
+        if not multi and not args.no_fasta_leg and not args.skew:
+            try:
+                out["build_from_fasta"] = fasta_leg(torch, blight_amd, dev, ascii_, offs, k, m, n, b, kw, args)
+            except Exception as e:
+                out["build_from_fasta"] = {"failed": repr(e)}
         if replicas is not None:
             out["replicas"] = replicas
         if slice_build is not None:
@@ -776,6 +956,8 @@ def main():
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("bench sanity check failed")
+    if args.mode == "sharded" and multi and not sharded:
+        raise SystemExit("bench: --mode sharded was asked for, but the sharded exchange did not run (%s): the line above is NOT a sharded number" % effective_mode)
 
 
 if __name__ == "__main__":

@@ -126,6 +126,7 @@ def load_library():
     lib.blmx_shard_build_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u64p, _u64p]
     lib.blmx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
+    lib.blmx_partition_stats.argtypes = [C.c_void_p, _u64p, C.c_int]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     lib.blmx_export.restype = C.c_int64
     lib.blmx_primitive.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
@@ -254,6 +255,12 @@ class kmer_Set_Light:
         st = blmx_stats_t()
         self._check(self._lib.blmx_stats(self._h, C.byref(st)))
         return {f[0]: getattr(st, f[0]) for f in blmx_stats_t._fields_}
+
+    def partition_stats(self, reset=False):
+        """one-pass partition: {batches, kmers, overflow_kmers, max_overflow_of_a_batch} since the last reset"""
+        a = np.zeros(4, dtype=np.uint64)
+        self._check(self._lib.blmx_partition_stats(self._h, a.ctypes.data_as(_u64p), int(reset)))
+        return {"batches": int(a[0]), "kmers": int(a[1]), "overflow_kmers": int(a[2]), "max_overflow_of_a_batch": int(a[3])}
 
     number_kmer = property(lambda self: self.stats()["number_kmer"])
     number_super_kmer = property(lambda self: self.stats()["number_super_kmer"])

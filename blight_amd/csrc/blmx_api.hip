@@ -802,6 +802,22 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 	return BLMX_OK;
 }
 
+int blmx_partition_stats(blmx_index* h, uint64_t* out4, int reset)
+{
+	if (!h || !out4)
+		return BLMX_EINVAL;
+	return guarded(h, [&] {
+		BLMX_HIP(hipSetDevice(h->ix.prm.device));
+		out4[0] = out4[1] = out4[2] = out4[3] = 0;
+		if (!h->ix.b_pstats.p)
+			return;
+		BLMX_HIP(hipDeviceSynchronize());  // the counters are written on the callers' streams
+		BLMX_HIP(hipMemcpy(out4, h->ix.b_pstats.p, 32, hipMemcpyDeviceToHost));
+		if (reset)
+			BLMX_HIP(hipMemset(h->ix.b_pstats.p, 0, 32));
+	});
+}
+
 int blmx_stats(const blmx_index* h, blmx_stats_t* out)
 {
 	if (!h || !out)

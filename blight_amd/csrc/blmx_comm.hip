@@ -613,7 +613,9 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 		local = StatusError{BLMX_ELIMIT, "a partitioned batch holds fewer than 2^32 - 1 k-mers"};
 	const uint32_t world = c.world, me = c.rank;
 	const char* e = getenv("BLIGHT_DIST_CHUNKS");
-	int pieces = c.pieces ? c.pieces : (e ? atoi(e) : 2);  // must be the same on every rank
+	// pieces overlap the exchange of one with the queries of another; with one rank there is nothing to overlap, and a piece of
+	// half the batch loses locality in its bins.  Must be the same on every rank.
+	int pieces = c.pieces ? c.pieces : (e ? atoi(e) : (c.world > 1 ? 2 : 1));
 	pieces = pieces < 1 ? 1 : (pieces > kMaxPieces ? kMaxPieces : pieces);
 	const size_t kw = (size_t)ix.KW;
 	uint64_t cut[kMaxPieces + 1];

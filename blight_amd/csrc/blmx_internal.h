@@ -280,7 +280,7 @@ struct Index {
 	DevBuf b_bins, b_minis, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp, b_plan, b_frac, b_pstats;
 	int plan_bits = -1;  // bin count (log2) the learnt shares in b_frac belong to, -1 = nothing learnt yet
 	uint32_t plan_nbins_sharded = 0;  // the same for the sharded exchange (bins split at the shard boundaries): bins of b_frac_sharded
-	DevBuf b_frac_sharded;
+	DevBuf b_frac_sharded, b_foreign;  // b_foreign: workgroup layout of the owner's slot kernel (k_foreign_plan)
 	std::mutex bin_mu;
 	hipEvent_t bin_done = nullptr;       // recorded after each binned pipeline: a call on another stream waits for it
 	hipStream_t bin_last_stream = nullptr;

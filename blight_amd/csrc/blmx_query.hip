@@ -1323,38 +1323,67 @@ void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const u
 	BLMX_HIP(hipMemcpyAsync(sp.h_info.p, sp.info.p, 4 * (size_t)(world + 2), hipMemcpyDeviceToHost, s));
 }
 
-// The owner's kernel: every source is a slot range with gaps (the unused tails of the bin regions); a workgroup finds its source,
-// then the bin whose region holds its 256 slots (binary search over the source's header words, uniform: scalar loads) and answers the
-// slots that are in use.  XCD-major over the concatenated ranges like k_query_slots.
+// The owner's kernels.  Every source is a slot range with gaps (the unused tails of the bin regions).  The workgroups walk the
+// regions BIN-MAJOR -- bin 0 of every source, then bin 1 of every source, ... -- so that one bin's slice of the index is worked on by
+// neighbouring workgroups whatever the number of senders (source-major order would fetch every slice once per sender).
+// k_foreign_plan (one workgroup, one thread per bin) lays out the workgroups: first_block[bin * nsrc + source]; the query kernel
+// finds its (bin, source) by a binary search over that table (uniform: scalar loads) and answers the slots that are in use.
 struct ForeignTable {
-	uint32_t nsrc, nblocks;
-	uint32_t first_block[17];
+	uint32_t nsrc, nb;
 	ForeignSlots src[16];
 };
-template <int KW, int LOGP>
-__global__ __launch_bounds__(256) void k_query_foreign_slots(DeviceIndexView v, ForeignTable ft, int narrow)
+__global__ __launch_bounds__(1 << kBinBitsMax) void k_foreign_plan(ForeignTable ft, uint32_t* __restrict__ first_block)
 {
+	__shared__ uint32_t s_wsum[(1 << kBinBitsMax) / 64];
+	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+	uint32_t mine = 0;
+	if (t < ft.nb)
+		for (uint32_t i = 0; i < ft.nsrc; i++)
+			mine += ((uint32_t)ft.src[i].hdr[t + 1] - (uint32_t)ft.src[i].hdr[t]) >> 8;
+	uint32_t v = mine;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t u = __shfl_up(v, o);
+		if ((int)lane >= o)
+			v += u;
+	}
+	if (lane == 63)
+		s_wsum[wave] = v;
+	__syncthreads();
+	uint32_t wbase = 0;
+	for (uint32_t w = 0; w < wave; w++)
+		wbase += s_wsum[w];
+	uint32_t at = wbase + v - mine;
+	if (t < ft.nb) {
+		for (uint32_t i = 0; i < ft.nsrc; i++) {
+			first_block[t * ft.nsrc + i] = at;
+			at += ((uint32_t)ft.src[i].hdr[t + 1] - (uint32_t)ft.src[i].hdr[t]) >> 8;
+		}
+		if (t + 1 == ft.nb)
+			first_block[ft.nb * ft.nsrc] = at;
+	}
+}
+
+template <int KW, int LOGP>
+__global__ __launch_bounds__(256) void k_query_foreign_slots(DeviceIndexView v, ForeignTable ft, const uint32_t* __restrict__ first_block, int narrow)
+{
+	const uint32_t n = ft.nb * ft.nsrc, nblocks = first_block[n];
 	const uint32_t per = gridDim.x >> 3;
-	const uint32_t blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-	if (blk >= ft.nblocks)
+	const uint32_t blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);  // XCD x takes the x-th contiguous eighth (the grid is a multiple of 8)
+	if (blk >= nblocks)
 		return;
-	uint32_t si = 0;
-	while (si + 1 < ft.nsrc && blk >= ft.first_block[si + 1])
-		si++;
-	const ForeignSlots& fs = ft.src[si];
-	const uint32_t first = (blk - ft.first_block[si]) << 8;  // slot inside the range
-	const uint32_t origin = (uint32_t)fs.hdr[0];             // the sender's number of the range's first slot
-	uint32_t lo = 0, hi = fs.nb;
+	uint32_t lo = 0, hi = n;  // the last (bin, source) whose first block is <= blk (empty regions share their successor's first block)
 	while (hi - lo > 1) {
 		const uint32_t mid = (lo + hi) >> 1;
-		if ((uint32_t)fs.hdr[mid] - origin <= first)
+		if (first_block[mid] <= blk)
 			lo = mid;
 		else
 			hi = mid;
 	}
-	const uint64_t h = fs.hdr[lo];
-	const uint32_t rb = (uint32_t)h - origin, used = (uint32_t)(h >> 32);
-	const uint32_t slot = first + threadIdx.x;
+	const uint32_t bin = lo / ft.nsrc, si = lo - bin * ft.nsrc;
+	const ForeignSlots& fs = ft.src[si];
+	const uint64_t h = fs.hdr[bin];
+	const uint32_t rb = (uint32_t)h - (uint32_t)fs.hdr[0], used = (uint32_t)(h >> 32);  // region start inside the range, slots in use
+	const uint32_t slot = rb + ((blk - first_block[lo]) << 8) + threadIdx.x;
 	if (slot < rb + used && slot < fs.nslots)
 		query_slot<KW, LOGP>(gated_view(v), fs.slots, fs.minis, fs.ids, narrow != 0, slot);
 }
@@ -1366,22 +1395,25 @@ void launch_query_foreign_slots(Index& ix, const ForeignSlots* src, uint32_t nsr
 	for (uint32_t i = 0; i < nsrc && ft.nsrc < 16; i++) {
 		if (src[i].nslots == 0 || src[i].nb == 0)
 			continue;
-		ft.first_block[ft.nsrc] = nblocks;
+		ft.nb = src[i].nb;  // the same for every source: the bins this rank owns
 		ft.src[ft.nsrc++] = src[i];
-		nblocks += (src[i].nslots + 255) >> 8;
+		nblocks += (src[i].nslots + 255) >> 8;  // regions are multiples of 256 slots: this is the exact number of workgroups
 	}
-	ft.first_block[ft.nsrc] = nblocks;
-	ft.nblocks = nblocks;
 	if (nblocks == 0)
 		return;
+	std::lock_guard<std::mutex> lock(ix.bin_mu);
+	partition_begin(ix, s);
+	ensure_buf(ix.b_foreign, ((size_t)ft.nb * ft.nsrc + 1) * 4, s);
+	hipLaunchKernelGGL(k_foreign_plan, dim3(1), dim3(1 << kBinBitsMax), 0, s, ft, ix.b_foreign.as<uint32_t>());
 	const DeviceIndexView v = ix.view();
 	const unsigned grid = (nblocks + 7u) & ~7u;
+	const uint32_t* fb = ix.b_foreign.as<uint32_t>();
 #define BLMX_QF(LP)                                                                                                            \
 	case LP:                                                                                                                   \
 		if (ix.KW == 1)                                                                                                        \
-			hipLaunchKernelGGL((k_query_foreign_slots<1, LP>), dim3(grid), dim3(256), 0, s, v, ft, (int)narrow);               \
+			hipLaunchKernelGGL((k_query_foreign_slots<1, LP>), dim3(grid), dim3(256), 0, s, v, ft, fb, (int)narrow);           \
 		else                                                                                                                   \
-			hipLaunchKernelGGL((k_query_foreign_slots<2, LP>), dim3(grid), dim3(256), 0, s, v, ft, (int)narrow);               \
+			hipLaunchKernelGGL((k_query_foreign_slots<2, LP>), dim3(grid), dim3(256), 0, s, v, ft, fb, (int)narrow);           \
 		break;
 	switch (v.b) {
 		BLMX_QF(0)
@@ -1398,6 +1430,7 @@ void launch_query_foreign_slots(Index& ix, const ForeignSlots* src, uint32_t nsr
 	}
 #undef BLMX_QF
 	BLMX_HIP(hipGetLastError());
+	partition_end(ix, s);
 }
 
 // IDs of the piece (they sit in sp.ids, slot by slot, wherever they were answered) -> the caller's order; this batch's shares become

@@ -320,6 +320,10 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
 int blmx_set_tuning(blmx_index* ix, const char* key, int value);
 
 int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
+/* One-pass partition of large k-mer batches (bin regions sized after the PREVIOUS batch): out4 = [batches that took it, their k-mers,
+ * k-mers that did not fit their bin's region and went through the overflow region (they are answered all the same, only without
+ * locality), the largest such count of one batch]; reset != 0 clears the counters.  Synchronises the device. */
+int blmx_partition_stats(blmx_index* ix, uint64_t* out4, int reset);
 
 /* Copy index arrays back to the host for array-level parity checks (tests only; not needed by callers).
  * which: 0 bucket_nt u32[nbuckets] | 1 bucket_start u64[nbuckets] | 2 packed sequence u64[ceil(total_nt/32)]

@@ -35,6 +35,7 @@ for kname, counters in acc.items():
     k["fetch_bytes"] = d.get("FETCH_SIZE", 0.0) * 1024.0
     k["write_bytes"] = d.get("WRITE_SIZE", 0.0) * 1024.0
     k["valu_insts"] = d.get("SQ_INSTS_VALU", 0.0)
+    k["l2_read_requests"] = d.get("TCP_TCC_READ_REQ_sum", 0.0)  # L1 -> L2 read requests per launch
     kernels[kname] = k
 for f in glob.glob(out_dir + "/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
