@@ -179,6 +179,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.tune_reads_mode = env_int("BLIGHT_READS_MODE", 0);
 	h->ix.tune_partition = env_int("BLIGHT_PARTITION", 0);
 	h->ix.tune_window_kb = env_int("BLIGHT_WINDOW_KB", 0);
+	h->ix.tune_fat_lines = env_int("BLIGHT_FAT_LINES", 1);
 	if (hipSetDevice(prm.device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
 		g_create_err = "hipStreamCreate failed";
 		delete h;
@@ -795,6 +796,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_window_kb = value;
 	else if (k == "slot_piece_min")
 		ix.tune_slot_piece_min = value;
+	else if (k == "fat_lines")  // before building
+		ix.tune_fat_lines = value != 0;
 	else if (k == "query_binning")
 		ix.bin_policy = value < 0 ? -1 : (value > 0 ? 1 : 0);
 	else
@@ -929,8 +932,14 @@ int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
 			std::vector<uint64_t> v((size_t)ix.total_logical_words);
 			for (uint32_t g = 0; g < ng; g++) {
 				const GroupDesc& gd = ix.h_groups[g];
+				const uint64_t w0 = gd.size[0] >> 5, F = (w0 + kLineData32 - 1) / kLineData32;  // fat layout: level 0 in 64-B lines of its own
 				for (uint64_t w32 = 0; w32 < 2 * gd.nwords; w32++) {
-					const uint64_t x = hl[(gd.line_base + w32 / kLineData32) * kLineWords32 + 1 + w32 % kLineData32];
+					uint64_t unit = gd.line_base + w32 / kLineData32, slot = w32 % kLineData32;
+					if (ix.fat_lines) {
+						unit = w32 < w0 ? gd.line_base + 4 * (w32 / kLineData32) : gd.line_base + 4 * F + (w32 - w0) / kLineData32;
+						slot = w32 < w0 ? w32 % kLineData32 : (w32 - w0) % kLineData32;
+					}
+					const uint64_t x = hl[unit * kLineWords32 + 1 + slot];
 					v[gd.wbase + (w32 >> 1)] |= x << (32 * (w32 & 1));
 				}
 			}

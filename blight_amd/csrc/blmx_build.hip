@@ -956,9 +956,33 @@ __device__ __forceinline__ uint32_t line_data_word(const GroupDesc* __restrict__
 	return (uint32_t)((w32 & 1) ? (v >> 32) : v);
 }
 
+// A group's lines in rank order ("logical lines"): without fat lines, line l covers the 32-bit words 3l .. 3l+2 of all levels back to
+// back; with fat lines (index_device.h) the first F = fat_lines_of(size0) lines cover level 0 alone -- the last of them padded with
+// zeros -- and the lines behind them the deeper levels.  line_base[] counts LOGICAL lines (rank bookkeeping); GroupDesc::line_base
+// counts 16-B units of the line array (a fat line takes four).
+__device__ __forceinline__ uint32_t logical_line_word(const GroupDesc* __restrict__ gd, const unsigned long long* __restrict__ bits,
+                                                      const unsigned long long* __restrict__ coll, uint64_t lrel, int s, bool fat)
+{
+	if (!fat)
+		return line_data_word(gd, bits, coll, lrel * kLineData32 + s);
+	const uint64_t w0 = gd->size[0] >> 5, F = fat_lines_of(gd->size[0]);
+	if (lrel < F) {
+		const uint64_t w32 = lrel * kLineData32 + s;
+		return w32 < w0 ? line_data_word(gd, bits, coll, w32) : 0u;
+	}
+	return line_data_word(gd, bits, coll, w0 + (lrel - F) * kLineData32 + s);
+}
+__device__ __forceinline__ uint64_t logical_line_unit(const GroupDesc* __restrict__ gd, uint64_t lrel, bool fat)
+{
+	if (!fat)
+		return gd->line_base + lrel;
+	const uint64_t F = fat_lines_of(gd->size[0]);
+	return lrel < F ? gd->line_base + lrel * kFatUnits : gd->line_base + F * kFatUnits + (lrel - F);
+}
+
 __global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
                             const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
-                            uint64_t* __restrict__ linepc)
+                            uint64_t* __restrict__ linepc, bool fat)
 {
 	const uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (L > nlines)
@@ -969,29 +993,28 @@ __global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t
 	}
 	const uint32_t g = group_of_line(line_base, ngroups, L);
 	const GroupDesc* gd = &groups[g];
-	const uint64_t first = (L - line_base[g]) * kLineData32;
 	uint64_t pc = 0;
 	for (int s = 0; s < kLineData32; s++)
-		pc += (uint64_t)__popc(line_data_word(gd, bits, coll, first + s));
+		pc += (uint64_t)__popc(logical_line_word(gd, bits, coll, L - line_base[g], s, fat));
 	linepc[L] = pc;
 }
 
 __global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
                              const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
-                             const uint64_t* __restrict__ linepre, uint4* __restrict__ lines)
+                             const uint64_t* __restrict__ linepre, uint4* __restrict__ lines, bool fat)
 {
 	const uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (L >= nlines)
 		return;
 	const uint32_t g = group_of_line(line_base, ngroups, L);
 	const GroupDesc* gd = &groups[g];
-	const uint64_t first = (L - line_base[g]) * kLineData32;
+	const uint64_t lrel = L - line_base[g];
 	uint4 o;
 	o.x = (uint32_t)(linepre[L] - linepre[line_base[g]]);  // rank restarts at 0 in every group (bbhash.h:447-465)
-	o.y = line_data_word(gd, bits, coll, first);
-	o.z = line_data_word(gd, bits, coll, first + 1);
-	o.w = line_data_word(gd, bits, coll, first + 2);
-	lines[L] = o;
+	o.y = logical_line_word(gd, bits, coll, lrel, 0, fat);
+	o.z = logical_line_word(gd, bits, coll, lrel, 1, fat);
+	o.w = logical_line_word(gd, bits, coll, lrel, 2, fat);
+	lines[logical_line_unit(gd, lrel, fat)] = o;  // (a fat line's filter words stay zero here: the filter passes set them)
 }
 
 // total set bits per group (= first fallback rank, bbhash.h:554)
@@ -1165,8 +1188,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_keys(DeviceIndexView v, const
 	for (uint64_t idx = s_ks[0] + threadIdx.x; idx < k1; idx += kBlock) {
 		const uint32_t j = sk_of_key(s_ks, nj, idx);
 		const GroupDesc* gd = &v.groups[s_mini[j] >> v.gshift];
-		const uint64_t fh = filter_hash<KW>(load_kmer<KW>(keys, idx));
-		atomicOr(&filter[filter_word(gd->prefix - v.id_base, gd->size[0], v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
+		const Kmer<KW> x = load_kmer<KW>(keys, idx);
+		const uint64_t fh = filter_hash<KW>(x);
+		if (v.fat)
+			atomicOr(fat_filter_slot<KW>(v, gd->line_base, gd->size[0], x, fh), (unsigned long long)filter_mask(fh));
+		else
+			atomicOr(&filter[filter_word(gd->prefix - v.id_base, gd->size[0], v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
 	}
 }
 
@@ -1220,7 +1247,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_junctions(DeviceIndexView v, 
 	if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bd.nt) || rel < pos || rel >= pos + (1ull << v.b))
 		return;
 	const uint64_t fh = filter_hash<KW>(x);
-	atomicOr(&filter[filter_word(gh.prefix - v.id_base, gh.size0, v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
+	if (v.fat)
+		atomicOr(fat_filter_slot<KW>(v, gh.line_base, gh.size0, x, fh), (unsigned long long)filter_mask(fh));
+	else
+		atomicOr(&filter[filter_word(gh.prefix - v.id_base, gh.size0, v.filter_bpk, fh)], (unsigned long long)filter_mask(fh));
 }
 
 // int_to_bool for a whole group (blight.cpp:464-469): one workgroup packs the group's 32-bit fields (indexed by rank)
@@ -1739,6 +1769,14 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		if ((int)(ceil(log2((double)(uint32_t)(h_gmax[g] + 1))) - (double)b) + (int)hint > 32)
 			hint = 0;
 	ix.pos_hint = hint;
+	// absent-key filter (index_device.h): tune_filter_bits per key.  Automatic: 8 bits per key (2-3 % false positives; more bits were
+	// no faster at b = 6) -- but 16 where the position hint shortens the scan: every false positive of the filter sends its whole wave
+	// through the reference's 2^b window (C5: 3.83 -> 2.75 ms).  With 8 bits per key the filter lives INSIDE the level-0 lines (64-B
+	// fat lines: filter test and level-0 probe in one request) unless tuned off.
+	const uint32_t bpk = ix.tune_filter_bits < 0 ? (hint ? 16u : 8u) : (uint32_t)std::min(ix.tune_filter_bits, 32);
+	const bool fat = bpk == 8 && ix.tune_fat_lines != 0;
+	ix.fat_lines = fat;
+	uint64_t ubase = 0;  // 16-B units of the line array (lbase below counts logical lines)
 	for (uint32_t g = 0; g < ngroups; g++) {
 		GroupDesc& gd = ix.h_groups[g];
 		int nb = (int)(ceil(log2((double)(uint32_t)(h_gmax[g] + 1))) - (double)b);
@@ -1751,7 +1789,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		gd.prefix = h_gpre[g];
 		gd.nkeys = h_gnk[g];
 		gd.wbase = wbase;
-		gd.line_base = lbase;
+		gd.line_base = ubase;
 		h_line_base[g] = lbase;
 		if (h_gnk[g]) {
 			const uint64_t total_bits = configure_levels(h_gnk[g], gd.size);
@@ -1764,7 +1802,17 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			if (gd.nwords >= (1ull << 31))  // the query kernel indexes a group's level array with 32-bit word numbers
 				throw StatusError{BLMX_ELIMIT, "an MPHF group holds more than 2^37 level bits"};
 			wbase += gd.nwords;
-			lbase += (2 * gd.nwords + kLineData32 - 1) / kLineData32;
+			if (fat) {
+				const uint64_t F = ((gd.size[0] >> 5) + kLineData32 - 1) / kLineData32, T = (2 * gd.nwords - (gd.size[0] >> 5) + kLineData32 - 1) / kLineData32;
+				lbase += F + T;
+				ubase += 4 * F + T;
+			} else {
+				const uint64_t L = (2 * gd.nwords + kLineData32 - 1) / kLineData32;
+				lbase += L;
+				ubase += L;
+			}
+			if (ubase >= (1ull << 32))
+				throw StatusError{BLMX_ELIMIT, "the MPHF lines of one index (shard) hold less than 64 GB"};
 		} else {
 			// no MPHF for an empty group (blight.cpp:452); size 64 keeps the probe arithmetic defined, never reached
 			for (int l = 0; l < kLevels; l++)
@@ -1775,7 +1823,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		largest_bucket = std::max(largest_bucket, h_gmax[g]);
 	}
 	h_line_base[ngroups] = lbase;
-	const uint64_t total_words = wbase, total_lines = lbase;
+	const uint64_t total_words = wbase, total_lines = lbase, total_units = ubase;
 
 	DevBuf d_loff, d_line_base, d_bgroups;
 	BLMX_HIP(d_loff.alloc(h_loff.size() * 8, false, s));
@@ -1994,15 +2042,15 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	BLMX_HIP(d_linepc.alloc((total_lines + 1) * 8, false, s));
 	BLMX_HIP(d_linepre.alloc((total_lines + 1) * 8, false, s));
 	BLMX_HIP(d_gpopc.alloc(((size_t)ngroups + 1) * 8, false, s));
-	BLMX_HIP(ix.lines.alloc((total_lines + 1) * kLineBytes, true, s));
+	BLMX_HIP(ix.lines.alloc((total_units + 1) * kLineBytes, true, s));
 	hipLaunchKernelGGL(k_line_popc, dim3(grid_for(total_lines + 1)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
-	                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>());
+	                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>(), fat);
 	BLMX_HIP(hipGetLastError());
 	exclusive_scan_u64(sc, d_linepc.as<uint64_t>(), d_linepre.as<uint64_t>(), total_lines + 1, s);
 	if (total_lines)
 		hipLaunchKernelGGL(k_line_write, dim3(grid_for(total_lines)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
 		                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepre.as<uint64_t>(),
-		                   ix.lines.as<uint4>());
+		                   ix.lines.as<uint4>(), fat);
 	hipLaunchKernelGGL(k_group_popc, dim3(grid_for(ngroups)), dim3(kBlock), 0, s, d_line_base.as<uint64_t>(), d_linepre.as<uint64_t>(), ngroups,
 	                   d_gpopc.as<uint64_t>());
 	BLMX_HIP(hipGetLastError());
@@ -2097,24 +2145,24 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	ix.positions_words = phys_pos / 64 + 3;
 	BLMX_HIP(ix.positions.alloc(ix.positions_words * 8, true, s));
 	ix.st.total_nt = total_nt;
-	// absent-key filter (index_device.h): tune_filter_bits per key, every key inserted by the positions pass
-	// automatic: 8 bits per key (2-3 % false positives; more bits were no faster at b = 6) -- but 16 where the position hint shortens
-	// the scan: every false positive of the filter sends its whole wave through the reference's 2^b window (C5: 3.83 -> 2.75 ms)
-	const uint32_t bpk = ix.tune_filter_bits < 0 ? (ix.pos_hint ? 16u : 8u) : (uint32_t)std::min(ix.tune_filter_bits, 32);
+	// absent-key filter: a separate array (filter_bits per key), or -- fat lines -- the six words behind every level-0 line
 	ix.filter_bpk = 0;
 	ix.filter_words = 0;
 	ix.filter.release();
 	if (bpk && N) {
-		ix.filter_words = (uint64_t)(((unsigned __int128)N * bpk) >> 6) + 64;
-		BLMX_HIP(ix.filter.alloc(ix.filter_words * 8, true, s));
+		if (!fat) {
+			ix.filter_words = (uint64_t)(((unsigned __int128)N * bpk) >> 6) + 64;
+			BLMX_HIP(ix.filter.alloc(ix.filter_words * 8, true, s));
+		}
 		ix.filter_bpk = bpk;
 		init_filter_gate(ix, s);
 	}
 	{
 		DeviceIndexView v = ix.view();
-		v.filter = ix.filter_bpk ? ix.filter.as<uint64_t>() : nullptr;  // whatever the query-time switch says
+		v.filter = ix.filter_bpk ? (fat ? ix.lines.as<uint64_t>() : ix.filter.as<uint64_t>()) : nullptr;  // whatever the query-time switch says
 		v.id_base = id_base;
-		unsigned long long* d_filter = ix.filter_bpk ? ix.filter.as<unsigned long long>() : nullptr;
+		const bool have_filter = ix.filter_bpk != 0;
+		unsigned long long* d_filter = (have_filter && !fat) ? ix.filter.as<unsigned long long>() : nullptr;
 		DevBuf d_field;  // position field of every local rank (ranks nobody owns -- overwritten duplicates -- stay 0 like in the reference)
 		BLMX_HIP(d_field.alloc((N + 1) * 4, true, s));
 		if (nsk)
@@ -2133,7 +2181,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		// second pass of the filter, on its own stream: the build does not wait for it, queries use the filter once it is done
 		ix.filter_wait();
 		ix.filter_state.store(2);
-		if (d_filter && nsk) {
+		if (have_filter && nsk) {
 			if (!ix.bg_stream)
 				BLMX_HIP(hipStreamCreateWithFlags(&ix.bg_stream, hipStreamNonBlocking));
 			if (!ix.filter_ready)
@@ -2167,7 +2215,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	}
 
 	// ---- public counters (blight.h:52-59, recap blight.cpp:361-378)
-	ix.total_lines = total_lines;
+	ix.total_lines = total_units;  // 16-B units of the line array
 	ix.total_logical_words = total_words;
 	blmx_stats_t& st = ix.st;
 	st.number_kmer = world > 1 ? global_N : N;
@@ -2182,7 +2230,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	st.positions_total_size = total_pos;
 	st.total_nt = total_nt;
 	st.largest_bucket = largest_bucket;
-	st.mphf_bytes = total_lines * kLineBytes;
+	st.mphf_bytes = total_units * kLineBytes;
 	st.fallback_keys = F;
 	st.nbuckets = nbuckets;
 	st.ngroups = ngroups;
@@ -2464,7 +2512,7 @@ void shard_halo_set(Index& ix, const uint64_t* recs, uint32_t world)
 		BLMX_HIP(hipGetLastError());
 		if (ix.filter_bpk && ix.st.local_number_kmer) {  // the end junction again, now with the halo behind it
 			DeviceIndexView v = ix.view();
-			v.filter = ix.filter.as<uint64_t>();
+			v.filter = ix.fat_lines ? ix.lines.as<uint64_t>() : ix.filter.as<uint64_t>();
 			const uint64_t cand = (uint64_t)(ix.prm.k - 1) + (1ull << ix.prm.bits_saved);
 			if (ix.KW == 1)
 				hipLaunchKernelGGL((k_filter_junctions<1>), dim3(grid_for(cand)), dim3(kBlock), 0, s, v, (const uint64_t*)nullptr, (uint64_t)0,

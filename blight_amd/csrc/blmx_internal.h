@@ -67,6 +67,7 @@ struct DeviceIndexView {
 	const uint64_t* filter;
 	uint64_t id_base;     // ID of the first key this index holds (0 unless sharded): group regions of the filter follow local IDs
 	uint32_t filter_bpk;  // filter bits per key
+	bool fat;             // level-0 lines are 64 B and carry the filter (index_device.h); `filter` is then only a flag (non-null = consult it)
 	// one word: 1 = consult the filter, 0 = skip it (the last large batch had almost no absent k-mers: the filter would only cost its
 	// load; k_gate_sample decides after every large batch).  nullptr = always use.
 	uint32_t* filter_gate;
@@ -232,6 +233,7 @@ struct Index {
 	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks, filter, filter_gate;
 	uint64_t filter_words = 0;
 	uint32_t filter_bpk = 0;   // bits per key the filter was built with (0 = none)
+	bool fat_lines = false;    // level-0 lines carry the filter (64-B lines; no separate filter array)
 	// The filter's passes (k_filter_keys: every key; k_filter_junctions: the few non-keys the reference's scan can find) run on their
 	// own stream AFTER the build has returned, and a helper thread waits for it, gives the build's temporaries back to the driver (hipFree waits for the
 	// device, so the build itself must not do it) and arms the filter.  0 = pass pending, 2 = filter usable.
@@ -309,6 +311,7 @@ struct Index {
 	int tune_filter_bits = -1;   // bits per key of the filter built at construction (0 = build none, -1 = automatic: 8, or 16 with the
 	                             // position hint of the wide windows; BLIGHT_FILTER_BITS)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
+	int tune_fat_lines = 1;      // build: with 8 filter bits per key the filter lives inside 64-B level-0 lines (0 = separate filter array, 16-B lines)
 	int tune_slot_piece_min = 0; // sharded exchange: pieces of at least this many k-mers travel as bin regions (0 = default 2^19; tests lower it)
 
 	Index()
@@ -352,7 +355,8 @@ struct Index {
 		v.fb_keys = fb_keys.as<uint64_t>();
 		v.fb_ranks = fb_ranks.as<uint64_t>();
 		v.total_nt = st.total_nt;
-		v.filter = (filter_bpk && tune_absent_filter && filter_usable()) ? filter.as<uint64_t>() : nullptr;
+		v.fat = fat_lines;
+		v.filter = (filter_bpk && tune_absent_filter && filter_usable()) ? (fat_lines ? lines.as<uint64_t>() : filter.as<uint64_t>()) : nullptr;
 		v.filter_bpk = filter_bpk;
 		v.filter_gate = (v.filter && tune_filter_gate) ? filter_gate.as<uint32_t>() : nullptr;
 		v.id_base = h_groups.empty() ? 0 : h_groups[0].prefix;

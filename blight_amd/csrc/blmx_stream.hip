@@ -584,7 +584,8 @@ void save_index(Index& ix, const char* path)
 	FileHeader h{};
 	memcpy(h.magic, kImageMagic, 8);
 	h.version = (ix.filter_bpk || ix.pos_hint) ? kImageVersionFilter : kImageVersion;
-	h.filter_bpk = ix.filter_bpk | (ix.pos_hint << 8);  // low byte: filter bits per key; next byte: hint bits of the position fields
+	h.filter_bpk = ix.filter_bpk | (ix.pos_hint << 8) | ((uint32_t)ix.fat_lines << 16);  // low byte: filter bits per key; next byte: hint bits of the
+	                                                                                       // position fields; bit 16: the filter lives in fat level-0 lines
 	h.abi = BLMX_ABI_VERSION;
 	h.stats_bytes = sizeof(blmx_stats_t);
 	h.group_desc_bytes = sizeof(GroupDesc);
@@ -614,7 +615,7 @@ void save_index(Index& ix, const char* path)
 	pin.ensure(kBounce);
 	for (const DevBuf* b : {&ix.buckets, &ix.groups, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks})
 		put_device(fh.f, *b, pin, ix.stream);
-	if (ix.filter_bpk)
+	if (ix.filter_bpk && !ix.fat_lines)
 		put_device(fh.f, ix.filter, pin, ix.stream);
 	put(fh.f, kImageEnd, 8);
 	if (fflush(fh.f) != 0)
@@ -655,8 +656,10 @@ void load_index(Index& ix, const char* path)
 	if (memcmp(h.magic, kImageMagic, 8) != 0)
 		throw StatusError{BLMX_EIO, "not a Blight MI355X index file"};
 	const uint32_t img_hint = (h.filter_bpk >> 8) & 0xffu;
+	const bool img_fat = (h.filter_bpk >> 16) & 1u;
 	h.filter_bpk &= 0xffu;
 	if ((h.version != kImageVersion && h.version != kImageVersionFilter) || (h.version == kImageVersion && (h.filter_bpk || img_hint)) || h.filter_bpk > 32 ||
+	    (img_fat && h.filter_bpk != 8) ||
 	    img_hint > 3 || img_hint > h.bits_saved ||
 	    h.stats_bytes != sizeof(blmx_stats_t) || h.group_desc_bytes != sizeof(GroupDesc))
 		throw StatusError{BLMX_EIO, "index file written by an incompatible library version"};
@@ -682,11 +685,14 @@ void load_index(Index& ix, const char* path)
 	get_device(fh.f, ix.fb_ranks, (h.nfb + 1) * 8, pin, s);
 	ix.filter_bpk = 0;
 	ix.filter_words = 0;
+	ix.fat_lines = img_fat;
 	if (h.filter_bpk) {
 		if (h.st.local_number_kmer > (1ull << 40))
 			throw StatusError{BLMX_EIO, "index file is inconsistent (header)"};
-		ix.filter_words = ((h.st.local_number_kmer * h.filter_bpk) >> 6) + 64;
-		get_device(fh.f, ix.filter, ix.filter_words * 8, pin, s);
+		if (!img_fat) {
+			ix.filter_words = ((h.st.local_number_kmer * h.filter_bpk) >> 6) + 64;
+			get_device(fh.f, ix.filter, ix.filter_words * 8, pin, s);
+		}
 		ix.filter_bpk = h.filter_bpk;
 		init_filter_gate(ix, s);
 	}
@@ -707,6 +713,7 @@ void load_index(Index& ix, const char* path)
 			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks, &ix.filter, &ix.filter_gate})
 				b->release();
 			ix.filter_bpk = 0;
+			ix.fat_lines = false;
 			ix.h_groups.clear();
 			ix.h_fb_group.clear();
 			throw StatusError{BLMX_EIO, std::string("index file is inconsistent (") + what + ")"};
@@ -726,12 +733,16 @@ void load_index(Index& ix, const char* path)
 					bad("level sizes");
 				bits += gd.size[l];
 			}
-			const uint64_t glines = gd.nkeys ? (bits / 32 + kLineData32 - 1) / kLineData32 : 0;
+			uint64_t glines = gd.nkeys ? (bits / 32 + kLineData32 - 1) / kLineData32 : 0;  // 16-B units of the group's lines
+			if (img_fat && gd.nkeys) {
+				const uint64_t w0 = gd.size[0] / 32, F = (w0 + kLineData32 - 1) / kLineData32;
+				glines = 4 * F + (bits / 32 - w0 + kLineData32 - 1) / kLineData32;
+			}
 			if (gd.nbits <= img_hint || gd.nbits > 32 || gd.nkeys > (1ull << 40) || gd.line_base > h.total_lines || glines > h.total_lines - gd.line_base ||
 			    gd.posstart > h.positions_words * 64 || gd.nkeys * gd.nbits > h.positions_words * 64 - gd.posstart || gd.fb_start > h.nfb ||
 			    gd.fb_count > h.nfb - gd.fb_start)
 				bad("group table");
-			if (ix.filter_bpk) {  // the filter region a query of this group can touch (index_device.h: filter_word)
+			if (ix.filter_bpk && !img_fat) {  // the filter region a query of this group can touch (index_device.h: filter_word)
 				const uint64_t local = gd.prefix - ix.h_groups[0].prefix;
 				if (gd.prefix < ix.h_groups[0].prefix || local > h.st.local_number_kmer ||
 				    ((local * ix.filter_bpk) >> 6) + (((gd.size[0] >> 1) * ix.filter_bpk) >> 6) + 1 > ix.filter_words)

@@ -150,19 +150,71 @@ __device__ __forceinline__ uint64_t filter_word(uint64_t local_prefix, uint64_t 
 	return first + (((h & 0xffffffffull) * words) >> 32);  // a group holds fewer than 2^32 keys
 }
 
+// ---- fat level-0 lines -------------------------------------------------------------------------------------------------------------
+// With DeviceIndexView::fat the lines of LEVEL 0 are 64 bytes: [u32 rank | 96 level-0 bits | 6 x u64 of the absent-key filter], and
+// the filter bits of a k-mer sit in the fat line its level-0 hash selects.  About 48 keys hash into the 96 bits of a line (gamma = 2),
+// so the six words give each of them the 8 bits of the separate filter (one word per key, five bits of it).  A query then gets the
+// filter test AND the level-0 probe from ONE 64-byte line -- one L1 -> L2 request instead of two for every k-mer, indexed or not
+// (the separate filter word cost the absent half of a 50/50 batch its only request and the indexed half a wasted one).  The deeper
+// levels keep 16-byte lines behind the group's fat lines.  One unit of line_base = 16 bytes in both layouts.
+__device__ __forceinline__ uint32_t fat_lines_of(uint64_t size0) { return ((uint32_t)(size0 >> 5) + kLineData32 - 1) / kLineData32; }
+constexpr int kFatUnits = 4;       // 16-B units per fat line
+constexpr int kFatFilterWords = 6;  // u64 filter words per fat line
+__device__ __forceinline__ uint32_t fat_filter_word(uint64_t fh) { return (uint32_t)(((fh & 0xffffffffull) * (uint64_t)kFatFilterWords) >> 32); }
+
+// head (16 B) and one filter word (8 B) of a fat line in ONE round trip: the compiler would sink the second load behind the test of
+// the first
+__device__ __forceinline__ void load_fat_head_and_filter(const uint4* __restrict__ line, uint32_t word, uint4& head, uint64_t& fw)
+{
+	const uint64_t* fp = reinterpret_cast<const uint64_t*>(line) + 2 + word;
+	uint2 f;
+	asm volatile(
+	    "global_load_dwordx4 %0, %2, off\n\t"
+	    "global_load_dwordx2 %1, %3, off\n\t"
+	    "s_waitcnt vmcnt(0)"
+	    : "=&v"(head), "=&v"(f)
+	    : "v"(line), "v"(fp)
+	    : "memory");
+	fw = (uint64_t)f.x | ((uint64_t)f.y << 32);
+}
+
 // mphf::lookup restricted to the level bit arrays (bbhash.h:561-566): probe levels until a set bit is found and rank it.
 // Levels 0..2 use the sizes that came with the group head; deeper levels read their size on demand.
+// use_filter (fat layout only): the absent-key filter is consulted with the level-0 line; `rejected` = the filter says "not indexed"
+// (kNotFound is returned as well: nothing else is looked at).
 template <int KW>
-__device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh,
-                                                        Kmer<KW> x)
+__device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x,
+                                                        bool use_filter, bool& rejected)
 {
 	LevelHasher hs(x.lo);
 	const uint4* __restrict__ lines = reinterpret_cast<const uint4*>(v.lines) + gh.line_base;
 	uint64_t rank;
 	uint64_t off = 0;
-	if (mphf_probe(lines, reduce_level(hs.next(0), gh.size0), rank))
-		return rank;
-	off = gh.size0;
+	rejected = false;
+	if (v.fat) {
+		const uint64_t b0 = reduce_level(hs.next(0), gh.size0);
+		const uint32_t w32 = (uint32_t)(b0 >> 5), fl = w32 / kLineData32;
+		const uint4* fat = lines + (size_t)fl * kFatUnits;
+		uint4 L;
+		if (use_filter) {
+			const uint64_t fh = filter_hash<KW>(x), fm = filter_mask(fh);
+			uint64_t fw;
+			load_fat_head_and_filter(fat, fat_filter_word(fh), L, fw);
+			if ((fw & fm) != fm) {
+				rejected = true;
+				return kNotFound;
+			}
+		} else {
+			L = *fat;
+		}
+		if (mphf_probe_line(L, w32 - fl * kLineData32, (uint32_t)b0 & 31u, rank))
+			return rank;
+		lines += (size_t)fat_lines_of(gh.size0) * kFatUnits;  // the deeper levels: 16-B lines over the bits behind level 0
+	} else {
+		if (mphf_probe(lines, reduce_level(hs.next(0), gh.size0), rank))
+			return rank;
+		off = gh.size0;
+	}
 	if (mphf_probe(lines, off + reduce_level(hs.next(1), gh.size1), rank))
 		return rank;
 	off += gh.size1;
@@ -189,13 +241,31 @@ __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v,
 	}
 	return kNotFound;
 }
+template <int KW>
+__device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x)
+{
+	bool rejected;
+	return mphf_lookup_levels<KW>(v, gd, gh, x, false, rejected);
+}
+
+// the filter bits of k-mer x in the fat layout: the word of the fat line its level-0 hash selects (build: k_filter_keys / _junctions)
+template <int KW>
+__device__ __forceinline__ unsigned long long* fat_filter_slot(const DeviceIndexView& v, uint64_t line_base, uint64_t size0, Kmer<KW> x, uint64_t fh)
+{
+	const uint64_t b0 = reduce_level(hash_bis(x.lo, kSeedH0), size0);
+	const uint32_t fl = (uint32_t)(b0 >> 5) / kLineData32;
+	uint64_t* line = const_cast<uint64_t*>(v.lines) + 2 * (line_base + (uint64_t)fl * kFatUnits);
+	return reinterpret_cast<unsigned long long*>(line + 2 + fat_filter_word(fh));
+}
 
 // mphf::lookup (bbhash.h:561-577): levels first, then the group's fallback table.
 template <int KW>
-__device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x)
+__device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x,
+                                                 bool use_filter = false)
 {
-	const uint64_t r = mphf_lookup_levels<KW>(v, gd, gh, x);
-	if (r != kNotFound)
+	bool rejected;
+	const uint64_t r = mphf_lookup_levels<KW>(v, gd, gh, x, use_filter, rejected);
+	if (r != kNotFound || rejected)
 		return r;
 	const uint32_t fb_count = gd->fb_count;  // from the descriptor: the compact query head does not carry the fallback fields
 	if (fb_count == 0)

@@ -234,13 +234,14 @@ __device__ __forceinline__ void query_one(const DeviceIndexView& v, Kmer<KW> x, 
 	                              : load_bucket_and_head(&v.buckets[mini], gd, bstart, bnt);
 	if (bnt == 0)  // blight.cpp:719-720
 		return;
-	if (v.filter) {  // absent-key filter (index_device.h): one 8-B load instead of the levels, the position and the window
+	if (v.filter && !v.fat) {  // absent-key filter (index_device.h): one 8-B load instead of the levels, the position and the window
 		const uint64_t fh = filter_hash<KW>(x);
 		const uint64_t fm = filter_mask(fh);
 		if ((v.filter[filter_word(gh.prefix - v.id_base, gh.size0, v.filter_bpk, fh)] & fm) != fm)
 			return;
 	}
-	const uint64_t h = mphf_lookup<KW>(v, gd, gh, x);
+	// (fat level-0 lines: the filter word comes with the level-0 line, inside the lookup)
+	const uint64_t h = mphf_lookup<KW>(v, gd, gh, x, v.fat && v.filter != nullptr);
 	if (h == kNotFound)  // blight.cpp:725-726
 		return;
 	const uint32_t field = read_position_field(v.positions, gh.posstart, gh.nbits, h);

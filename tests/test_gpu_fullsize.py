@@ -314,3 +314,66 @@ def test_more_than_2_pow_32_kmers():
     assert np.array_equal(orc.query_kmers(h_q[:400000], threads=8), h_ids[:400000])
     orc.close()
     ix.close()
+
+
+def test_c2_ecoli_shape_few_long_unitigs():
+    """BASELINE config 2 (E. coli K-12 BCALM2 unitigs, k = 31, ~4.6 M k-mers, query self): few LONG unitigs -- 9,200 x 530 nt, SURVEY 8d --
+    and an index that fits the Infinity Cache.  Self-query of all 4.6 M k-mers is a permutation of [0, N); random 31-mers are absent;
+    a 1e5-query sample (indexed, random, near misses) equals the CPU oracle's answers on the exported index image, and the oracle
+    built from the same unitigs gives the same IDs for whole unitigs (the oracle can build this size)."""
+    import torch
+    import blight_amd as B
+    import bench
+    from oracle import oracle as O
+    k, m, n, b = 31, 9, 7, 6
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    nu, L = 9200, 530
+    c = torch.randint(0, 4, (nu * L,), device=dev, dtype=torch.uint8, generator=g)
+    ascii_ = (65 + 2 * c + 2 * (c == 2).to(torch.uint8) + 13 * (c == 3).to(torch.uint8)).contiguous()
+    offs = (torch.arange(nu + 1, device=dev, dtype=torch.int64) * L).contiguous()
+    ix = B.kmer_Set_Light(k, m, n, 6, 1, b)
+    ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), nu, nu * L)
+    ix.set_tuning("absent_filter", 1)
+    st = ix.stats()
+    N = nu * (L - k + 1)
+    assert st["number_kmer"] == N == 4_600_000
+    s = torch.cuda.current_stream().cuda_stream
+    pos = _all_kmer_positions(torch, offs, k)
+    kmers = torch.empty(N, device=dev, dtype=torch.int64)
+    err = torch.zeros(1, device=dev, dtype=torch.int32)
+    ix.kmers_at_device(ascii_.data_ptr(), pos.data_ptr(), N, kmers.data_ptr(), err.data_ptr(), s)
+    ids = torch.empty(N, device=dev, dtype=torch.int64)
+    for policy in (0, 1, -1):  # automatic, partitioned pipeline (exact pass, then the one-pass partition), direct kernel
+        ix.set_query_binning(policy)
+        for _ in range(2 if policy == 1 else 1):
+            ix.query_kmers_device(kmers.data_ptr(), N, ids.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert int(err.item()) == 0
+            counts = torch.bincount(ids.clamp(min=0), minlength=N)
+            assert int(ids.min().item()) >= 0 and bool((counts == 1).all().item())  # a permutation of [0, N)
+    ix.set_query_binning(0)
+    # the oracle on the exported image: a 1e5 sample of indexed k-mers, random k-mers and near misses
+    arrays = bench.export_index(ix, st, k, b)
+    orc = O.ImportedOracle(k, m, n, b, st["total_nt"], st["number_kmer"], st["positions_total_size"], arrays)
+    rng = np.random.default_rng(22)
+    hk = kmers.cpu().numpy().view(np.uint64)
+    sample = hk[rng.integers(0, N, 60000)]
+    neg = rng.integers(0, 1 << 62, size=20000, dtype=np.uint64)
+    neg = np.array([min(int(x), O.p_rc(int(x), k)) for x in neg], dtype=np.uint64)
+    near = sample[:20000] ^ (np.uint64(1) << rng.integers(0, 62, 20000).astype(np.uint64))
+    near = np.array([min(int(x), O.p_rc(int(x), k)) for x in near], dtype=np.uint64)
+    q = np.concatenate([sample, neg, near])
+    want = orc.query_kmers(q)
+    assert np.array_equal(ix.query_kmer_hash(q), want)
+    assert (want[:60000] >= 0).all() and (want[60000:80000] < 0).all()
+    # the oracle BUILT from the same unitigs (not the exported image): whole unitigs through the sequence front end
+    raw = bytes(ascii_.cpu().numpy())
+    seqs = [raw[i * L:(i + 1) * L].decode() for i in range(nu)]
+    built = O.Oracle(k, m, n, b, seqs)
+    assert built.stats["number_kmer"] == N
+    some = seqs[::460]
+    assert np.array_equal(ix.query_sequences_hash(some), np.concatenate([built.query_sequence(x) for x in some]))
+    for key in ("g_nkeys", "g_prefix", "bucket_nt", "bucket_start", "seq", "positions"):
+        assert np.array_equal(ix.export(key), built.arrays()[key]), key
