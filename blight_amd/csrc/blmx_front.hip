@@ -760,6 +760,7 @@ public:
 	RawFile(const RawFile&) = delete;
 	RawFile& operator=(const RawFile&) = delete;
 	bool ok() const { return ok_; }
+	uint64_t size() const { return fd_ >= 0 ? size_ : 0; }  // bytes of a plain file (0: gzip, unknown)
 
 	// Fills `pin` with the next window (about `want` bytes, more when a line is longer) and returns its length; 0 = end of file.
 	// Every window but the last ends behind a newline.
@@ -926,6 +927,110 @@ void stream_file(Index& ix, const char* path, int mode, Payload* payload, uint32
 }
 
 }  // namespace
+
+// construct_index(file) (reference blight.cpp:108-125, reader :212-229) with the parse on the device: the RAW bytes of the file
+// stream through pinned windows into HBM like file_query's, and newlines, the record rule and the sequences themselves are found
+// there (front_seq_lines): the host only moves bytes.  Out: the sequences' characters back to back, nseq + 1 offsets, both in HBM.
+void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBuf& d_offs, uint64_t& nseq, uint64_t& total)
+{
+	RawFile rf(path);
+	if (!rf.ok())
+		throw StatusError{BLMX_EIO, "Problem with files opening"};  // blight.cpp:188-189
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	HostFront& hf = host_front(ix);
+	std::lock_guard<std::mutex> lock(ix.mu);
+	for (auto& w : hf.win)
+		prepare_window_slot(w);
+	// every window's device work runs on ONE stream (the appends are ordered); the pinned slots rotate so that reading the next
+	// window overlaps the copy and the kernels of the previous ones
+	hipStream_t s = hf.win[0].s;
+	DevBuf d_state;  // [0..3] line carry (two generations), [4] sequences, [5] characters, [6] short flag
+	BLMX_HIP(d_state.alloc(64, true, s));
+	uint64_t* carry = d_state.as<uint64_t>();
+	uint64_t* d_tot = carry + 4;
+	int* d_short = reinterpret_cast<int*>(carry + 6);
+	const uint64_t W = window_positions(ix), k = ix.prm.k;
+	const uint64_t fsize = rf.size();  // 0 = unknown (gzip)
+	uint64_t cap_text = 0, cap_offs = 0, seen = 0;  // `seen` raw bytes bound what has been appended
+	auto reserve = [&](uint64_t more) {
+		const uint64_t need_text = seen + more + 64, need_offs = (seen + more) / (k + 1) + 4;
+		if (need_text > cap_text) {
+			DevBuf bigger;
+			const uint64_t nb = std::max<uint64_t>(need_text, fsize ? fsize + 64 : 2 * cap_text);
+			BLMX_HIP(bigger.alloc(nb, false, s));
+			if (cap_text) {
+				BLMX_HIP(hipMemcpyAsync(bigger.p, d_text.p, cap_text, hipMemcpyDeviceToDevice, s));
+				BLMX_HIP(hipStreamSynchronize(s));
+			}
+			std::swap(bigger.p, d_text.p);
+			std::swap(bigger.bytes, d_text.bytes);
+			std::swap(bigger.owner, d_text.owner);
+			cap_text = nb;
+		}
+		if (need_offs > cap_offs) {
+			DevBuf bigger;
+			const uint64_t no = std::max<uint64_t>(need_offs, fsize ? fsize / (k + 1) + 4 : 2 * cap_offs);
+			BLMX_HIP(bigger.alloc(no * 8, false, s));
+			if (cap_offs) {
+				BLMX_HIP(hipMemcpyAsync(bigger.p, d_offs.p, cap_offs * 8, hipMemcpyDeviceToDevice, s));
+				BLMX_HIP(hipStreamSynchronize(s));
+			} else {
+				BLMX_HIP(hipMemsetAsync(bigger.p, 0, 8, s));  // offs[0] = 0
+			}
+			std::swap(bigger.p, d_offs.p);
+			std::swap(bigger.bytes, d_offs.bytes);
+			std::swap(bigger.owner, d_offs.owner);
+			cap_offs = no;
+		}
+	};
+	reserve(0);
+	hipEvent_t copied[kWindowSlots] = {};
+	struct EvGuard {
+		hipEvent_t* e;
+		hipStream_t s;
+		~EvGuard()
+		{
+			(void)hipStreamSynchronize(s);  // no copy out of a pinned slot may still be in flight when the caller unwinds
+			for (int i = 0; i < kWindowSlots; i++)
+				if (e[i])
+					(void)hipEventDestroy(e[i]);
+		}
+	} guard{copied, s};
+	for (int i = 0; i < kWindowSlots; i++)
+		BLMX_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+	bool used[kWindowSlots] = {};
+	FrontScratch& fs = hf.win[0].fs;
+	Trace tr;
+	for (uint64_t i = 0;; i++) {
+		const int slot = (int)(i % kWindowSlots);
+		WindowSlot& w = hf.win[slot];
+		if (used[slot])
+			BLMX_HIP(hipEventSynchronize(copied[slot]));  // the pinned buffer is free again once its copy has left
+		tr.lap("wait slot", i);
+		const uint64_t nbytes = rf.next(w.h_in, W, *hf.pool);
+		tr.lap("read", i);
+		if (nbytes == 0)
+			break;
+		if (nbytes >= 0xffffffc0ull)
+			throw StatusError{BLMX_ELIMIT, "a line of 4 GiB or more"};
+		reserve(nbytes);
+		seen += nbytes;
+		grow(w.d_in, nbytes + 64, s);
+		BLMX_HIP(hipMemcpyAsync(w.d_in.p, w.h_in.p, nbytes, hipMemcpyHostToDevice, s));
+		BLMX_HIP(hipEventRecord(copied[slot], s));
+		used[slot] = true;
+		front_seq_lines(ix, fs, w.d_in.as<uint8_t>(), nbytes, carry + 2 * (i & 1), carry + 2 * ((i + 1) & 1), d_short, d_tot, d_text.as<uint8_t>(),
+		                d_offs.as<uint64_t>(), s);
+		tr.lap("enqueue", i);
+	}
+	uint64_t h_state[8] = {};
+	BLMX_HIP(hipMemcpyAsync(h_state, d_state.p, 64, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	if (*reinterpret_cast<const int*>(&h_state[6]))
+		throw StatusError{BLMX_ESHORT, "a sequence is shorter than k"};
+	nseq = h_state[4];
+	total = h_state[5];
+}
 
 // file_query: returns good / erroneous k-mer counts (the reference prints them: "Good kmer", "Erroneous kmers").
 void query_file(Index& ix, const char* path, uint64_t& good, uint64_t& erroneous) { stream_file(ix, path, 0, nullptr, 0, good, erroneous); }

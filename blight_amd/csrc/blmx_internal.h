@@ -200,6 +200,7 @@ struct FrontScratch {
 	DevBuf valid;  // bit q = a k-mer starts at window position q
 	DevBuf vpre;   // k-mers that start before each 64-position word (the last entry = all of them)
 	DevBuf tmp;    // rocPRIM scan scratch
+	DevBuf lpre;   // raw, construction: per line, sequences and characters of the window's sequence lines before it
 };
 struct HostFront;  // blmx_stream.hip: pinned staging, window slots, small-call slots and worker threads of one index
 void destroy_host_front(HostFront*);
@@ -439,6 +440,10 @@ void launch_read_front(const Index& ix, const FrontScratch* fs, const uint8_t* d
 void launch_read_query(const Index& ix, const FrontScratch* fs, const uint8_t* d_bytes, uint64_t nbytes, uint64_t npos, const uint64_t* offs,
                        const uint64_t* koffs, uint64_t nseq, int64_t* d_ids, unsigned long long* d_counts, int* d_err, hipStream_t s);
 bool read_query_fusable(const Index& ix);
+void front_seq_lines(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_carry_in, uint64_t* d_carry_out,
+                     int* d_short_flag, uint64_t* d_tot, uint8_t* d_text, uint64_t* d_offs, hipStream_t s);
+// construct_index(file) with the parse on the device (blmx_front.hip): raw bytes -> pinned windows -> HBM -> sequences + offsets
+void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBuf& d_offs, uint64_t& nseq, uint64_t& total);
 // host-buffer entry points (blmx_stream.hip): pinned staging, windows in flight, small-call slots
 void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
 void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode);

@@ -398,6 +398,88 @@ __global__ void k_valid_lines(const unsigned long long* __restrict__ nl, const u
 	valid[w] = out;
 }
 
+// ---- raw FASTA bytes -> the sequences themselves (construction: construct_index(file), reference blight.cpp:212-229) ---------------
+// Behind the line table and the record rule above (k_line_ok, mode 0: the second line of a pair is a sequence iff both lines are
+// non-empty; a sequence shorter than k raises the short flag), the sequence lines of a window are appended to the text the build
+// takes -- characters back to back + one offset per sequence -- entirely on the device: the host only moves the file's bytes.
+// Two bitmaps per window, both one lane per 64-byte word like k_valid_lines: mask (bit i = byte i belongs to a sequence line) and
+// ends (bit e = the newline at e ends a sequence line); their popcount prefixes give, for every byte, the characters and the sequences
+// appended before it -- no per-line scan, and no size the host would have to read back.
+__global__ void k_seq_masks(const unsigned long long* __restrict__ nl, const uint32_t* __restrict__ nlpre, const uint8_t* __restrict__ ok, uint64_t nwords,
+                            uint64_t total, unsigned long long* __restrict__ mask, unsigned long long* __restrict__ ends)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords)
+		return;
+	unsigned long long bits = nl[w];
+	uint32_t j = nlpre[w];
+	int a = 0;
+	unsigned long long out = 0, en = 0;
+	for (;;) {
+		const int e = bits ? __ffsll(bits) - 1 : 64;  // local position of the newline that ends line j, if it is in this word
+		if (ok[j]) {
+			if (e > a)
+				out |= ((e >= 64) ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << a) - 1ull);
+			if (e < 64)
+				en |= 1ull << e;
+		}
+		if (e >= 64)
+			break;
+		bits &= bits - 1;
+		a = e + 1;
+		j++;
+		if (a >= 64)
+			break;
+	}
+	if (total - w * 64 < 64)  // the last word: nothing behind the end of the window (an unterminated last line runs up to it)
+		out &= (1ull << (total - w * 64)) - 1ull;
+	mask[w] = out;
+	ends[w] = en;
+}
+// tot[0] = sequences, tot[1] = characters appended before this window (device-resident: no host round trip per window).
+// One lane per word writes the end offset of every sequence line that ends in it.
+__global__ void k_seq_offsets(const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ mpre, const unsigned long long* __restrict__ ends,
+                              const uint32_t* __restrict__ epre, uint64_t nwords, const uint64_t* __restrict__ tot, uint64_t* __restrict__ offs_out)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords)
+		return;
+	unsigned long long en = ends[w];
+	const unsigned long long m = mask[w];
+	uint64_t idx = tot[0] + epre[w];
+	while (en) {
+		const int e = __ffsll(en) - 1;
+		offs_out[++idx] = tot[1] + (uint64_t)mpre[w] + (uint64_t)__popcll(m & ((1ull << e) - 1ull));
+		en &= en - 1;
+	}
+}
+// the unterminated last line of the file, when it is a sequence, and the new totals
+__global__ void k_seq_advance(const uint8_t* __restrict__ ok, const uint32_t* __restrict__ nlpre, const uint32_t* __restrict__ mpre,
+                              const uint32_t* __restrict__ epre, uint64_t nwords, uint64_t* __restrict__ tot, uint64_t* __restrict__ offs_out)
+{
+	const uint64_t nseq = tot[0] + epre[nwords], nchar = tot[1] + mpre[nwords];
+	const uint32_t last = nlpre[nwords];  // the line behind the window's last newline (empty when the window ends behind a newline)
+	uint64_t add = 0;
+	if (ok[last]) {
+		offs_out[nseq + 1] = nchar;
+		add = 1;
+	}
+	tot[0] = nseq + add;
+	tot[1] = nchar;
+}
+// one lane per byte: consecutive lanes read consecutive bytes and -- inside a sequence line -- write consecutive bytes
+__global__ __launch_bounds__(256) void k_seq_copy(const uint8_t* __restrict__ bytes, uint64_t total, const unsigned long long* __restrict__ mask,
+                                                  const uint32_t* __restrict__ mpre, const uint64_t* __restrict__ tot, uint8_t* __restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total)
+		return;
+	const unsigned long long m = mask[i >> 6];
+	const uint32_t lane = (uint32_t)i & 63u;
+	if ((m >> lane) & 1ull)
+		out[tot[1] + (uint64_t)mpre[i >> 6] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = bytes[i];
+}
+
 struct PopcU64 {
 	__host__ __device__ uint32_t operator()(unsigned long long v) const
 	{
@@ -474,6 +556,45 @@ void front_valid_raw(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, 
 	                   fs.nlpos.as<uint32_t>(), fs.ok.as<uint8_t>(), nwords, (int)ix.prm.k, fs.valid.as<unsigned long long>());
 	BLMX_HIP(hipGetLastError());
 	popcount_prefix(fs, fs.valid.as<unsigned long long>(), nwords, fs.vpre.as<uint32_t>(), s);
+}
+
+// The sequences of a raw FASTA window (cut behind a newline unless it is the last one) appended to d_text / d_offs at the running
+// totals d_tot = [sequences, characters] (device-resident, advanced here).  d_carry as in front_valid_raw.  *d_short_flag is raised by
+// a sequence shorter than k.  The caller guarantees room for nbytes more characters and nbytes / (k + 1) + 1 more offsets.
+void front_seq_lines(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_carry_in, uint64_t* d_carry_out,
+                     int* d_short_flag, uint64_t* d_tot, uint8_t* d_text, uint64_t* d_offs, hipStream_t s)
+{
+	const uint64_t nwords = (nbytes + 63) / 64;
+	ensure_scratch(fs.marks, (nwords + 2) * 8, s);
+	ensure_scratch(fs.mpre, (nwords + 2) * 4, s);
+	ensure_scratch(fs.valid, (nwords + kBitmapPad) * 8, s);
+	ensure_scratch(fs.vpre, (nwords + kBitmapPad) * 4, s);
+	ensure_scratch(fs.nlpos, (nbytes + 2) * 4, s);  // at most one line per byte
+	ensure_scratch(fs.ok, nbytes + 2, s);
+	BLMX_HIP(hipMemsetAsync((char*)fs.marks.p + nwords * 8, 0, 16, s));
+	hipLaunchKernelGGL(k_raw_newlines, dim3(grid_for(nwords * 4, 256)), dim3(256), 0, s, d_bytes, nbytes, nwords, fs.marks.as<unsigned long long>());
+	BLMX_HIP(hipGetLastError());
+	popcount_prefix(fs, fs.marks.as<unsigned long long>(), nwords, fs.mpre.as<uint32_t>(), s);
+	hipLaunchKernelGGL(k_line_table, dim3(grid_for(nwords + 1, 256)), dim3(256), 0, s, fs.marks.as<unsigned long long>(), fs.mpre.as<uint32_t>(), nwords,
+	                   nbytes, fs.nlpos.as<uint32_t>());
+	hipLaunchKernelGGL(k_line_ok, dim3(1024), dim3(256), 0, s, d_bytes, fs.nlpos.as<uint32_t>(), fs.mpre.as<uint32_t>(), nwords, d_carry_in, d_carry_out,
+	                   (int)ix.prm.k, 0, fs.ok.as<uint8_t>(), d_short_flag);
+	BLMX_HIP(hipGetLastError());
+	// (the number of lines is only known on the device: everything below runs over the window's 64-byte words)
+	ensure_scratch(fs.lpre, (nwords + 2) * 8 + (nwords + 2) * 4, s);
+	unsigned long long* d_ends = fs.lpre.as<unsigned long long>();
+	uint32_t* d_epre = reinterpret_cast<uint32_t*>(d_ends + nwords + 2);
+	hipLaunchKernelGGL(k_seq_masks, dim3(grid_for(nwords, 256)), dim3(256), 0, s, fs.marks.as<unsigned long long>(), fs.mpre.as<uint32_t>(), fs.ok.as<uint8_t>(),
+	                   nwords, nbytes, fs.valid.as<unsigned long long>(), d_ends);
+	BLMX_HIP(hipGetLastError());
+	popcount_prefix(fs, fs.valid.as<unsigned long long>(), nwords, fs.vpre.as<uint32_t>(), s);
+	popcount_prefix(fs, d_ends, nwords, d_epre, s);
+	hipLaunchKernelGGL(k_seq_offsets, dim3(grid_for(nwords, 256)), dim3(256), 0, s, fs.valid.as<unsigned long long>(), fs.vpre.as<uint32_t>(), d_ends, d_epre, nwords,
+	                   d_tot, d_offs);
+	hipLaunchKernelGGL(k_seq_copy, dim3(grid_for(nbytes, 256)), dim3(256), 0, s, d_bytes, nbytes, fs.valid.as<unsigned long long>(), fs.vpre.as<uint32_t>(), d_tot,
+	                   d_text);
+	hipLaunchKernelGGL(k_seq_advance, dim3(1), dim3(1), 0, s, fs.ok.as<uint8_t>(), fs.mpre.as<uint32_t>(), fs.vpre.as<uint32_t>(), d_epre, nwords, d_tot, d_offs);
+	BLMX_HIP(hipGetLastError());
 }
 
 static FrontWhere where_of(const FrontScratch* fs, const uint64_t* offs, const uint64_t* koffs, uint64_t nseq)

@@ -489,13 +489,18 @@ void build_from_fasta_streamed(Index& ix, const char* path)
 	if (ix.built)
 		throw StatusError{BLMX_ESTATE, "index already built"};
 	DevBuf d_ascii, d_offs;
-	std::vector<uint64_t> offs;
-	uint64_t total = 0;
-	load_fasta_to_device(ix, path, d_ascii, offs, total);
-	const uint64_t nseq = offs.size() - 1;
-	BLMX_HIP(d_offs.alloc((nseq + 1) * 8, false, ix.stream));
-	BLMX_HIP(hipMemcpyAsync(d_offs.p, offs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
-	BLMX_HIP(hipStreamSynchronize(ix.stream));
+	uint64_t total = 0, nseq = 0;
+	const char* e = getenv("BLIGHT_HOST_PARSE");
+	if (e && atoi(e) != 0) {  // the round-2 reader: host threads parse the records (kept for comparison)
+		std::vector<uint64_t> offs;
+		load_fasta_to_device(ix, path, d_ascii, offs, total);
+		nseq = offs.size() - 1;
+		BLMX_HIP(d_offs.alloc((nseq + 1) * 8, false, ix.stream));
+		BLMX_HIP(hipMemcpyAsync(d_offs.p, offs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
+		BLMX_HIP(hipStreamSynchronize(ix.stream));
+	} else {
+		load_fasta_raw_to_device(ix, path, d_ascii, d_offs, nseq, total);
+	}
 	build_from_device(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), nseq, total);
 	ix.built = true;
 }
