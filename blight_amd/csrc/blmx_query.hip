@@ -671,7 +671,6 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	__shared__ uint32_t s_wsum[kBinThreads / 64];
 	static_assert(kBinThreads == kNB, "one bin per thread");
 	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	s_cnt[t] = 0;
 	{
 		const uint32_t nb = sp->nbins;
 		const uint32_t rb = t < nb ? sp->base[t] : 0u;
@@ -679,8 +678,13 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		s_rcap[t] = t < nb ? sp->base[t + 1] - rb : 0u;
 	}
 	const uint32_t ovf_at = sp->main_slots, all_slots = sp->main_slots + sp->ovf_cap, nbins_p = sp->nbins;
+	// A workgroup walks over tiles (grid = one workgroup per CU, or one per tile): the stores of one tile drain while the minimizers
+	// of the next are computed, the region table is loaded once, and there is no dispatch gap between tiles on a CU whose LDS holds
+	// only one of these workgroups.
+	for (uint64_t tile = blockIdx.x; tile * kTile < nq; tile += gridDim.x) {
+	s_cnt[t] = 0;
 	__syncthreads();
-	const uint64_t base = (uint64_t)blockIdx.x * kTile;
+	const uint64_t base = tile * kTile;
 	Kmer<KW> x[kPer];
 	uint32_t mini[kPer], rank[kPer];
 #pragma unroll
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		s_gbase[t] = g;
 		s_obase[t] = ob;
 		{
-			const size_t ri = (size_t)blockIdx.x * kNB + t;
+			const size_t ri = (size_t)tile * kNB + t;
 			rt.gbase[ri] = g;
 			rt.obase[ri] = ob;
 			rt.count[ri] = c;
@@ -765,6 +769,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 			slots[2 * dst] = s_keys[2 * sidx];
 			slots[2 * dst + 1] = s_keys[2 * sidx + 1];
 		}
+	}
+	__syncthreads();  // the staged tile has been read: the next one may overwrite it
 	}
 }
 
@@ -1106,6 +1112,16 @@ static void launch_query_slots_kw(const Index& ix, const SlotPlan* d_plan, uint3
 #undef BLMX_QS
 }
 
+// workgroups of k_bin_onepass: one per tile, or -- BLIGHT_ONEPASS_GRID=n -- n persistent ones that walk over the tiles
+static uint32_t onepass_grid(uint32_t nblk)
+{
+	static const int n = [] {
+		const char* e = getenv("BLIGHT_ONEPASS_GRID");
+		return e ? atoi(e) : 0;
+	}();
+	return n > 0 ? std::min<uint32_t>(nblk, (uint32_t)n) : nblk;
+}
+
 // 1024 bins for the one-pass partition (and for the exact pass in front of it, which it learns from): its runs are written region by
 // region, and with the histogram pass gone the query kernel's gain from finer bins (3.9 -> 3.5 ms at C4) is no longer eaten by the
 // passes around it (C4: 6.14 -> 5.73 ms per step)
@@ -1162,11 +1178,12 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	ix.prof_mark(2, s);
 	ix.prof_mark(3, s);
+	const uint32_t pgrid = onepass_grid(nblk);
 	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
+		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
 		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt);
 	else
-		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
+		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
 		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt);
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(4, s);
@@ -1307,11 +1324,12 @@ void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const u
 	hipLaunchKernelGGL(k_plan_make, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac_sharded.as<float>() : nullptr, n, nbins, pct, (uint32_t)sp.max_main,
 	                   (uint32_t)n, 1024u, sp.plan.as<SlotPlan>(), sp.cursors.as<uint32_t>());
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
+	const uint32_t pgrid = onepass_grid(sp.nblk);
 	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(sp.nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
+		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
 		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
 	else
-		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(sp.nblk), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
+		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
 		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
 	FirstBins f;
 	f.world = world;
