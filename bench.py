@@ -892,6 +892,7 @@ def main():
                                                                     st["number_kmer"], k, k, m, n, b, nq, 100 * args.present, 100 * (1 - args.present)),
                        "parallelism": "1 GPU" if not multi else ("%s x%d" % (effective_mode, world)),
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"],
+                       "build_scratch_peak_bytes": st["build_scratch_peak_bytes"],
                        "build_seconds": t_build, "build_seconds_filter_armed": t_build_armed,
                        "build_kmers_per_sec": st["number_kmer"] / t_build_armed,
                        "build_note": "build_seconds: until construct_index returned (queries are answered from then on, unfiltered); "

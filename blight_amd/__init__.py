@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblight_mi355x.so")
 
-ABI_VERSION = 10  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
+ABI_VERSION = 11  # must equal BLMX_ABI_VERSION of include/blight_mi355x.h (struct layouts mirrored below)
 BLMX_OK, BLMX_EINVAL, BLMX_ESHORT, BLMX_EDNA, BLMX_EIO, BLMX_EHIP, BLMX_ENOMEM, BLMX_ESTATE, BLMX_ELIMIT, BLMX_ERCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 COMM_ID_BYTES = 128
 
@@ -35,7 +35,7 @@ class blmx_stats_t(C.Structure):
                [(n, C.c_uint32) for n in ("nbuckets", "ngroups", "k", "m", "log2_mphf", "bits_saved", "kmer_bytes",
                                           "max_levels_used")] + [("build_seconds", C.c_double), ("local_number_kmer", C.c_uint64)] + \
                [(n, C.c_uint32) for n in ("shard_rank", "shard_world", "shard_group_lo", "shard_group_hi", "mphf_groups_lds_built",
-                                          "reserved0")]
+                                          "reserved0")] + [("build_scratch_peak_bytes", C.c_uint64)]
 
 
 _lib = None

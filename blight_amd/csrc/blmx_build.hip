@@ -1373,7 +1373,10 @@ struct BuildPoolScope {
 	}
 	~BuildPoolScope()
 	{
+		BuildPool* used = BuildPool::current();
 		BuildPool::current() = nullptr;
+		if (defer_to && used)
+			defer_to->st.build_scratch_peak_bytes = std::max<uint64_t>(defer_to->st.build_scratch_peak_bytes, used->peak_held);
 		if (defer_to && defer_to->filter_state.load() == 0) {
 			defer_to->deferred_blocks.insert(defer_to->deferred_blocks.end(), own.free_blocks.begin(), own.free_blocks.end());
 			own.free_blocks.clear();
@@ -1540,6 +1543,7 @@ template <int KW>
 void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
 {
 	const auto t_begin = std::chrono::steady_clock::now();
+	ix.st.build_scratch_peak_bytes = 0;
 	struct StartThread {  // declared before the pool scope: runs after it has parked its blocks in the index
 		Index& ix;
 		~StartThread() { ix.start_filter_thread(); }
@@ -2405,7 +2409,7 @@ void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in
 		Index& ix;
 		~Cleanup() { shard_build_abort(ix); }
 	} cleanup{ix};
-	BuildPoolScope scope(&x->pool);
+	BuildPoolScope scope(&x->pool, &ix);  // (records the exchange pool's high-water mark in the stats)
 	PhaseMarks mark(s);
 	Scratch sc;
 	sc.s = s;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -85,11 +86,14 @@ struct BuildPool {
 		size_t bytes;
 	};
 	std::vector<Block> free_blocks;
+	size_t held = 0, peak_held = 0;  // bytes this pool holds from the driver (live temporaries + parked blocks), and their high-water mark
 	~BuildPool() { drain(); }
 	void drain()
 	{
-		for (const Block& b : free_blocks)
+		for (const Block& b : free_blocks) {
 			(void)hipFree(b.p);
+			held -= std::min(held, b.bytes);
+		}
 		free_blocks.clear();
 	}
 	hipError_t get(size_t n, void** p, size_t* bytes)
@@ -112,6 +116,10 @@ struct BuildPool {
 			e = hipMalloc(p, n);
 		}
 		*bytes = n;
+		if (e == hipSuccess) {
+			held += n;
+			peak_held = std::max(peak_held, held);
+		}
 		return e;
 	}
 	void put(void* p, size_t bytes) { free_blocks.push_back(Block{p, bytes}); }

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout; blmx_abi_version() returns the value the library was built with,
  * so a stale caller binary is detected instead of corrupting memory. */
-#define BLMX_ABI_VERSION 10
+#define BLMX_ABI_VERSION 11
 
 #define BLMX_OK 0
 #define BLMX_EINVAL (-1)  /* bad parameter: std::invalid_argument in the reference ctor, blight.h:75-92            */
@@ -76,6 +76,8 @@ typedef struct blmx_stats_t {
 	uint32_t shard_rank, shard_world, shard_group_lo, shard_group_hi;
 	uint32_t mphf_groups_lds_built; /* MPHF groups built by the LDS-staged kernel (the rest: global level kernels) */
 	uint32_t reserved0;
+	uint64_t build_scratch_peak_bytes; /* HBM the last build held for its temporaries at its peak (next to the finished arrays and the
+	                                    * caller's input); given back when the build -- and the filter's background passes -- are done */
 } blmx_stats_t;
 
 /* ctor / dtor.  On failure *out is NULL and blmx_create_error() returns the reference's exception text
