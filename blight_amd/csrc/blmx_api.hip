@@ -180,6 +180,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.tune_partition = env_int("BLIGHT_PARTITION", 0);
 	h->ix.tune_window_kb = env_int("BLIGHT_WINDOW_KB", 0);
 	h->ix.tune_fat_lines = env_int("BLIGHT_FAT_LINES", 1);
+	h->ix.tune_build_passes = env_int("BLIGHT_BUILD_PASSES", 0);
 	if (hipSetDevice(prm.device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
 		g_create_err = "hipStreamCreate failed";
 		delete h;
@@ -798,6 +799,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_slot_piece_min = value;
 	else if (k == "fat_lines")  // before building
 		ix.tune_fat_lines = value != 0;
+	else if (k == "build_passes")  // before building: 0 = automatic
+		ix.tune_build_passes = value < 0 ? 0 : (value > 64 ? 64 : value);
 	else if (k == "query_binning")
 		ix.bin_policy = value < 0 ? -1 : (value > 0 ? 1 : 0);
 	else

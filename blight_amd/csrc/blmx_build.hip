@@ -286,6 +286,23 @@ __global__ void k_owner_segments(const uint32_t* __restrict__ sorted_owner, uint
 	seg_first[d] = lo;
 }
 
+// out[t] = first index i in [0, n) with arr[i] >= target[t] (n if none); arr non-decreasing
+__global__ void k_lower_bounds(const uint64_t* __restrict__ arr, uint64_t n, const uint64_t* __restrict__ target, uint32_t m, uint64_t* __restrict__ out)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= m)
+		return;
+	uint64_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (arr[mid] < target[t])
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	out[t] = lo;
+}
+
 __device__ __forceinline__ uint32_t segment_of(const OwnerTable& t, uint64_t i)
 {
 	uint32_t r = 0;
@@ -490,13 +507,13 @@ __device__ __forceinline__ uint32_t sk_of_key(const uint64_t* s_ks, uint32_t nj,
 
 template <int KW>
 __global__ __launch_bounds__(kBlock) void k_expand_keys(const uint64_t* __restrict__ src, const uint32_t* __restrict__ order,
-                                                        const uint64_t* __restrict__ sk_pos, const uint64_t* __restrict__ key_start, uint64_t nsk,
-                                                        int k, uint64_t* __restrict__ keys)
+                                                        const uint64_t* __restrict__ sk_pos, const uint64_t* __restrict__ key_start, uint64_t j_begin,
+                                                        uint64_t j_end, int k, uint64_t* __restrict__ keys)
 {
 	__shared__ uint64_t s_ks[kSkPerBlock + 1];
 	__shared__ uint64_t s_p[kSkPerBlock];
-	const uint64_t j0 = (uint64_t)blockIdx.x * kSkPerBlock;
-	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, nsk - j0);
+	const uint64_t j0 = j_begin + (uint64_t)blockIdx.x * kSkPerBlock;  // the sorted super-k-mers [j_begin, j_end) (a pass of the build)
+	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, j_end - j0);
 	for (uint32_t t = threadIdx.x; t <= nj; t += kBlock)
 		s_ks[t] = key_start[j0 + t];
 	for (uint32_t t = threadIdx.x; t < nj; t += kBlock)
@@ -900,9 +917,9 @@ __global__ void k_sliced_finish(const uint32_t* __restrict__ glist, uint32_t nla
 
 // first work list of the global level kernels: the key indices of the groups that do NOT fit the LDS path
 __global__ void k_seed_large_list(const uint64_t* __restrict__ g_prefix, const uint8_t* __restrict__ small, const uint64_t* __restrict__ seed_off,
-                                  uint32_t ngroups, uint32_t* __restrict__ list)
+                                  uint32_t ngroups, uint32_t* __restrict__ list, uint32_t g_base)
 {
-	const uint32_t g = blockIdx.x;
+	const uint32_t g = g_base + blockIdx.x;
 	if (g >= ngroups || small[g])
 		return;
 	const uint64_t kb = g_prefix[g], n = g_prefix[g + 1] - kb, o = seed_off[g];
@@ -919,9 +936,9 @@ __global__ void k_widen_u32(const uint32_t* __restrict__ in, uint64_t n, uint64_
 
 // fallback keys of the LDS-built groups -> global key indices appended to the fallback list
 __global__ void k_fb_collect(const uint64_t* __restrict__ g_prefix, const uint32_t* __restrict__ fb_count, const uint64_t* __restrict__ fb_off,
-                             const uint32_t* __restrict__ listA, uint32_t ngroups, uint64_t* __restrict__ fb_list)
+                             const uint32_t* __restrict__ listA, uint32_t ngroups, uint64_t* __restrict__ fb_list, uint32_t g_base)
 {
-	const uint32_t g = blockIdx.x;
+	const uint32_t g = g_base + blockIdx.x;
 	if (g >= ngroups)
 		return;
 	const uint32_t c = fb_count[g];
@@ -980,11 +997,12 @@ __device__ __forceinline__ uint64_t logical_line_unit(const GroupDesc* __restric
 	return lrel < F ? gd->line_base + lrel * kFatUnits : gd->line_base + F * kFatUnits + (lrel - F);
 }
 
-__global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
+__global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t L0, uint64_t nlines,
                             const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
                             uint64_t* __restrict__ linepc, bool fat)
 {
-	const uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t L = L0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // the logical lines [L0, nlines) (a pass of the build)
+	linepc -= L0;
 	if (L > nlines)
 		return;
 	if (L == nlines) {
@@ -999,11 +1017,12 @@ __global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t
 	linepc[L] = pc;
 }
 
-__global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t nlines,
+__global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t L0, uint64_t nlines,
                              const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
                              const uint64_t* __restrict__ linepre, uint4* __restrict__ lines, bool fat)
 {
-	const uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t L = L0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	linepre -= L0;
 	if (L >= nlines)
 		return;
 	const uint32_t g = group_of_line(line_base, ngroups, L);
@@ -1018,13 +1037,13 @@ __global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_
 }
 
 // total set bits per group (= first fallback rank, bbhash.h:554)
-__global__ void k_group_popc(const uint64_t* __restrict__ line_base, const uint64_t* __restrict__ linepre, uint32_t ngroups,
+__global__ void k_group_popc(const uint64_t* __restrict__ line_base, const uint64_t* __restrict__ linepre, uint32_t g_begin, uint32_t g_end, uint64_t L0,
                              uint64_t* __restrict__ g_popc)
 {
-	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= ngroups)
+	const uint64_t g = g_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= g_end)
 		return;
-	g_popc[g] = linepre[line_base[g + 1]] - linepre[line_base[g]];
+	g_popc[g] = linepre[line_base[g + 1] - L0] - linepre[line_base[g] - L0];
 }
 
 // ---- K9: fallback -----------------------------------------------------------------------------------------------------
@@ -1103,17 +1122,18 @@ __global__ void k_fb_table(const uint32_t* __restrict__ perm, uint64_t F, const 
 // k_fb_positions (a duplicated key keeps the position of its LAST occurrence: assignment order).
 template <int KW>
 __global__ __launch_bounds__(kBlock) void k_fill_positions(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ nt_start,
-                                                           const uint64_t* __restrict__ key_start, uint64_t nsk, const uint64_t* __restrict__ keys,
+                                                           const uint64_t* __restrict__ key_start, uint64_t j_begin, uint64_t nsk, const uint64_t* __restrict__ keys,
                                                            uint64_t id_base, uint32_t* __restrict__ field_of_rank)
 {
 	__shared__ uint64_t s_ks[kSkPerBlock + 1];
 	__shared__ uint64_t s_pos0[kSkPerBlock];
 	__shared__ uint32_t s_mini[kSkPerBlock];
+	// (the sorted super-k-mers [j_begin, nsk): a pass of the build)
 	// XCD-major block order (workgroup b runs on XCD b % 8; the grid is a multiple of 8): XCD x takes the x-th contiguous
 	// eighth of the sorted super-k-mers, so that the ~600 KB rank range a group's scattered 4-B stores fall into is owned by
 	// ONE L2, which merges them into full lines, instead of being written in pieces from all eight (90 -> 65 ms at C4)
 	const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-	const uint64_t j0 = (uint64_t)blk * kSkPerBlock;
+	const uint64_t j0 = j_begin + (uint64_t)blk * kSkPerBlock;
 	if (j0 >= nsk)
 		return;
 	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, nsk - j0);
@@ -1170,12 +1190,12 @@ __global__ void k_fb_positions(DeviceIndexView v, const uint32_t* __restrict__ p
 // hundred KB of one group's region (XCD-major block order: one L2 owns it).
 template <int KW>
 __global__ __launch_bounds__(kBlock) void k_filter_keys(DeviceIndexView v, const uint32_t* __restrict__ smini, const uint64_t* __restrict__ key_start,
-                                                        uint64_t nsk, const uint64_t* __restrict__ keys, unsigned long long* __restrict__ filter)
+                                                        uint64_t j_begin, uint64_t nsk, const uint64_t* __restrict__ keys, unsigned long long* __restrict__ filter)
 {
 	__shared__ uint64_t s_ks[kSkPerBlock + 1];
 	__shared__ uint32_t s_mini[kSkPerBlock];
 	const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-	const uint64_t j0 = (uint64_t)blk * kSkPerBlock;
+	const uint64_t j0 = j_begin + (uint64_t)blk * kSkPerBlock;
 	if (j0 >= nsk)
 		return;
 	const uint32_t nj = (uint32_t)min((uint64_t)kSkPerBlock, nsk - j0);
@@ -1260,11 +1280,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_junctions(DeviceIndexView v, 
 // ORed atomically (the array is zero-initialised), every other word is a plain store.
 constexpr int kPackThreads = 512;       // one output word per thread and chunk
 constexpr uint32_t kPackFields = 16384;  // fields staged per chunk (64 KB of LDS)
-__global__ __launch_bounds__(kPackThreads) void k_pack_positions(const GroupDesc* __restrict__ groups, uint64_t id_base,
+__global__ __launch_bounds__(kPackThreads) void k_pack_positions(const GroupDesc* __restrict__ groups, uint32_t g_base, uint64_t id_base,
                                                                  const uint32_t* __restrict__ field_of_rank, unsigned long long* __restrict__ positions)
 {
 	__shared__ uint32_t s_f[kPackFields];
-	const GroupDesc* gd = &groups[blockIdx.x];
+	const GroupDesc* gd = &groups[g_base + blockIdx.x];
 	const uint64_t n = gd->nkeys;
 	const uint32_t nbits = gd->nbits;
 	if (n == 0 || nbits == 0)
@@ -1827,7 +1847,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		largest_bucket = std::max(largest_bucket, h_gmax[g]);
 	}
 	h_line_base[ngroups] = lbase;
-	const uint64_t total_words = wbase, total_lines = lbase, total_units = ubase;
+	const uint64_t total_words = wbase, total_units = ubase;
 
 	DevBuf d_loff, d_line_base, d_bgroups;
 	BLMX_HIP(d_loff.alloc(h_loff.size() * 8, false, s));
@@ -1856,28 +1876,64 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	}
 
 	mark("K5 scatter_pack");
-	// ---- K6: keys in (bucket, position) order
-	DevBuf d_keys;
-	BLMX_HIP(d_keys.alloc((N + 1) * 8 * KW, false, s));
-	if (nsk)
-		hipLaunchKernelGGL((k_expand_keys<KW>), dim3(grid_for(nsk, kSkPerBlock)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
-		                   d_skpos.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, k, d_keys.as<uint64_t>());
-	BLMX_HIP(hipGetLastError());
-	BLMX_HIP(hipStreamSynchronize(s));
-	d_src.release();
-	d_skpos.release();
-	d_order.release();
+	// ---- K6 .. K9b in PASSES over ranges of MPHF groups (the reference builds one of 2^s super-buckets at a time to bound its memory,
+	// blight.cpp:335-356; log2_superbuckets = s bounds the number of passes here).  Keys, survivor lists and position fields only exist
+	// for the groups of the current pass; everything a pass produces (level bits -> lines, fallback entries, positions) goes straight
+	// into the finished arrays.  Groups are independent from K6 on, so the arrays do not depend on the number of passes.
+	uint32_t npass = 1;
+	{
+		// automatic: as few passes as keep a pass at or below 2^30 keys (keys + two survivor lists + fields = 20 B per key of the pass)
+		const uint32_t cap = 1u << std::min<uint32_t>(ix.prm.log2_superbuckets, 6u);
+		const int forced = ix.tune_build_passes;
+		uint64_t want = forced > 0 ? (uint64_t)forced : (N + (1ull << 30) - 1) >> 30;
+		while (npass < want && npass < (forced > 0 ? 64u : cap) && npass < ngroups)
+			npass <<= 1;
+	}
+	std::vector<uint32_t> pg(npass + 1, 0);  // group boundaries of the passes, balanced by keys
+	pg[npass] = ngroups;
+	for (uint32_t p = 1; p < npass; p++) {
+		const uint64_t target = (uint64_t)(((unsigned __int128)N * p) / npass);
+		pg[p] = (uint32_t)(std::lower_bound(h_gpre.begin(), h_gpre.end(), target) - h_gpre.begin());
+		pg[p] = std::max(pg[p], pg[p - 1]);
+	}
+	auto key_at = [&](uint32_t g) -> uint64_t { return g < ngroups ? h_gpre[g] : N; };  // first key of group g (local numbering)
+	// first sorted super-k-mer of every pass: its keys start at the pass's first key
+	std::vector<uint64_t> pj(npass + 1, 0);
+	pj[npass] = nsk;
+	if (npass > 1 && nsk) {
+		std::vector<uint64_t> tgt(npass + 1);
+		for (uint32_t p = 0; p <= npass; p++)
+			tgt[p] = key_at(pg[p]);
+		DevBuf d_tgt, d_lb;
+		BLMX_HIP(d_tgt.alloc(tgt.size() * 8, false, s));
+		BLMX_HIP(d_lb.alloc(tgt.size() * 8, false, s));
+		BLMX_HIP(hipMemcpyAsync(d_tgt.p, tgt.data(), tgt.size() * 8, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_lower_bounds, dim3(1), dim3(128), 0, s, d_keystart.as<uint64_t>(), nsk, d_tgt.as<uint64_t>(), npass + 1, d_lb.as<uint64_t>());
+		BLMX_HIP(hipGetLastError());
+		BLMX_HIP(hipMemcpyAsync(pj.data(), d_lb.p, pj.size() * 8, hipMemcpyDeviceToHost, s));
+		BLMX_HIP(hipStreamSynchronize(s));
+		pj[0] = 0;
+		pj[npass] = nsk;
+	}
+	uint64_t max_keys = 0, max_lines = 0;
+	for (uint32_t p = 0; p < npass; p++) {
+		max_keys = std::max(max_keys, key_at(pg[p + 1]) - key_at(pg[p]));
+		max_lines = std::max(max_lines, h_line_base[pg[p + 1]] - h_line_base[pg[p]]);
+	}
 
-	mark("K6 expand_keys");
-	// ---- K7: BBHash levels.  Groups whose level-0 array fits the LDS budget are built by one workgroup each
-	// (k_mphf_group_lds); the others go through the global level kernels, which skip the keys of the LDS-built groups.
-	DevBuf d_bits, d_coll, d_listA, d_listB, d_cnt, d_small, d_fbcnt, d_fboff, d_lvmax, d_fball;
+	// what every pass writes into
+	DevBuf d_bits, d_coll, d_cnt, d_small, d_fbcnt, d_lvmax, d_lvcnt, d_gpopc, d_gfbstart, d_gfbcount;
 	BLMX_HIP(d_bits.alloc((total_words + 1) * 8, true, s));
 	BLMX_HIP(d_coll.alloc((total_words + 1) * 8, true, s));
 	BLMX_HIP(d_cnt.alloc(8, true, s));
+	BLMX_HIP(d_fbcnt.alloc((size_t)ngroups * 4, true, s));
+	BLMX_HIP(d_lvmax.alloc(4, true, s));
+	BLMX_HIP(d_gpopc.alloc(((size_t)ngroups + 1) * 8, true, s));
+	BLMX_HIP(d_gfbstart.alloc((size_t)ngroups * 8, true, s));
+	BLMX_HIP(d_gfbcount.alloc((size_t)ngroups * 4, true, s));
+	BLMX_HIP(ix.lines.alloc((total_units + 1) * kLineBytes, true, s));
 	std::vector<uint8_t> h_small(ngroups, 0);  // 1 = one workgroup builds all levels in LDS, 2 = one workgroup per (level, slice), 0 = global kernels
-	uint64_t n_small = 0, keys_large = 0;
-	std::vector<uint32_t> h_sliced;
+	uint64_t n_small = 0, n_sliced = 0;
 	const char* lds_env = getenv("BLIGHT_BUILD_NO_LDS");  // test hook: 1 = global level kernels for every group, 2 = for the groups above the
 	const int lds_off = lds_env ? atoi(lds_env) : 0;      //            single-workgroup budget only (no sliced path)
 	for (uint32_t g = 0; g < ngroups; g++) {
@@ -1887,265 +1943,21 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			n_small++;
 		} else if (gd.nkeys && lds_off == 0 && gd.nkeys < 0xffffffffull) {
 			h_small[g] = 2;
-			h_sliced.push_back(g);
-		} else {
-			keys_large += gd.nkeys;
+			n_sliced++;
 		}
 	}
 	BLMX_HIP(d_small.alloc((size_t)ngroups, false, s));
 	BLMX_HIP(hipMemcpyAsync(d_small.p, h_small.data(), ngroups, hipMemcpyHostToDevice, s));
+	if (n_sliced)
+		BLMX_HIP(d_lvcnt.alloc((size_t)(kLevels + 1) * ngroups * 4, true, s));
 	BuildGroups bg{d_gpre.as<uint64_t>(), d_bgroups.as<GroupDesc>(), d_loff.as<uint64_t>(), ngroups, d_small.as<uint8_t>()};
-	int levels_used = 0;
-	uint64_t F_lds = 0;
-	std::vector<uint64_t> h_fboff;
-	if (n_small || !h_sliced.empty()) {
-		DevBuf d_lA, d_lB;
-		BLMX_HIP(d_lA.alloc((N + 1) * 4, false, s));
-		BLMX_HIP(d_lB.alloc((N + 1) * 4, false, s));
-		BLMX_HIP(d_fbcnt.alloc((size_t)ngroups * 4, true, s));
-		BLMX_HIP(d_lvmax.alloc(4, true, s));
-		if (!h_sliced.empty()) {
-			// work items (group, slice) of every level, largest groups first inside a level
-			std::sort(h_sliced.begin(), h_sliced.end(), [&](uint32_t a, uint32_t b2) {
-				return ix.h_groups[a].nkeys != ix.h_groups[b2].nkeys ? ix.h_groups[a].nkeys > ix.h_groups[b2].nkeys : a < b2;
-			});
-			std::vector<uint2> h_items;
-			size_t level_off[kLevels + 1];
-			for (int l = 0; l < kLevels; l++) {
-				level_off[l] = h_items.size();
-				for (uint32_t g : h_sliced) {
-					const uint32_t words = (uint32_t)(ix.h_groups[g].size[l] >> 5);
-					for (uint32_t sl = 0; sl * kLdsLevelWords < words; sl++)
-						h_items.push_back(make_uint2(g, sl));
-				}
-			}
-			level_off[kLevels] = h_items.size();
-			DevBuf d_items, d_lvcnt, d_glist;
-			BLMX_HIP(d_items.alloc(h_items.size() * sizeof(uint2), false, s));
-			BLMX_HIP(d_lvcnt.alloc((size_t)(kLevels + 1) * ngroups * 4, true, s));
-			BLMX_HIP(d_glist.alloc(h_sliced.size() * 4, false, s));
-			BLMX_HIP(hipMemcpyAsync(d_items.p, h_items.data(), h_items.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
-			BLMX_HIP(hipMemcpyAsync(d_glist.p, h_sliced.data(), h_sliced.size() * 4, hipMemcpyHostToDevice, s));
-			for (int l = 0; l < kLevels; l++) {
-				const size_t ni = level_off[l + 1] - level_off[l];
-				if (ni)
-					hipLaunchKernelGGL((k_mphf_level_sliced<KW>), dim3((unsigned)ni), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(), l,
-					                   d_items.as<uint2>() + level_off[l], d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_lvcnt.as<uint32_t>(),
-					                   d_bits.as<uint32_t>());
-				if (trace) {
-					char what[64];
-					snprintf(what, sizeof what, "  K7 sliced level %d (%zu wg)", l, ni);
-					mark(what);
-				}
-			}
-			hipLaunchKernelGGL(k_sliced_finish, dim3(grid_for(h_sliced.size())), dim3(kBlock), 0, s, d_glist.as<uint32_t>(), (uint32_t)h_sliced.size(),
-			                   ngroups, d_lvcnt.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>());
-			BLMX_HIP(hipGetLastError());
-			BLMX_HIP(hipStreamSynchronize(s));  // the host vectors and the item buffers go out of scope
-		}
-		std::vector<uint32_t> h_order;
-		h_order.reserve(n_small);
-		for (uint32_t g = 0; g < ngroups; g++)
-			if (h_small[g] == 1)
-				h_order.push_back(g);
-		std::sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b2) {
-			return ix.h_groups[a].nkeys != ix.h_groups[b2].nkeys ? ix.h_groups[a].nkeys > ix.h_groups[b2].nkeys : a < b2;
-		});
-		DevBuf d_gorder;
-		if (!h_order.empty()) {
-			BLMX_HIP(d_gorder.alloc(h_order.size() * 4, false, s));
-			BLMX_HIP(hipMemcpyAsync(d_gorder.p, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, s));
-			hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3((unsigned)h_order.size()), dim3(kGroupBlock), 0, s, bg, d_keys.as<uint64_t>(),
-			                   d_lA.as<uint32_t>(), d_lB.as<uint32_t>(), d_bits.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>(),
-			                   d_gorder.as<uint32_t>());
-			BLMX_HIP(hipGetLastError());
-		}
-		std::vector<uint32_t> h_fbcnt(ngroups);
-		BLMX_HIP(hipMemcpyAsync(h_fbcnt.data(), d_fbcnt.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
-		levels_used = read_scalar(d_lvmax.as<int>(), s);
-		h_fboff.assign(ngroups, 0);
-		for (uint32_t g = 0; g < ngroups; g++) {
-			h_fboff[g] = F_lds;
-			F_lds += h_fbcnt[g];
-		}
-		if (F_lds) {
-			BLMX_HIP(d_fboff.alloc((size_t)ngroups * 8, false, s));
-			BLMX_HIP(hipMemcpyAsync(d_fboff.p, h_fboff.data(), (size_t)ngroups * 8, hipMemcpyHostToDevice, s));
-			BLMX_HIP(d_fball.alloc((F_lds + 1) * 8, false, s));
-			hipLaunchKernelGGL(k_fb_collect, dim3(ngroups), dim3(256), 0, s, d_gpre.as<uint64_t>(), d_fbcnt.as<uint32_t>(), d_fboff.as<uint64_t>(),
-			                   d_lA.as<uint32_t>(), ngroups, d_fball.as<uint64_t>());
-			BLMX_HIP(hipGetLastError());
-		}
-		BLMX_HIP(hipStreamSynchronize(s));
-	}
-	// global path: seeded with the keys of the large groups only (all keys when the LDS path is unused)
-	if (keys_large && N >= 0xffffffffull)
-		throw StatusError{BLMX_ELIMIT, "the global MPHF level kernels index keys with 32 bits (an MPHF group of 2^32 keys or more, or BLIGHT_BUILD_NO_LDS)"};
-	uint64_t count = keys_large;
-	const uint32_t* cur = nullptr;
-	uint32_t* nxt = nullptr;
-	uint64_t F = 0;
-	DevBuf d_seed, d_seedoff;
-	if (keys_large && (n_small || !h_sliced.empty())) {
-		std::vector<uint64_t> h_seedoff(ngroups, 0);
-		uint64_t o = 0;
-		for (uint32_t g = 0; g < ngroups; g++) {
-			h_seedoff[g] = o;
-			if (!h_small[g])
-				o += ix.h_groups[g].nkeys;
-		}
-		BLMX_HIP(d_seedoff.alloc((size_t)ngroups * 8, false, s));
-		BLMX_HIP(hipMemcpyAsync(d_seedoff.p, h_seedoff.data(), (size_t)ngroups * 8, hipMemcpyHostToDevice, s));
-		BLMX_HIP(d_seed.alloc((keys_large + 1) * 4, false, s));
-		hipLaunchKernelGGL(k_seed_large_list, dim3(ngroups), dim3(256), 0, s, d_gpre.as<uint64_t>(), d_small.as<uint8_t>(), d_seedoff.as<uint64_t>(),
-		                   ngroups, d_seed.as<uint32_t>());
-		BLMX_HIP(hipGetLastError());
-		BLMX_HIP(hipStreamSynchronize(s));  // h_seedoff goes out of scope
-		cur = d_seed.as<uint32_t>();
-	}
-	for (int level = 0; level < kLevels && count > 0; level++) {
-		levels_used = std::max(levels_used, level + 1);
-		hipLaunchKernelGGL((k_mphf_mark<KW>), dim3(grid_for(count)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
-		                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>());
-		// survivors list: at most `count` entries (level 0 walks all keys and skips those of the LDS-built groups)
-		DevBuf& dst = (level & 1) ? d_listB : d_listA;
-		BLMX_HIP(dst.alloc((std::min(count, keys_large) + 1) * 4, false, s));
-		nxt = dst.as<uint32_t>();
-		BLMX_HIP(hipMemsetAsync(d_cnt.p, 0, 8, s));
-		hipLaunchKernelGGL((k_mphf_survive<KW>), dim3(grid_for(count, kSurviveBlock)), dim3(kSurviveBlock), 0, s, bg, d_keys.as<uint64_t>(), cur, count, level,
-		                   d_coll.as<unsigned long long>(), nxt, d_cnt.as<unsigned long long>());
-		BLMX_HIP(hipGetLastError());
-		count = read_scalar(d_cnt.as<unsigned long long>(), s);
-		cur = nxt;
-		if (level == kLevels - 1)
-			F = count;
-	}
-	// one fallback list of absolute key indices: the global path's survivors followed by those of the LDS-built groups
-	// (sorted by key index below)
-	const uint64_t* fb_all = nullptr;
-	{
-		DevBuf d_merge;
-		BLMX_HIP(d_merge.alloc((F + F_lds + 1) * 8, false, s));
-		if (F)
-			hipLaunchKernelGGL(k_widen_u32, dim3(grid_for(F)), dim3(kBlock), 0, s, cur, F, d_merge.as<uint64_t>());
-		if (F_lds)
-			BLMX_HIP(hipMemcpyAsync(d_merge.as<uint64_t>() + F, d_fball.p, F_lds * 8, hipMemcpyDeviceToDevice, s));
-		BLMX_HIP(hipGetLastError());
-		BLMX_HIP(hipStreamSynchronize(s));
-		std::swap(d_fball.p, d_merge.p);
-		std::swap(d_fball.bytes, d_merge.bytes);
-		fb_all = d_fball.as<uint64_t>();
-		F += F_lds;
-		if (F >= 0xffffffffull)
-			throw StatusError{BLMX_ELIMIT, "2^32 - 1 or more fallback keys"};
-	}
-
-	mark("K7 mphf levels");
-	// ---- K8: collisions cleared + ranks -> 16-B lines [u32 rank | 96 bits]
-	DevBuf d_linepc, d_linepre, d_gpopc;
-	BLMX_HIP(d_linepc.alloc((total_lines + 1) * 8, false, s));
-	BLMX_HIP(d_linepre.alloc((total_lines + 1) * 8, false, s));
-	BLMX_HIP(d_gpopc.alloc(((size_t)ngroups + 1) * 8, false, s));
-	BLMX_HIP(ix.lines.alloc((total_units + 1) * kLineBytes, true, s));
-	hipLaunchKernelGGL(k_line_popc, dim3(grid_for(total_lines + 1)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
-	                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>(), fat);
-	BLMX_HIP(hipGetLastError());
-	exclusive_scan_u64(sc, d_linepc.as<uint64_t>(), d_linepre.as<uint64_t>(), total_lines + 1, s);
-	if (total_lines)
-		hipLaunchKernelGGL(k_line_write, dim3(grid_for(total_lines)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(),
-		                   ngroups, total_lines, d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepre.as<uint64_t>(),
-		                   ix.lines.as<uint4>(), fat);
-	hipLaunchKernelGGL(k_group_popc, dim3(grid_for(ngroups)), dim3(kBlock), 0, s, d_line_base.as<uint64_t>(), d_linepre.as<uint64_t>(), ngroups,
-	                   d_gpopc.as<uint64_t>());
-	BLMX_HIP(hipGetLastError());
-	BLMX_HIP(hipStreamSynchronize(s));
-	d_bits.release();
-	d_coll.release();
-	d_linepc.release();
-
-	mark("K8 lines+ranks");
-	// ---- K9a: fallback table
-	DevBuf d_fbsorted, d_fk, d_frank, d_fgrp, d_perm, d_tgrp, d_gfbstart, d_gfbcount;
-	BLMX_HIP(ix.fb_keys.alloc((F + 1) * 8 * KW, true, s));
-	BLMX_HIP(ix.fb_ranks.alloc((F + 1) * 8, true, s));
-	ix.h_fb_group.clear();
-	if (F) {
-		BLMX_HIP(d_fbsorted.alloc(F * 8, false, s));
-		size_t bytes = 0;
-		unsigned idx_bits = 1;
-		while (idx_bits < 64 && (N >> idx_bits))
-			idx_bits++;
-		BLMX_HIP(rocprim::radix_sort_keys(nullptr, bytes, fb_all, d_fbsorted.as<uint64_t>(), (size_t)F, 0u, idx_bits, s));
-		void* tmp = sc.get(bytes);
-		BLMX_HIP(rocprim::radix_sort_keys(tmp, bytes, fb_all, d_fbsorted.as<uint64_t>(), (size_t)F, 0u, idx_bits, s));
-		BLMX_HIP(d_fk.alloc(F * 8 * KW, false, s));
-		BLMX_HIP(d_frank.alloc(F * 8, false, s));
-		BLMX_HIP(d_fgrp.alloc(F * 4, false, s));
-		hipLaunchKernelGGL((k_fb_prepare<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, bg, d_keys.as<uint64_t>(), d_fbsorted.as<uint64_t>(), F,
-		                   d_gpopc.as<uint64_t>(), d_fk.as<uint64_t>(), d_frank.as<uint64_t>(), d_fgrp.as<uint32_t>());
-		BLMX_HIP(hipGetLastError());
-		// table order = (group, key, input order).  The entries arrive in input order (= group, position), so two or three
-		// STABLE radix sorts do it: by the key (low word, then high word), then by the group -- a comparison sort through an
-		// indirect comparator took 100 ms for the 3.7e7 fallback keys of the skewed human-scale input.
-		BLMX_HIP(d_perm.alloc(F * 4, false, s));
-		{
-			DevBuf d_k0, d_k1, d_p0, d_p1;
-			BLMX_HIP(d_k0.alloc(F * 8, false, s));
-			BLMX_HIP(d_k1.alloc(F * 8, false, s));
-			BLMX_HIP(d_p0.alloc(F * 4, false, s));
-			BLMX_HIP(d_p1.alloc(F * 4, false, s));
-			auto sort_by = [&](const uint64_t* kin, const uint32_t* pin, uint32_t* pout, unsigned bits) {
-				size_t nb = 0;
-				BLMX_HIP(rocprim::radix_sort_pairs(nullptr, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)F, 0u, bits, s));
-				void* t2 = sc.get(nb);
-				BLMX_HIP(rocprim::radix_sort_pairs(t2, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)F, 0u, bits, s));
-			};
-			hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(F)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), (const uint32_t*)nullptr, F,
-			                   KW, 0, d_k0.as<uint64_t>(), d_p0.as<uint32_t>());
-			sort_by(d_k0.as<uint64_t>(), d_p0.as<uint32_t>(), d_p1.as<uint32_t>(), 64u);
-			uint32_t* cur_p = d_p1.as<uint32_t>();
-			uint32_t* other_p = d_p0.as<uint32_t>();
-			if (KW == 2) {
-				hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(F)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), cur_p, F, KW, 1,
-				                   d_k0.as<uint64_t>(), (uint32_t*)nullptr);
-				sort_by(d_k0.as<uint64_t>(), cur_p, other_p, 64u);
-				std::swap(cur_p, other_p);
-			}
-			hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(F)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), cur_p, F, KW, 2,
-			                   d_k0.as<uint64_t>(), (uint32_t*)nullptr);
-			sort_by(d_k0.as<uint64_t>(), cur_p, d_perm.as<uint32_t>(), 32u);
-			BLMX_HIP(hipGetLastError());
-			BLMX_HIP(hipStreamSynchronize(s));
-		}
-		BLMX_HIP(d_tgrp.alloc(F * 4, false, s));
-		BLMX_HIP(d_gfbstart.alloc((size_t)ngroups * 8, true, s));
-		BLMX_HIP(d_gfbcount.alloc((size_t)ngroups * 4, true, s));
-		hipLaunchKernelGGL((k_fb_table<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, d_perm.as<uint32_t>(), F, d_fk.as<uint64_t>(),
-		                   d_frank.as<uint64_t>(), d_fgrp.as<uint32_t>(), ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(),
-		                   d_tgrp.as<uint32_t>(), d_gfbstart.as<uint64_t>(), d_gfbcount.as<uint32_t>());
-		BLMX_HIP(hipGetLastError());
-		std::vector<uint64_t> h_fs(ngroups);
-		std::vector<uint32_t> h_fc(ngroups);
-		ix.h_fb_group.resize(F);
-		BLMX_HIP(hipMemcpyAsync(h_fs.data(), d_gfbstart.p, (size_t)ngroups * 8, hipMemcpyDeviceToHost, s));
-		BLMX_HIP(hipMemcpyAsync(h_fc.data(), d_gfbcount.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, s));
-		BLMX_HIP(hipMemcpyAsync(ix.h_fb_group.data(), d_tgrp.p, F * 4, hipMemcpyDeviceToHost, s));
-		BLMX_HIP(hipStreamSynchronize(s));
-		for (uint32_t g = 0; g < ngroups; g++) {
-			ix.h_groups[g].fb_start = h_fs[g];
-			ix.h_groups[g].fb_count = h_fc[g] ? h_fc[g] - (uint32_t)h_fs[g] : 0;
-		}
-	}
-	// final group table (with fallback ranges); a shard's IDs are global: add the key count of all lower groups
+	// final group table minus the fallback ranges (they are only known after the passes; the kernels of the passes do not read them);
+	// a shard's IDs are global: add the key count of all lower groups
 	if (id_base)
 		for (uint32_t g = 0; g < ngroups; g++)
 			ix.h_groups[g].prefix += id_base;
 	BLMX_HIP(ix.groups.alloc((size_t)ngroups * sizeof(GroupDesc), false, s));
 	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
-	make_query_heads(ix);
-
-	mark("K9a fallback");
-	// ---- K9b: positions
 	ix.positions_words = phys_pos / 64 + 3;
 	BLMX_HIP(ix.positions.alloc(ix.positions_words * 8, true, s));
 	ix.st.total_nt = total_nt;
@@ -2161,28 +1973,336 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		ix.filter_bpk = bpk;
 		init_filter_gate(ix, s);
 	}
-	{
-		DeviceIndexView v = ix.view();
-		v.filter = ix.filter_bpk ? (fat ? ix.lines.as<uint64_t>() : ix.filter.as<uint64_t>()) : nullptr;  // whatever the query-time switch says
-		v.id_base = id_base;
-		const bool have_filter = ix.filter_bpk != 0;
-		unsigned long long* d_filter = (have_filter && !fat) ? ix.filter.as<unsigned long long>() : nullptr;
-		DevBuf d_field;  // position field of every local rank (ranks nobody owns -- overwritten duplicates -- stay 0 like in the reference)
-		BLMX_HIP(d_field.alloc((N + 1) * 4, true, s));
-		if (nsk)
-			hipLaunchKernelGGL((k_fill_positions<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(),
-			                   d_keystart.as<uint64_t>(), nsk, d_keys.as<uint64_t>(), id_base, d_field.as<uint32_t>());
-		if (F)
-			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(F)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint64_t>(), F,
-			                   ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(),
-			                   d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, id_base, d_field.as<uint32_t>());
-		if (N)
-			hipLaunchKernelGGL(k_pack_positions, dim3(ngroups), dim3(kPackThreads), 0, s, ix.groups.as<GroupDesc>(), id_base, d_field.as<uint32_t>(),
-			                   ix.positions.as<unsigned long long>());
+	const bool have_filter = ix.filter_bpk != 0;
+	unsigned long long* d_filter = (have_filter && !fat) ? ix.filter.as<unsigned long long>() : nullptr;
+	DeviceIndexView v = ix.view();
+	v.filter = have_filter ? (fat ? ix.lines.as<uint64_t>() : ix.filter.as<uint64_t>()) : nullptr;  // whatever the query-time switch says
+	v.id_base = id_base;
+	v.fb_keys = nullptr;  // (not built yet; k_fill_positions does not look there)
+
+	// buffers of ONE pass: keys, two survivor lists, position fields, line popcounts
+	DevBuf d_keys, d_lA, d_lB, d_field, d_linepc, d_linepre;
+	BLMX_HIP(d_keys.alloc((max_keys + 1) * 8 * KW, false, s));
+	if (n_small || n_sliced) {
+		BLMX_HIP(d_lA.alloc((max_keys + 1) * 4, false, s));
+		BLMX_HIP(d_lB.alloc((max_keys + 1) * 4, false, s));
+	}
+	BLMX_HIP(d_field.alloc((max_keys + 1) * 4, false, s));
+	BLMX_HIP(d_linepc.alloc((max_lines + 2) * 8, false, s));
+	BLMX_HIP(d_linepre.alloc((max_lines + 2) * 8, false, s));
+	// the fallback table grows pass by pass (groups in increasing order = table order)
+	std::vector<std::unique_ptr<DevBuf>> fb_tk, fb_trank;
+	std::vector<uint64_t> fb_count_of_pass;
+	ix.h_fb_group.clear();
+	uint64_t F = 0;
+	int levels_used = 0;
+	mark("passes: setup");
+
+	for (uint32_t p = 0; p < npass; p++) {
+		const uint32_t g0 = pg[p], g1 = pg[p + 1];
+		const uint64_t kb0 = key_at(g0), kb1 = key_at(g1), Np = kb1 - kb0, j0 = pj[p], j1 = pj[p + 1];
+		if (Np == 0)
+			continue;
+		// absolute key numbers index the pass buffers: pointers shifted by the pass's first key
+		uint64_t* keys_p = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(d_keys.p) - (uintptr_t)kb0 * 8 * KW);
+		uint32_t* lA_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(d_lA.p) - (uintptr_t)kb0 * 4);
+		uint32_t* lB_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(d_lB.p) - (uintptr_t)kb0 * 4);
+		uint32_t* field_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(d_field.p) - (uintptr_t)kb0 * 4);
+		// ---- K6: keys in (bucket, position) order
+		hipLaunchKernelGGL((k_expand_keys<KW>), dim3(grid_for(j1 - j0, kSkPerBlock)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
+		                   d_skpos.as<uint64_t>(), d_keystart.as<uint64_t>(), j0, j1, k, keys_p);
 		BLMX_HIP(hipGetLastError());
+		if (npass == 1)
+			mark("K6 expand_keys");
+		// ---- K7: BBHash levels.  Groups whose level-0 array fits the LDS budget are built by one workgroup each
+		// (k_mphf_group_lds); the others go through the global level kernels, which skip the keys of the LDS-built groups.
+		std::vector<uint32_t> h_order, h_sliced;
+		uint64_t keys_large = 0;
+		for (uint32_t g = g0; g < g1; g++) {
+			if (h_small[g] == 1)
+				h_order.push_back(g);
+			else if (h_small[g] == 2)
+				h_sliced.push_back(g);
+			else
+				keys_large += ix.h_groups[g].nkeys;
+		}
+		auto by_size = [&](uint32_t a, uint32_t b2) { return ix.h_groups[a].nkeys != ix.h_groups[b2].nkeys ? ix.h_groups[a].nkeys > ix.h_groups[b2].nkeys : a < b2; };
+		uint64_t F_lds = 0;
+		DevBuf d_fball;
+		if (!h_order.empty() || !h_sliced.empty()) {
+			if (!h_sliced.empty()) {
+				// work items (group, slice) of every level, largest groups first inside a level
+				std::sort(h_sliced.begin(), h_sliced.end(), by_size);
+				std::vector<uint2> h_items;
+				size_t level_off[kLevels + 1];
+				for (int l = 0; l < kLevels; l++) {
+					level_off[l] = h_items.size();
+					for (uint32_t g : h_sliced) {
+						const uint32_t words = (uint32_t)(ix.h_groups[g].size[l] >> 5);
+						for (uint32_t sl = 0; sl * kLdsLevelWords < words; sl++)
+							h_items.push_back(make_uint2(g, sl));
+					}
+				}
+				level_off[kLevels] = h_items.size();
+				DevBuf d_items, d_glist;
+				BLMX_HIP(d_items.alloc(h_items.size() * sizeof(uint2), false, s));
+				BLMX_HIP(d_glist.alloc(h_sliced.size() * 4, false, s));
+				BLMX_HIP(hipMemcpyAsync(d_items.p, h_items.data(), h_items.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+				BLMX_HIP(hipMemcpyAsync(d_glist.p, h_sliced.data(), h_sliced.size() * 4, hipMemcpyHostToDevice, s));
+				for (int l = 0; l < kLevels; l++) {
+					const size_t ni = level_off[l + 1] - level_off[l];
+					if (ni)
+						hipLaunchKernelGGL((k_mphf_level_sliced<KW>), dim3((unsigned)ni), dim3(kGroupBlock), 0, s, bg, keys_p, l, d_items.as<uint2>() + level_off[l], lA_p,
+						                   lB_p, d_lvcnt.as<uint32_t>(), d_bits.as<uint32_t>());
+					if (trace) {
+						char what[64];
+						snprintf(what, sizeof what, "  K7 sliced level %d (%zu wg)", l, ni);
+						mark(what);
+					}
+				}
+				hipLaunchKernelGGL(k_sliced_finish, dim3(grid_for(h_sliced.size())), dim3(kBlock), 0, s, d_glist.as<uint32_t>(), (uint32_t)h_sliced.size(),
+				                   ngroups, d_lvcnt.as<uint32_t>(), d_fbcnt.as<uint32_t>(), d_lvmax.as<int>());
+				BLMX_HIP(hipGetLastError());
+				BLMX_HIP(hipStreamSynchronize(s));  // the host vectors and the item buffers go out of scope
+			}
+			DevBuf d_gorder;
+			if (!h_order.empty()) {
+				std::sort(h_order.begin(), h_order.end(), by_size);  // largest groups first: the multi-slice groups must not be the tail of the grid
+				BLMX_HIP(d_gorder.alloc(h_order.size() * 4, false, s));
+				BLMX_HIP(hipMemcpyAsync(d_gorder.p, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, s));
+				hipLaunchKernelGGL((k_mphf_group_lds<KW>), dim3((unsigned)h_order.size()), dim3(kGroupBlock), 0, s, bg, keys_p, lA_p, lB_p, d_bits.as<uint32_t>(),
+				                   d_fbcnt.as<uint32_t>(), d_lvmax.as<int>(), d_gorder.as<uint32_t>());
+				BLMX_HIP(hipGetLastError());
+			}
+			std::vector<uint32_t> h_fbcnt(g1 - g0);
+			BLMX_HIP(hipMemcpyAsync(h_fbcnt.data(), d_fbcnt.as<uint32_t>() + g0, (size_t)(g1 - g0) * 4, hipMemcpyDeviceToHost, s));
+			BLMX_HIP(hipStreamSynchronize(s));
+			std::vector<uint64_t> h_fboff(ngroups, 0);
+			for (uint32_t g = g0; g < g1; g++) {
+				h_fboff[g] = F_lds;
+				F_lds += h_fbcnt[g - g0];
+			}
+			if (F_lds) {
+				DevBuf d_fboff;
+				BLMX_HIP(d_fboff.alloc((size_t)ngroups * 8, false, s));
+				BLMX_HIP(hipMemcpyAsync(d_fboff.p, h_fboff.data(), (size_t)ngroups * 8, hipMemcpyHostToDevice, s));
+				BLMX_HIP(d_fball.alloc((F_lds + 1) * 8, false, s));
+				hipLaunchKernelGGL(k_fb_collect, dim3(g1 - g0), dim3(256), 0, s, d_gpre.as<uint64_t>(), d_fbcnt.as<uint32_t>(), d_fboff.as<uint64_t>(), lA_p, ngroups,
+				                   d_fball.as<uint64_t>(), g0);
+				BLMX_HIP(hipGetLastError());
+				BLMX_HIP(hipStreamSynchronize(s));  // h_fboff / d_fboff go out of scope
+			}
+		}
+		// global path: seeded with the keys of the large groups only
+		if (keys_large && N >= 0xffffffffull)
+			throw StatusError{BLMX_ELIMIT, "the global MPHF level kernels index keys with 32 bits (an MPHF group of 2^32 keys or more, or BLIGHT_BUILD_NO_LDS)"};
+		uint64_t count = keys_large, Fg = 0;
+		const uint32_t* cur = nullptr;
+		uint32_t* nxt = nullptr;
+		DevBuf d_seed, d_listA, d_listB;
+		if (keys_large) {
+			std::vector<uint64_t> h_seedoff(ngroups, 0);
+			uint64_t o = 0;
+			for (uint32_t g = g0; g < g1; g++) {
+				h_seedoff[g] = o;
+				if (!h_small[g])
+					o += ix.h_groups[g].nkeys;
+			}
+			DevBuf d_seedoff;
+			BLMX_HIP(d_seedoff.alloc((size_t)ngroups * 8, false, s));
+			BLMX_HIP(hipMemcpyAsync(d_seedoff.p, h_seedoff.data(), (size_t)ngroups * 8, hipMemcpyHostToDevice, s));
+			BLMX_HIP(d_seed.alloc((keys_large + 1) * 4, false, s));
+			hipLaunchKernelGGL(k_seed_large_list, dim3(g1 - g0), dim3(256), 0, s, d_gpre.as<uint64_t>(), d_small.as<uint8_t>(), d_seedoff.as<uint64_t>(), ngroups,
+			                   d_seed.as<uint32_t>(), g0);
+			BLMX_HIP(hipGetLastError());
+			BLMX_HIP(hipStreamSynchronize(s));  // h_seedoff goes out of scope
+			cur = d_seed.as<uint32_t>();
+		}
+		for (int level = 0; level < kLevels && count > 0; level++) {
+			levels_used = std::max(levels_used, level + 1);
+			hipLaunchKernelGGL((k_mphf_mark<KW>), dim3(grid_for(count)), dim3(kBlock), 0, s, bg, keys_p, cur, count, level, d_bits.as<unsigned long long>(),
+			                   d_coll.as<unsigned long long>());
+			DevBuf& dst = (level & 1) ? d_listB : d_listA;
+			BLMX_HIP(dst.alloc((std::min(count, keys_large) + 1) * 4, false, s));
+			nxt = dst.as<uint32_t>();
+			BLMX_HIP(hipMemsetAsync(d_cnt.p, 0, 8, s));
+			hipLaunchKernelGGL((k_mphf_survive<KW>), dim3(grid_for(count, kSurviveBlock)), dim3(kSurviveBlock), 0, s, bg, keys_p, cur, count, level,
+			                   d_coll.as<unsigned long long>(), nxt, d_cnt.as<unsigned long long>());
+			BLMX_HIP(hipGetLastError());
+			count = read_scalar(d_cnt.as<unsigned long long>(), s);
+			cur = nxt;
+			if (level == kLevels - 1)
+				Fg = count;
+		}
+		// one fallback list of absolute key indices: the global path's survivors followed by those of the LDS-built groups
+		// (sorted by key index below)
+		const uint64_t Fp = Fg + F_lds;
+		if (F + Fp >= 0xffffffffull)
+			throw StatusError{BLMX_ELIMIT, "2^32 - 1 or more fallback keys"};
+		DevBuf d_fbmerged;
+		if (Fp) {
+			BLMX_HIP(d_fbmerged.alloc((Fp + 1) * 8, false, s));
+			if (Fg)
+				hipLaunchKernelGGL(k_widen_u32, dim3(grid_for(Fg)), dim3(kBlock), 0, s, cur, Fg, d_fbmerged.as<uint64_t>());
+			if (F_lds)
+				BLMX_HIP(hipMemcpyAsync(d_fbmerged.as<uint64_t>() + Fg, d_fball.p, F_lds * 8, hipMemcpyDeviceToDevice, s));
+			BLMX_HIP(hipGetLastError());
+		}
+		if (npass == 1)
+			mark("K7 mphf levels");
+		// ---- K8: collisions cleared + ranks -> lines [u32 rank | 96 bits] of this pass's groups
+		const uint64_t L0 = h_line_base[g0], L1 = h_line_base[g1];
+		hipLaunchKernelGGL(k_line_popc, dim3(grid_for(L1 - L0 + 1)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(), ngroups, L0, L1,
+		                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>(), fat);
+		BLMX_HIP(hipGetLastError());
+		exclusive_scan_u64(sc, d_linepc.as<uint64_t>(), d_linepre.as<uint64_t>(), L1 - L0 + 1, s);
+		if (L1 > L0)
+			hipLaunchKernelGGL(k_line_write, dim3(grid_for(L1 - L0)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(), ngroups, L0, L1,
+			                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepre.as<uint64_t>(), ix.lines.as<uint4>(), fat);
+		hipLaunchKernelGGL(k_group_popc, dim3(grid_for(g1 - g0)), dim3(kBlock), 0, s, d_line_base.as<uint64_t>(), d_linepre.as<uint64_t>(), g0, g1, L0,
+		                   d_gpopc.as<uint64_t>());
+		BLMX_HIP(hipGetLastError());
+		if (npass == 1)
+			mark("K8 lines+ranks");
+		// ---- K9a: fallback table of this pass's groups
+		DevBuf d_fbsorted, d_perm, d_tgrp;
+		DevBuf* tk = nullptr;
+		DevBuf* trank = nullptr;
+		if (Fp) {
+			DevBuf d_fk, d_frank, d_fgrp;
+			BLMX_HIP(d_fbsorted.alloc(Fp * 8, false, s));
+			size_t bytes = 0;
+			unsigned idx_bits = 1;
+			while (idx_bits < 64 && (N >> idx_bits))
+				idx_bits++;
+			BLMX_HIP(rocprim::radix_sort_keys(nullptr, bytes, d_fbmerged.as<uint64_t>(), d_fbsorted.as<uint64_t>(), (size_t)Fp, 0u, idx_bits, s));
+			void* tmp = sc.get(bytes);
+			BLMX_HIP(rocprim::radix_sort_keys(tmp, bytes, d_fbmerged.as<uint64_t>(), d_fbsorted.as<uint64_t>(), (size_t)Fp, 0u, idx_bits, s));
+			BLMX_HIP(d_fk.alloc(Fp * 8 * KW, false, s));
+			BLMX_HIP(d_frank.alloc(Fp * 8, false, s));
+			BLMX_HIP(d_fgrp.alloc(Fp * 4, false, s));
+			hipLaunchKernelGGL((k_fb_prepare<KW>), dim3(grid_for(Fp)), dim3(kBlock), 0, s, bg, keys_p, d_fbsorted.as<uint64_t>(), Fp, d_gpopc.as<uint64_t>(),
+			                   d_fk.as<uint64_t>(), d_frank.as<uint64_t>(), d_fgrp.as<uint32_t>());
+			BLMX_HIP(hipGetLastError());
+			// table order = (group, key, input order).  The entries arrive in input order (= group, position), so two or three
+			// STABLE radix sorts do it: by the key (low word, then high word), then by the group -- a comparison sort through an
+			// indirect comparator took 100 ms for the 3.7e7 fallback keys of the skewed human-scale input.
+			BLMX_HIP(d_perm.alloc(Fp * 4, false, s));
+			{
+				DevBuf d_k0, d_k1, d_p0, d_p1;
+				BLMX_HIP(d_k0.alloc(Fp * 8, false, s));
+				BLMX_HIP(d_k1.alloc(Fp * 8, false, s));
+				BLMX_HIP(d_p0.alloc(Fp * 4, false, s));
+				BLMX_HIP(d_p1.alloc(Fp * 4, false, s));
+				auto sort_by = [&](const uint64_t* kin, const uint32_t* pin, uint32_t* pout, unsigned bits) {
+					size_t nb = 0;
+					BLMX_HIP(rocprim::radix_sort_pairs(nullptr, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)Fp, 0u, bits, s));
+					void* t2 = sc.get(nb);
+					BLMX_HIP(rocprim::radix_sort_pairs(t2, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)Fp, 0u, bits, s));
+				};
+				hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(Fp)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), (const uint32_t*)nullptr, Fp, KW, 0,
+				                   d_k0.as<uint64_t>(), d_p0.as<uint32_t>());
+				sort_by(d_k0.as<uint64_t>(), d_p0.as<uint32_t>(), d_p1.as<uint32_t>(), 64u);
+				uint32_t* cur_p = d_p1.as<uint32_t>();
+				uint32_t* other_p = d_p0.as<uint32_t>();
+				if (KW == 2) {
+					hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(Fp)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), cur_p, Fp, KW, 1,
+					                   d_k0.as<uint64_t>(), (uint32_t*)nullptr);
+					sort_by(d_k0.as<uint64_t>(), cur_p, other_p, 64u);
+					std::swap(cur_p, other_p);
+				}
+				hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(Fp)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), cur_p, Fp, KW, 2, d_k0.as<uint64_t>(),
+				                   (uint32_t*)nullptr);
+				sort_by(d_k0.as<uint64_t>(), cur_p, d_perm.as<uint32_t>(), 32u);
+				BLMX_HIP(hipGetLastError());
+				BLMX_HIP(hipStreamSynchronize(s));
+			}
+			fb_tk.emplace_back(new DevBuf());
+			fb_trank.emplace_back(new DevBuf());
+			tk = fb_tk.back().get();
+			trank = fb_trank.back().get();
+			BLMX_HIP(tk->alloc((Fp + 1) * 8 * KW, false, s));
+			BLMX_HIP(trank->alloc((Fp + 1) * 8, false, s));
+			fb_count_of_pass.push_back(Fp);
+			BLMX_HIP(d_tgrp.alloc(Fp * 4, false, s));
+			hipLaunchKernelGGL((k_fb_table<KW>), dim3(grid_for(Fp)), dim3(kBlock), 0, s, d_perm.as<uint32_t>(), Fp, d_fk.as<uint64_t>(), d_frank.as<uint64_t>(),
+			                   d_fgrp.as<uint32_t>(), tk->as<uint64_t>(), trank->as<uint64_t>(), d_tgrp.as<uint32_t>(), d_gfbstart.as<uint64_t>(),
+			                   d_gfbcount.as<uint32_t>());
+			BLMX_HIP(hipGetLastError());
+			std::vector<uint64_t> h_fs(g1 - g0);
+			std::vector<uint32_t> h_fc(g1 - g0);
+			const size_t at = ix.h_fb_group.size();
+			ix.h_fb_group.resize(at + Fp);
+			BLMX_HIP(hipMemcpyAsync(h_fs.data(), d_gfbstart.as<uint64_t>() + g0, (size_t)(g1 - g0) * 8, hipMemcpyDeviceToHost, s));
+			BLMX_HIP(hipMemcpyAsync(h_fc.data(), d_gfbcount.as<uint32_t>() + g0, (size_t)(g1 - g0) * 4, hipMemcpyDeviceToHost, s));
+			BLMX_HIP(hipMemcpyAsync(ix.h_fb_group.data() + at, d_tgrp.p, Fp * 4, hipMemcpyDeviceToHost, s));
+			BLMX_HIP(hipStreamSynchronize(s));
+			for (uint32_t g = g0; g < g1; g++) {  // (k_fb_table numbers the entries of THIS pass: the table of the passes before lies in front)
+				ix.h_groups[g].fb_start = h_fc[g - g0] ? F + h_fs[g - g0] : 0;
+				ix.h_groups[g].fb_count = h_fc[g - g0] ? h_fc[g - g0] - (uint32_t)h_fs[g - g0] : 0;
+			}
+		}
+		if (npass == 1)
+			mark("K9a fallback");
+		// ---- K9b: positions of this pass's keys
+		BLMX_HIP(hipMemsetAsync(d_field.p, 0, (Np + 1) * 4, s));  // ranks nobody owns -- overwritten duplicates -- stay 0 like in the reference
+		hipLaunchKernelGGL((k_fill_positions<KW>), dim3((grid_for(j1 - j0, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(),
+		                   d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), j0, j1, keys_p, id_base, field_p);
+		if (Fp)
+			hipLaunchKernelGGL((k_fb_positions<KW>), dim3(grid_for(Fp)), dim3(kBlock), 0, s, v, d_perm.as<uint32_t>(), d_fbsorted.as<uint64_t>(), Fp, tk->as<uint64_t>(),
+			                   trank->as<uint64_t>(), d_tgrp.as<uint32_t>(), d_smini.as<uint32_t>(), d_ntstart.as<uint64_t>(), d_keystart.as<uint64_t>(), nsk, id_base,
+			                   field_p);
+		hipLaunchKernelGGL(k_pack_positions, dim3(g1 - g0), dim3(kPackThreads), 0, s, ix.groups.as<GroupDesc>(), g0, id_base, field_p,
+		                   ix.positions.as<unsigned long long>());
+		// the filter's first pass needs the keys: with several passes it runs here, pass by pass (with one pass: in the background, below)
+		if (have_filter && npass > 1)
+			hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(j1 - j0, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(),
+			                   d_keystart.as<uint64_t>(), j0, j1, keys_p, d_filter);
+		BLMX_HIP(hipGetLastError());
+		BLMX_HIP(hipStreamSynchronize(s));  // the pass's temporaries go out of scope
+		F += Fp;
+		if (npass > 1 && trace) {
+			char what[64];
+			snprintf(what, sizeof what, "pass %u of %u (%llu keys)", p + 1, npass, (unsigned long long)Np);
+			mark(what);
+		}
+	}
+	levels_used = std::max(levels_used, read_scalar(d_lvmax.as<int>(), s));
+	d_src.release();
+	d_skpos.release();
+	d_order.release();
+	d_bits.release();
+	d_coll.release();
+	d_lA.release();
+	d_lB.release();
+	d_field.release();
+	d_linepc.release();
+	d_linepre.release();
+	// the fallback table: the passes' segments back to back
+	BLMX_HIP(ix.fb_keys.alloc((F + 1) * 8 * KW, true, s));
+	BLMX_HIP(ix.fb_ranks.alloc((F + 1) * 8, true, s));
+	{
+		uint64_t at = 0;
+		for (size_t i = 0; i < fb_tk.size(); i++) {
+			const uint64_t c = fb_count_of_pass[i];
+			BLMX_HIP(hipMemcpyAsync(ix.fb_keys.as<uint64_t>() + at * KW, fb_tk[i]->p, c * 8 * KW, hipMemcpyDeviceToDevice, s));
+			BLMX_HIP(hipMemcpyAsync(ix.fb_ranks.as<uint64_t>() + at, fb_trank[i]->p, c * 8, hipMemcpyDeviceToDevice, s));
+			at += c;
+		}
 		BLMX_HIP(hipStreamSynchronize(s));
-		mark("K9b positions");
-		// second pass of the filter, on its own stream: the build does not wait for it, queries use the filter once it is done
+		fb_tk.clear();
+		fb_trank.clear();
+	}
+	// final group table (with the fallback ranges)
+	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
+	make_query_heads(ix);
+	v = ix.view();
+	v.filter = have_filter ? (fat ? ix.lines.as<uint64_t>() : ix.filter.as<uint64_t>()) : nullptr;
+	v.id_base = id_base;
+	mark(npass == 1 ? "K9b positions" : "passes: fallback table + group table");
+	{
+		// the filter's passes on their own stream: the build does not wait for them, queries use the filter once they are done.  With one
+		// pass: every key (k_filter_keys) and the junction k-mers; with several: the junction k-mers (the keys went in pass by pass).
 		ix.filter_wait();
 		ix.filter_state.store(2);
 		if (have_filter && nsk) {
@@ -2190,19 +2310,25 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 				BLMX_HIP(hipStreamCreateWithFlags(&ix.bg_stream, hipStreamNonBlocking));
 			if (!ix.filter_ready)
 				BLMX_HIP(hipEventCreateWithFlags(&ix.filter_ready, hipEventDisableTiming));
-			// what the two passes read leaves the build's pool with them (the helper thread frees it)
+			// what the passes read leaves the build's pool with them (the helper thread frees it)
 			DevBuf* hand_over[4] = {&d_ntstart, &d_smini, &d_keystart, &d_keys};
 			for (int i = 0; i < 4; i++) {
 				ix.filter_pending[i].release();
+				if (i > 0 && npass > 1)
+					continue;  // only the super-k-mer starts are still needed
 				ix.filter_pending[i].p = hand_over[i]->p;
 				ix.filter_pending[i].bytes = hand_over[i]->bytes;
 				ix.filter_pending[i].owner = nullptr;
+				if (hand_over[i]->owner)
+					hand_over[i]->owner->held -= std::min(hand_over[i]->owner->held, hand_over[i]->bytes);
 				hand_over[i]->p = nullptr;
 				hand_over[i]->bytes = 0;
+				hand_over[i]->owner = nullptr;
 			}
 			ix.filter_state.store(0);
-			hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, ix.bg_stream, v,
-			                   ix.filter_pending[1].as<uint32_t>(), ix.filter_pending[2].as<uint64_t>(), nsk, ix.filter_pending[3].as<uint64_t>(), d_filter);
+			if (npass == 1)
+				hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, ix.bg_stream, v,
+				                   ix.filter_pending[1].as<uint32_t>(), ix.filter_pending[2].as<uint64_t>(), (uint64_t)0, nsk, ix.filter_pending[3].as<uint64_t>(), d_filter);
 			if (ix.tune_filter_junctions) {
 				const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1) + (uint64_t)(k - 1) + (1ull << b), blocks = (cand + kBlock - 1) / kBlock;
 				const unsigned gx = (unsigned)std::min<uint64_t>(blocks, 1u << 22), gy = (unsigned)((blocks + gx - 1) / gx);
@@ -2229,7 +2355,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	st.shard_world = world;
 	st.shard_group_lo = glo;
 	st.shard_group_hi = ghi;
-	st.mphf_groups_lds_built = (uint32_t)(n_small + h_sliced.size());
+	st.mphf_groups_lds_built = (uint32_t)(n_small + n_sliced);
 	st.largest_mphf = largest_mphf;
 	st.positions_total_size = total_pos;
 	st.total_nt = total_nt;

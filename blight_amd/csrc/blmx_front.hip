@@ -983,7 +983,9 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 			cap_offs = no;
 		}
 	};
+	Trace tr;
 	reserve(0);
+	tr.lap("allocate text+offsets", 0);
 	hipEvent_t copied[kWindowSlots] = {};
 	struct EvGuard {
 		hipEvent_t* e;
@@ -1000,7 +1002,6 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 		BLMX_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
 	bool used[kWindowSlots] = {};
 	FrontScratch& fs = hf.win[0].fs;
-	Trace tr;
 	for (uint64_t i = 0;; i++) {
 		const int slot = (int)(i % kWindowSlots);
 		WindowSlot& w = hf.win[slot];
@@ -1026,6 +1027,7 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 	uint64_t h_state[8] = {};
 	BLMX_HIP(hipMemcpyAsync(h_state, d_state.p, 64, hipMemcpyDeviceToHost, s));
 	BLMX_HIP(hipStreamSynchronize(s));
+	tr.lap("wait for the device", 0);
 	if (*reinterpret_cast<const int*>(&h_state[6]))
 		throw StatusError{BLMX_ESHORT, "a sequence is shorter than k"};
 	nseq = h_state[4];

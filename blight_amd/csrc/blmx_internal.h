@@ -321,6 +321,7 @@ struct Index {
 	                             // position hint of the wide windows; BLIGHT_FILTER_BITS)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
 	int tune_fat_lines = 1;      // build: with 8 filter bits per key the filter lives inside 64-B level-0 lines (0 = separate filter array, 16-B lines)
+	int tune_build_passes = 0;   // build: passes over ranges of MPHF groups (0 = automatic: at most 2^log2_superbuckets, <= 2^30 keys per pass)
 	int tune_slot_piece_min = 0; // sharded exchange: pieces of at least this many k-mers travel as bin regions (0 = default 2^19; tests lower it)
 
 	Index()

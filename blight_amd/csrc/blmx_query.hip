@@ -1112,12 +1112,19 @@ static void launch_query_slots_kw(const Index& ix, const SlotPlan* d_plan, uint3
 #undef BLMX_QS
 }
 
-// workgroups of k_bin_onepass: one per tile, or -- BLIGHT_ONEPASS_GRID=n -- n persistent ones that walk over the tiles
+// workgroups of k_bin_onepass: three per compute unit that walk over the tiles (one per tile: 1.55 ms per 1e8 at C4; 512 .. 2048
+// walking workgroups: 1.45 - 1.48 ms, profiles/r03_exp_onepass_grid_c4.txt); BLIGHT_ONEPASS_GRID=n overrides (0 = one per tile)
 static uint32_t onepass_grid(uint32_t nblk)
 {
 	static const int n = [] {
 		const char* e = getenv("BLIGHT_ONEPASS_GRID");
-		return e ? atoi(e) : 0;
+		if (e)
+			return atoi(e);
+		int dev = 0, cus = 256;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+			cus = prop.multiProcessorCount;
+		return 3 * cus;
 	}();
 	return n > 0 ? std::min<uint32_t>(nblk, (uint32_t)n) : nblk;
 }

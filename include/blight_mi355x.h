@@ -313,6 +313,12 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
  *   "query_heads"    0: query kernels read the full group descriptor instead of the compact head
  *   "reads_mode"     sequence / file queries: 0 automatic, 1 front end fused with the query body, 2 front end -> partitioned pipeline
  *   "window_kb"      KiB of characters per front-end window
+ *   "fat_lines"      before building: 0 = the absent-key filter in an array of its own and 16-byte MPHF lines throughout (default 1: with 8
+ *                    filter bits per key the filter lives inside 64-byte level-0 lines, one request for filter test and level-0 probe)
+ *   "build_passes"   before building: the construction expands keys, builds the MPHFs and fills the positions for one range of MPHF
+ *                    groups at a time (the reference: one of 2^log2_superbuckets super-buckets at a time, blight.cpp:335-356), which
+ *                    bounds its scratch memory.  0 = automatic (as few passes as keep a pass below 2^30 keys, at most
+ *                    2^min(log2_superbuckets, 6)); n > 0 = that many (rounded up to a power of two).  The index does not depend on it.
  *   "slot_piece_min" sharded exchange: pieces of a batch with at least this many k-mers travel as the one-pass partition's bin regions
  *                    (k-mers + minimizers out, 4-byte IDs back); smaller ones, and the first batch of an index, as dense per-owner
  *                    segments (0 = default 2^19).  The same on every rank is not required: the format travels with the counts.

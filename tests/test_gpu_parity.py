@@ -464,3 +464,46 @@ def test_absent_filter_keeps_every_answer_of_the_reference(B, O, k, kb, m, n, b,
     none.construct_index_from_sequences(seqs)
     assert np.array_equal(none.query_kmer_hash(q.reshape(-1)), want)
     assert none.stats()["device_bytes"] < ix.stats()["device_bytes"]
+
+
+@pytest.mark.parametrize("k,kb,m,n,b,fat", [(31, 8, 7, 5, 6, 1), (31, 8, 9, 7, 4, 0), (63, 16, 9, 7, 8, 1)])
+def test_build_passes_do_not_change_the_index(B, O, k, kb, m, n, b, fat):
+    """The construction works through the MPHF groups in passes (keys, survivor lists and position fields of one range of groups at a
+    time: the reference builds one of 2^s super-buckets at a time, blight.cpp:335-356).  Every array, counter and answer is the same for
+    1, 2, 4, 8 and 32 passes -- duplicates and low-complexity sequence put fallback keys into several groups, so the fallback table is
+    assembled from several passes -- and equals the oracle's."""
+    rng = np.random.default_rng(77 + k + b)
+    seqs = [_rand_seq(rng, k + int(rng.integers(0, 90))) for _ in range(1500)]
+    seqs += [seqs[3], seqs[40], seqs[41][2:] if len(seqs[41]) > k + 2 else seqs[41], "A" * (k + 30), "AC" * (k + 5), "ACG" * (k + 1), seqs[900]] + seqs[1000:1040]
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    base = None
+    q = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
+    want = orc.query_kmers(q.reshape(-1) if kb == 8 else q)
+    for passes in (1, 2, 4, 8, 32):
+        ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+        ix.set_tuning("build_passes", passes)
+        ix.set_tuning("fat_lines", fat)
+        ix.construct_index_from_sequences(seqs)
+        ix.set_tuning("absent_filter", 1)
+        arrays = {name: ix.export(name) for name in B.EXPORT}
+        st = {f: v for f, v in ix.stats().items() if f not in ("build_seconds", "number_query", "build_scratch_peak_bytes")}
+        assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), passes
+        if base is None:
+            base = (arrays, st)
+            assert st["fallback_keys"] > 0 and len(set(arrays["fb_group"].tolist())) > 1  # fallback keys in more than one group
+            a = orc.arrays()
+            for key in ("bucket_nt", "bucket_start", "seq", "positions", "g_nkeys", "g_prefix", "g_posstart"):
+                assert np.array_equal(arrays[key], a[key]), key
+        else:
+            for name in B.EXPORT:
+                assert np.array_equal(arrays[name], base[0][name]), (passes, name)
+            assert st == base[1], (passes, [(f, st[f], base[1][f]) for f in st if st[f] != base[1][f]])
+        rq = q[rng.integers(0, len(q), 2000)]
+        import tempfile
+        if passes == 4:
+            with tempfile.TemporaryDirectory() as td:
+                ix.dump_disk(td + "/p.blmx")
+                ld = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+                ld.load_disk(td + "/p.blmx")
+                assert np.array_equal(ld.query_kmer_hash(rq.reshape(-1)), ix.query_kmer_hash(rq.reshape(-1)))
+        ix.close()
