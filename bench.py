@@ -477,6 +477,29 @@ def reads_leg(torch, B, ix, dev, ascii_, total, k, args, orc):
     return out
 
 
+def scalar_calls_leg(ix, q, ids, kw, k):
+    """kmer_Set_Light::query_kmer_hash(kmer_t): ONE k-mer per call (reference blight.cpp:545-550) from 1 and 8 OpenMP threads through the
+    C++ facade; concurrent calls are answered together by one launch (the combiner of blmx_front.hip)"""
+    import numpy as np
+    libpath = os.path.join(ROOT, "tools", "libbench_calls.so" if k <= 32 else "libbench_calls128.so")
+    if not os.path.exists(libpath):
+        return None
+    lib = ctypes.CDLL(libpath)
+    u64p, i64p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int64)
+    lib.blight_bench_kmer_calls.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64p]
+    n = 100_000
+    h_q = np.ascontiguousarray(q[:n].cpu().numpy().view(np.uint64).reshape(-1))
+    want = ids[:n].cpu().numpy()
+    out = {"entry": "kmer_Set_Light::query_kmer_hash(kmer_t) via include/blight.h, one k-mer per call, OpenMP callers", "kmers": n}
+    for threads in sorted({1, min(8, host_cores())}):
+        got = np.empty(n, dtype=np.int64)
+        secs, found, cs = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = lib.blight_bench_kmer_calls(ix._h, h_q.ctypes.data_as(u64p), n, threads, ctypes.byref(secs), ctypes.byref(found), ctypes.byref(cs), got.ctypes.data_as(i64p))
+        assert rc == 0
+        out["threads_%d" % threads] = {"queries_per_s": n / secs.value, "ids_equal_to_device": bool(np.array_equal(got, want))}
+    return out
+
+
 def write_fasta(torch, dev, ascii_, offs, nu, path):
     """the first `nu` unitigs as 2-line FASTA records (">\n<sequence>\n": the reference's reader skips the header line, blight.cpp:212-229),
     assembled on the device chunk by chunk and written to `path`; returns the file size"""
@@ -943,6 +966,10 @@ def main():
                     out["host_buffers"] = host_kmer_legs(torch, ix, q, ids, kw)
                 except Exception as e:
                     out["host_buffers"] = {"failed": repr(e)}
+                try:
+                    out["scalar_calls"] = scalar_calls_leg(ix, q, ids, kw, k)
+                except Exception as e:
+                    out["scalar_calls"] = {"failed": repr(e)}
         if orc is not None:
             orc.close()
         if not multi and not args.no_fasta_leg and not args.skew:

@@ -240,11 +240,37 @@ constexpr uint64_t kSmallKmers = 8192;       // k-mer batches up to this size: o
 struct SmallSlot {
 	Pinned h;
 	hipStream_t s = nullptr;
+	DevBuf counter;            // completion counter of the slot's launches (DoneSignal): only ever grows
+	unsigned int target = 0, ticket = 0;
 	~SmallSlot()
 	{
-		if (s)
+		if (s) {
+			(void)hipStreamSynchronize(s);
 			(void)hipStreamDestroy(s);
+		}
 	}
+};
+
+// One small call waiting to be answered.  Calls that arrive while a launch is in flight are answered TOGETHER by the next one: a
+// caller either leads (packs everything that waits into one pinned slot, launches once, hands the answers out) or spins on its
+// request until a leader has answered it.  With c concurrent callers a launch carries up to c calls, so the per-call cost of the
+// launch and of its completion falls with the number of callers instead of being paid by each (reference: every caller runs the
+// query on its own core, blight.cpp:537-550, 575-591).
+struct SmallReq {
+	enum Kind { kSequences, kKmers } kind;
+	// sequences: characters [a0, a0 + nbytes) of `chars`, nseq sequences with offsets `offs` (absolute), koffs = k-mers before each
+	const char* chars = nullptr;
+	const uint64_t* offs = nullptr;
+	const uint64_t* koffs = nullptr;
+	uint64_t a0 = 0, nbytes = 0, nseq = 0;
+	// k-mers
+	const void* kmers = nullptr;
+	bool want_bool = false;
+	uint64_t n = 0;  // answers (k-mers)
+	void* out = nullptr;
+	std::atomic<int> state{0};  // 0 waiting | 1 answered | 2 failed (code, msg) | 3 "you lead now"
+	int code = 0;
+	std::string msg;
 };
 
 void grow(DevBuf& b, size_t bytes, hipStream_t s)
@@ -264,6 +290,9 @@ struct HostFront {
 	std::mutex small_mu;
 	std::condition_variable small_cv;
 	std::unique_ptr<WorkerPool> pool;
+	std::mutex comb_mu;                 // the combiner of small calls: requests that wait for a launch, and whether somebody leads
+	std::vector<SmallReq*> comb_wait;
+	bool comb_led = false;
 	DevBuf d_counts, d_carry;  // file streaming: found / not found, line carry between windows
 	// scratch of blmx_query_sequences_device (calls on different streams are ordered with an event)
 	FrontScratch dev_fs;
@@ -328,6 +357,8 @@ struct SmallLease {
 				BLMX_HIP(hipSetDevice(ix.prm.device));
 				n->h.ensure(kSmallSlotBytes);
 				BLMX_HIP(hipStreamCreateWithFlags(&n->s, hipStreamNonBlocking));
+				BLMX_HIP(n->counter.alloc(64, true, n->s));
+				BLMX_HIP(hipStreamSynchronize(n->s));
 				sl = n.get();
 				hf.small_all.push_back(std::move(n));
 				return;
@@ -379,6 +410,201 @@ void query_window(Index& ix, WindowSlot& w, uint64_t nbytes, uint64_t npos, uint
 
 }  // namespace
 
+// ---- the combiner of small calls ---------------------------------------------------------------------------------------------------
+namespace {
+
+// wait until the launch with this ticket has stored all its answers: spin on the flag the kernel writes (pinned memory), then --
+// should that take implausibly long -- fall back to the stream
+void wait_small(SmallSlot& sl, volatile unsigned int* flag, unsigned int ticket)
+{
+	for (int spin = 0; spin < 400000; spin++) {
+		if (*flag == ticket)
+			return;
+		_mm_pause();
+	}
+	BLMX_HIP(hipStreamSynchronize(sl.s));
+}
+
+// answer everything in `batch` with (at most) one fused read launch and one k-mer launch on one pinned slot
+void serve_small(Index& ix, HostFront& hf, std::vector<SmallReq*>& batch)
+{
+	SmallLease lease(ix, hf);
+	SmallSlot& sl = *lease.sl;
+	char* base = sl.h.as<char>();
+	const size_t kb = (size_t)ix.KW * 8;
+	uint64_t nbytes = 0, nseq = 0, nk_seq = 0, nkm = 0;
+	for (const SmallReq* r : batch) {
+		if (r->kind == SmallReq::kSequences) {
+			nbytes += r->nbytes;
+			nseq += r->nseq;
+			nk_seq += r->n;
+		} else {
+			nkm += r->n;
+		}
+	}
+	// slot layout: [flag 64 B][characters][offsets nseq + 1][k-mers before each, nseq + 1][error word][IDs of the sequences][k-mers][IDs of the k-mers]
+	const size_t o_chars = 64, o_offs = align_up(o_chars + nbytes + 64, 64), o_koffs = o_offs + (nseq + 1) * 8, o_err = o_koffs + (nseq + 1) * 8,
+	             o_ids = align_up(o_err + 8, 64), o_kmers = align_up(o_ids + nk_seq * 8, 64), o_kids = align_up(o_kmers + nkm * kb, 64);
+	volatile unsigned int* flag = reinterpret_cast<volatile unsigned int*>(base);
+	uint64_t* h_offs = reinterpret_cast<uint64_t*>(base + o_offs);
+	uint64_t* h_koffs = reinterpret_cast<uint64_t*>(base + o_koffs);
+	int* h_err = reinterpret_cast<int*>(base + o_err);
+	*h_err = 0;
+	uint64_t cb = 0, cs = 0, ck = 0, cm = 0;
+	for (const SmallReq* r : batch) {
+		if (r->kind == SmallReq::kSequences) {
+			memcpy(base + o_chars + cb, r->chars + r->a0, r->nbytes);
+			for (uint64_t i = 0; i < r->nseq; i++) {
+				h_offs[cs + i] = cb + (r->offs[i] - r->a0);
+				h_koffs[cs + i] = ck + r->koffs[i];
+			}
+			cb += r->nbytes;
+			cs += r->nseq;
+			ck += r->n;
+		} else {
+			memcpy(base + o_kmers + cm * kb, r->kmers, r->n * kb);
+			cm += r->n;
+		}
+	}
+	h_offs[nseq] = nbytes;
+	h_koffs[nseq] = nk_seq;
+	unsigned int units = 0;
+	if (nk_seq)
+		units += read_query_signal_units(nbytes);
+	if (nkm)
+		units += query_signal_units(nkm);
+	sl.target += units;
+	sl.ticket++;
+	const DoneSignal done{sl.counter.as<unsigned int>(), flag, sl.target, sl.ticket};
+	if (nk_seq)
+		launch_read_query(ix, nullptr, reinterpret_cast<const uint8_t*>(base + o_chars), nbytes, nbytes, h_offs, h_koffs, nseq,
+		                  reinterpret_cast<int64_t*>(base + o_ids), nullptr, h_err, sl.s, done);
+	if (nkm)
+		launch_query(ix, base + o_kmers, nullptr, nkm, base + o_kids, kQueryIds, sl.s, done);
+	if (units)
+		wait_small(sl, flag, sl.ticket);
+	// hand the answers out.  An invalid character fails the sequence calls of this launch that hold one (the reference throws per call).
+	const bool bad_char = *h_err != 0;
+	ck = cm = 0;
+	for (SmallReq* r : batch) {
+		if (r->kind == SmallReq::kSequences) {
+			bool bad = false;
+			if (bad_char)
+				for (uint64_t i = 0; i < r->nbytes && !bad; i++) {
+					const unsigned char c = (unsigned char)r->chars[r->a0 + i];
+					const unsigned d = (unsigned)c - 65u;
+					bad = !(d <= 51u && ((0x0008004500080045ull >> d) & 1ull));
+				}
+			if (bad) {
+				r->code = BLMX_EDNA;
+				r->msg = "Invalid char in DNA";
+			} else if (r->n) {
+				memcpy(r->out, base + o_ids + ck * 8, r->n * 8);
+			}
+			ck += r->n;
+		} else {
+			const int64_t* ids = reinterpret_cast<const int64_t*>(base + o_kids) + cm;
+			if (r->want_bool)
+				for (uint64_t i = 0; i < r->n; i++)
+					reinterpret_cast<uint8_t*>(r->out)[i] = ids[i] >= 0 ? 1 : 0;
+			else
+				memcpy(r->out, ids, r->n * 8);
+			cm += r->n;
+		}
+	}
+	ix.number_query.fetch_add(nk_seq + nkm, std::memory_order_relaxed);
+}
+
+// what one launch may carry (one pinned slot of kSmallSlotBytes)
+constexpr uint64_t kCombineChars = kSmallChars, kCombineSeqs = kSmallSeqs, kCombineKmers = kSmallKmers;
+
+// the calling thread's request: answered by a leader's launch, or by its own when nobody leads
+void combine_small(Index& ix, HostFront& hf, SmallReq& me)
+{
+	bool lead;
+	{
+		std::lock_guard<std::mutex> l(hf.comb_mu);
+		lead = !hf.comb_led;
+		if (lead)
+			hf.comb_led = true;
+		else
+			hf.comb_wait.push_back(&me);
+	}
+	if (!lead) {
+		for (int spin = 0;; spin++) {
+			const int st = me.state.load(std::memory_order_acquire);
+			if (st == 1 || st == 2)
+				break;
+			if (st == 3) {  // the previous leader has left and made this caller the next one (its request is no longer in the queue)
+				lead = true;
+				break;
+			}
+			if (spin < 4000)
+				_mm_pause();
+			else
+				std::this_thread::yield();
+		}
+	}
+	if (lead) {
+		std::vector<SmallReq*> batch;
+		batch.push_back(&me);
+		uint64_t chars = me.kind == SmallReq::kSequences ? me.nbytes : 0, seqs = me.kind == SmallReq::kSequences ? me.nseq : 0,
+		         kmers = me.kind == SmallReq::kKmers ? me.n : 0, kseq = me.kind == SmallReq::kSequences ? me.n : 0;
+		{
+			std::lock_guard<std::mutex> l(hf.comb_mu);
+			size_t keep = 0;
+			for (SmallReq* r : hf.comb_wait) {  // everything that fits one slot rides along
+				const bool sq = r->kind == SmallReq::kSequences;
+				const bool fits = sq ? (chars + r->nbytes <= kCombineChars && seqs + r->nseq <= kCombineSeqs && kseq + r->n <= 48000) : (kmers + r->n <= kCombineKmers);
+				if (fits) {
+					batch.push_back(r);
+					if (sq) {
+						chars += r->nbytes;
+						seqs += r->nseq;
+						kseq += r->n;
+					} else {
+						kmers += r->n;
+					}
+				} else {
+					hf.comb_wait[keep++] = r;
+				}
+			}
+			hf.comb_wait.resize(keep);
+		}
+		int code = BLMX_OK;
+		std::string msg;
+		try {
+			serve_small(ix, hf, batch);
+		} catch (const StatusError& e) {
+			code = e.code;
+			msg = e.msg;
+		}
+		{
+			// leadership goes to a caller that is still waiting (it will observe state 3), or nobody leads
+			std::lock_guard<std::mutex> l(hf.comb_mu);
+			if (hf.comb_wait.empty()) {
+				hf.comb_led = false;
+			} else {
+				SmallReq* next = hf.comb_wait.front();
+				hf.comb_wait.erase(hf.comb_wait.begin());
+				next->state.store(3, std::memory_order_release);
+			}
+		}
+		for (SmallReq* r : batch) {
+			if (code != BLMX_OK && r->code == BLMX_OK) {
+				r->code = code;
+				r->msg = msg;
+			}
+			if (r != &me)
+				r->state.store(r->code == BLMX_OK ? 1 : 2, std::memory_order_release);
+		}
+	}
+	if (me.code != BLMX_OK)
+		throw StatusError{me.code, me.msg};
+}
+
+}  // namespace
+
 // ---- query_sequence_hash for nseq sequences (reference blight.cpp:575-591) -----------------------------------------------------
 void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out)
 {
@@ -404,27 +630,18 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 	BLMX_HIP(hipSetDevice(ix.prm.device));
 	HostFront& hf = host_front(ix);
 	// ---- one launch on a pinned slot
-	if (total - a0 <= kSmallChars && nseq <= kSmallSeqs && read_query_fusable(ix)) {
-		SmallLease lease(ix, hf);
-		SmallSlot& sl = *lease.sl;
-		const uint64_t nbytes = total - a0;
-		char* base = sl.h.as<char>();
-		const size_t o_offs = align_up(nbytes + 64, 64), o_koffs = o_offs + (nseq + 1) * 8, o_err = o_koffs + (nseq + 1) * 8,
-		             o_ids = align_up(o_err + 8, 64);
-		memcpy(base, concat + a0, nbytes);
-		uint64_t* h_offs = reinterpret_cast<uint64_t*>(base + o_offs);
-		for (uint64_t i = 0; i <= nseq; i++)
-			h_offs[i] = offsets[i] - a0;
-		memcpy(base + o_koffs, koffs.data(), (nseq + 1) * 8);
-		int* h_err = reinterpret_cast<int*>(base + o_err);
-		*h_err = 0;
-		launch_read_query(ix, nullptr, reinterpret_cast<const uint8_t*>(base), nbytes, nbytes, h_offs, reinterpret_cast<const uint64_t*>(base + o_koffs), nseq,
-		                  reinterpret_cast<int64_t*>(base + o_ids), nullptr, h_err, sl.s);
-		BLMX_HIP(hipStreamSynchronize(sl.s));
-		if (*h_err)
-			throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
-		memcpy(ids_out, base + o_ids, nk_all * 8);
-		ix.number_query.fetch_add(nk_all, std::memory_order_relaxed);
+	if (total - a0 <= kSmallChars && nseq <= kSmallSeqs && nk_all <= 48000 && read_query_fusable(ix)) {
+		SmallReq rq;  // answered by ONE launch together with whatever other callers are waiting (combine_small)
+		rq.kind = SmallReq::kSequences;
+		rq.chars = concat;
+		rq.offs = offsets;
+		rq.koffs = koffs.data();
+		rq.a0 = a0;
+		rq.nbytes = total - a0;
+		rq.nseq = nseq;
+		rq.n = nk_all;
+		rq.out = ids_out;
+		combine_small(ix, hf, rq);
 		return;
 	}
 	// ---- windows in position space: k-mers may start at [A, B), the window holds the characters [A, B + k - 1)
@@ -634,7 +851,17 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 	HostFront& hf = host_front(ix);
 	const size_t kb = (size_t)ix.KW * 8;
 	const size_t ob = mode == kQueryIds ? 8 : (mode == kQueryPos ? 4 : 1);
-	if (nq <= kSmallKmers) {  // one launch on a pinned slot the device reads and writes directly (scalar calls of the facade land here)
+	if (nq <= kSmallKmers && !minis && (mode == kQueryIds || mode == kQueryBool) && ix.prm.bits_saved <= 8) {
+		SmallReq rq;  // scalar calls of the facade land here: answered by ONE launch together with whatever other callers are waiting
+		rq.kind = SmallReq::kKmers;
+		rq.kmers = kmers;
+		rq.want_bool = mode == kQueryBool;
+		rq.n = nq;
+		rq.out = out;
+		combine_small(ix, hf, rq);
+		return;
+	}
+	if (nq <= kSmallKmers) {  // caller-supplied minimizers / positions: one launch of its own on a pinned slot
 		SmallLease lease(ix, hf);
 		SmallSlot& sl = *lease.sl;
 		char* base = sl.h.as<char>();

@@ -374,6 +374,16 @@ struct Index {
 	}
 };
 
+// Completion signal of a small launch (the combiner of blmx_front.hip): the last wave / workgroup of the launch writes `ticket` to a
+// flag in pinned host memory behind a system-scope fence, and the host spins on that word instead of going through
+// hipStreamSynchronize (which costs more than the kernel itself for a launch of a few waves).  counter lives in HBM and only ever
+// grows: the launch is complete when it reaches `target`.  flag == nullptr: no signal.
+struct DoneSignal {
+	unsigned int* counter;
+	volatile unsigned int* flag;
+	unsigned int target, ticket;
+};
+
 // build (blmx_build.hip)
 void make_query_heads(Index& ix);  // from ix.h_groups, after the group table is final (build and load)
 void init_filter_gate(Index& ix, hipStream_t s);  // with the filter (build and load)
@@ -396,7 +406,8 @@ enum QueryMode { kQueryIds = 0, kQueryPos = 1, kQueryBool = 2, kQueryIds32 = 3 /
                  kQueryNoFilter = 0x200 /* flag: the minimizers come from the caller and may be wrong: the absent-key filter only knows
                                            what a query with the k-mer's OWN minimizer can find */ };
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
-                  hipStream_t s);
+                  hipStream_t s, DoneSignal done = DoneSignal{nullptr, nullptr, 0, 0});
+unsigned int query_signal_units(uint64_t nq);  // what a launch_query of nq k-mers adds to DoneSignal::counter (its waves)
 // Large batches: partition the queries by the top bits of their minimizer first (one counting pass), run the query
 // kernel on the partitioned batch, gather the IDs back into the caller's order.
 void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s);
@@ -447,7 +458,9 @@ void front_valid_raw(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, 
 void launch_read_front(const Index& ix, const FrontScratch* fs, const uint8_t* d_bytes, uint64_t nbytes, uint64_t npos, const uint64_t* offs,
                        const uint64_t* koffs, uint64_t nseq, void* d_kmers, uint32_t* d_minis, int* d_err, hipStream_t s);
 void launch_read_query(const Index& ix, const FrontScratch* fs, const uint8_t* d_bytes, uint64_t nbytes, uint64_t npos, const uint64_t* offs,
-                       const uint64_t* koffs, uint64_t nseq, int64_t* d_ids, unsigned long long* d_counts, int* d_err, hipStream_t s);
+                       const uint64_t* koffs, uint64_t nseq, int64_t* d_ids, unsigned long long* d_counts, int* d_err, hipStream_t s,
+                       DoneSignal done = DoneSignal{nullptr, nullptr, 0, 0});
+unsigned int read_query_signal_units(uint64_t npos);  // what a launch_read_query over npos positions adds to DoneSignal::counter (its workgroups)
 bool read_query_fusable(const Index& ix);
 void front_seq_lines(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_carry_in, uint64_t* d_carry_out,
                      int* d_short_flag, uint64_t* d_tot, uint8_t* d_text, uint64_t* d_offs, hipStream_t s);

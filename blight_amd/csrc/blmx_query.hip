@@ -55,7 +55,7 @@ __global__ void k_gate_set(uint32_t* __restrict__ gate, uint64_t nq)
 template <int KW, int LOGP, bool WANT_POS>
 __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t* __restrict__ kmers,
                                                const uint32_t* __restrict__ minis, uint64_t nq, void* __restrict__ out,
-                                               int mode)
+                                               int mode, DoneSignal done)
 {
 	// kQueryXcdMajor (batch partitioned by minimizer): workgroup b runs on XCD b % 8, each XCD has its own L2.  Give XCD x
 	// the x-th contiguous eighth of the batch, so that one bin's slice of the index is cached by ONE L2 instead of being
@@ -92,7 +92,14 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 		reinterpret_cast<int32_t*>(out)[o] = posj;
 	else
 		reinterpret_cast<uint8_t*>(out)[o] = id >= 0 ? 1 : 0;
+	if (done.flag) {  // small launches: the last wave that has stored its answers tells the host (waves without a k-mer left above)
+		__threadfence_system();
+		if (lane_id() == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1) && atomicAdd(done.counter, 1u) + 1u == done.target)
+			*done.flag = done.ticket;
+	}
 }
+
+unsigned int query_signal_units(uint64_t nq) { return (unsigned int)((nq + 63) / 64); }
 
 // (An absent-key filter makes the absent half of a wave's lanes leave early; compacting the survivors through an LDS ring so that
 // the query body runs with all 64 lanes busy -- per workgroup, per wave, or persistent waves striding over the batch -- was built and
@@ -353,7 +360,7 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)(
 
 template <int KW>
 static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, int mode,
-                            hipStream_t s)
+                            hipStream_t s, DoneSignal done)
 {
 	DeviceIndexView v = ix.view();
 	if (mode & kQueryNoFilter)
@@ -368,9 +375,9 @@ static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t
 #define BLMX_Q(LP)                                                                                  \
 	case LP:                                                                                        \
 		if ((mode & 0xff) == (int)kQueryPos)                                                        \
-			hipLaunchKernelGGL((k_query<KW, LP, true>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode);  \
+			hipLaunchKernelGGL((k_query<KW, LP, true>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode, done);  \
 		else                                                                                        \
-			hipLaunchKernelGGL((k_query<KW, LP, false>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode); \
+			hipLaunchKernelGGL((k_query<KW, LP, false>), dim3(grid), dim3(256), 0, s, v, km, d_minis, nq, d_out, mode, done); \
 		break;
 	switch (v.b) {
 		BLMX_Q(0)
@@ -390,14 +397,16 @@ static void launch_query_kw(const Index& ix, const void* d_kmers, const uint32_t
 }
 
 void launch_query(const Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, void* d_out, QueryMode mode,
-                  hipStream_t s)
+                  hipStream_t s, DoneSignal done)
 {
 	if (nq == 0)
 		return;
+	if (done.flag && ix.prm.bits_saved > 8)
+		throw StatusError{BLMX_EINVAL, "internal: completion signals need bits_to_save <= 8"};
 	if (ix.KW == 1)
-		launch_query_kw<1>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s);
+		launch_query_kw<1>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s, done);
 	else
-		launch_query_kw<2>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s);
+		launch_query_kw<2>(ix, d_kmers, d_minis, nq, d_out, (int)mode, s, done);
 	BLMX_HIP(hipGetLastError());
 }
 

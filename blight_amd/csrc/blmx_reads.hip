@@ -217,10 +217,10 @@ __global__ __launch_bounds__(kFrontBlock) void k_read_front(const uint8_t* __res
 template <int KW, int LOGP>
 __global__ __launch_bounds__(kFrontBlock) void k_read_query(DeviceIndexView v, const uint8_t* __restrict__ bytes, uint64_t total, FrontWhere fw,
                                                             int64_t* __restrict__ ids, unsigned long long* __restrict__ counts,
-                                                            int* __restrict__ err)
+                                                            int* __restrict__ err, DoneSignal done)
 {
 	const uint64_t base = (uint64_t)blockIdx.x * kFrontBlock;
-	if (!front_block_live(fw, base))
+	if (!front_block_live(fw, base))  // (bitmap mode only; launches with a completion signal use the offsets mode: every workgroup stays)
 		return;
 	FrontLane<KW> f;
 	front_block<KW>(bytes, total, base, v.k, v.m, f);
@@ -256,7 +256,15 @@ __global__ __launch_bounds__(kFrontBlock) void k_read_query(DeviceIndexView v, c
 				atomicAdd(&counts[2 * stripe + 1], (unsigned long long)s_absent);
 		}
 	}
+	if (done.flag) {  // small launches: the last workgroup that has stored its answers tells the host
+		__threadfence_system();
+		__syncthreads();
+		if (threadIdx.x == 0 && atomicAdd(done.counter, 1u) + 1u == done.target)
+			*done.flag = done.ticket;
+	}
 }
+
+unsigned int read_query_signal_units(uint64_t npos) { return (unsigned int)((npos + kFrontBlock - 1) / kFrontBlock); }
 
 // ---- VALID bitmap of a window of concatenated sequences --------------------------------------------------------------------
 // starts: bit p set iff a sequence starts at window position p.  A k-mer starts at q iff q + k <= total and no sequence
@@ -626,13 +634,13 @@ void launch_read_front(const Index& ix, const FrontScratch* fs, const uint8_t* d
 
 template <int KW>
 static void launch_read_query_kw(const Index& ix, const FrontWhere& fw, const uint8_t* d_bytes, uint64_t nbytes, uint64_t npos, int64_t* d_ids,
-                                 unsigned long long* d_counts, int* d_err, hipStream_t s)
+                                 unsigned long long* d_counts, int* d_err, hipStream_t s, DoneSignal done)
 {
 	const DeviceIndexView v = ix.view();
 	const unsigned grid = grid_for(npos, kFrontBlock);
 #define BLMX_RQ(LP)                                                                                                                      \
 	case LP:                                                                                                                             \
-		hipLaunchKernelGGL((k_read_query<KW, LP>), dim3(grid), dim3(kFrontBlock), 0, s, v, d_bytes, nbytes, fw, d_ids, d_counts, d_err); \
+		hipLaunchKernelGGL((k_read_query<KW, LP>), dim3(grid), dim3(kFrontBlock), 0, s, v, d_bytes, nbytes, fw, d_ids, d_counts, d_err, done); \
 		break;
 	switch (v.b) {
 		BLMX_RQ(0)
@@ -653,15 +661,15 @@ static void launch_read_query_kw(const Index& ix, const FrontWhere& fw, const ui
 bool read_query_fusable(const Index& ix) { return ix.prm.bits_saved <= 8; }
 
 void launch_read_query(const Index& ix, const FrontScratch* fs, const uint8_t* d_bytes, uint64_t nbytes, uint64_t npos, const uint64_t* offs,
-                       const uint64_t* koffs, uint64_t nseq, int64_t* d_ids, unsigned long long* d_counts, int* d_err, hipStream_t s)
+                       const uint64_t* koffs, uint64_t nseq, int64_t* d_ids, unsigned long long* d_counts, int* d_err, hipStream_t s, DoneSignal done)
 {
 	if (npos == 0)
 		return;
 	const FrontWhere fw = where_of(fs, offs, koffs, nseq);
 	if (ix.KW == 1)
-		launch_read_query_kw<1>(ix, fw, d_bytes, nbytes, npos, d_ids, d_counts, d_err, s);
+		launch_read_query_kw<1>(ix, fw, d_bytes, nbytes, npos, d_ids, d_counts, d_err, s, done);
 	else
-		launch_read_query_kw<2>(ix, fw, d_bytes, nbytes, npos, d_ids, d_counts, d_err, s);
+		launch_read_query_kw<2>(ix, fw, d_bytes, nbytes, npos, d_ids, d_counts, d_err, s, done);
 	BLMX_HIP(hipGetLastError());
 }
 

@@ -47,3 +47,38 @@ extern "C" int blight_bench_read_calls(blmx_index* h, const char* concat, const 
 		return -1;
 	}
 }
+
+// The scalar calling pattern: kmer_Set_Light::query_kmer_hash(kmer_t) once per k-mer (reference blight.cpp:545-550) from `threads`
+// OpenMP threads.  kmers = n canonical k-mers (one or two 64-bit words each, low word first); ids_out (may be null) gets the answers.
+extern "C" int blight_bench_kmer_calls(blmx_index* h, const uint64_t* kmers, uint64_t n, int threads, double* seconds, uint64_t* found, uint64_t* checksum,
+                                       int64_t* ids_out)
+{
+	try {
+		std::unique_ptr<kmer_Set_Light> index(kmer_Set_Light::attach(h));
+		constexpr int kWords = sizeof(kmer_t) / 8;
+		auto kmer_at = [&](uint64_t i) -> kmer_t {
+			kmer_t x = 0;
+			for (int w = kWords - 1; w >= 0; w--)
+				x = (kWords > 1 ? (x << 32) << 32 : (kmer_t)0) | (kmer_t)kmers[i * kWords + (uint64_t)w];
+			return x;
+		};
+		if (n)
+			index->query_kmer_hash(kmer_at(0));
+		uint64_t nf = 0, cs = 0;
+		const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 64) reduction(+ : nf, cs)
+		for (long i = 0; i < (long)n; i++) {
+			const int64_t id = index->query_kmer_hash(kmer_at((uint64_t)i));
+			if (ids_out)
+				ids_out[i] = id;
+			nf += id >= 0;
+			cs += ((uint64_t)i + 1) * (uint64_t)(id + 2);
+		}
+		*seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		*found = nf;
+		*checksum = cs;
+		return 0;
+	} catch (const std::exception&) {
+		return -1;
+	}
+}
