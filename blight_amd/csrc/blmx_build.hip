@@ -1442,8 +1442,10 @@ struct ShardCtx {
 // nucleotides of halo a shard keeps: a window starts at most k nucleotides before the end of a bucket and covers 2^b positions + k - 1
 inline uint64_t halo_length(const Index& ix) { return (1ull << ix.prm.bits_saved) + (uint64_t)ix.prm.k; }
 
+// packed != nullptr: the text is already 2-bit packed (the file loader's output); it is taken over and K1's encoding is skipped
 template <int KW>
-void chop_input(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, Chopped& out, PhaseMarks& mark)
+void chop_input(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, Chopped& out, PhaseMarks& mark,
+                DevBuf* packed = nullptr)
 {
 	hipStream_t s = ix.stream;
 	const int k = (int)ix.prm.k, m = (int)ix.prm.m;
@@ -1461,14 +1463,25 @@ void chop_input(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	const uint64_t nbw = ((npos + kBlock - 1) / kBlock) * (kBlock / 64);  // bitmap words written by K2
 	const uint64_t src_words = (total_len + 31) / 32;
 	DevBuf d_ustart, d_Hb, d_Eb;
-	BLMX_HIP(d_src.alloc((src_words + 4) * 8, true, s));
+	if (packed) {
+		if (packed->bytes < (src_words + 4) * 8)
+			throw StatusError{BLMX_EINVAL, "internal: packed text too small"};
+		d_src.release();
+		std::swap(d_src.p, packed->p);
+		std::swap(d_src.bytes, packed->bytes);
+		std::swap(d_src.owner, packed->owner);
+	} else {
+		BLMX_HIP(d_src.alloc((src_words + 4) * 8, true, s));
+	}
 	BLMX_HIP(d_ustart.alloc((nbw + 4) * 8, true, s));
 	BLMX_HIP(d_Hb.alloc((nbw + 1) * 8, true, s));
 	BLMX_HIP(d_Eb.alloc((nbw + 1) * 8, true, s));
 	if (nseq) {
 		hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(nseq)), dim3(kBlock), 0, s, d_offs, nseq, k, d_ustart.as<unsigned long long>(),
 		                   d_err.as<int>());
-		if ((reinterpret_cast<uintptr_t>(d_ascii) & 15) == 0)
+		if (packed)
+			;  // already encoded
+		else if ((reinterpret_cast<uintptr_t>(d_ascii) & 15) == 0)
 			hipLaunchKernelGGL((k_encode_pack<true>), dim3(grid_for(src_words)), dim3(kBlock), 0, s, d_ascii, total_len, src_words,
 			                   d_src.as<uint64_t>(), d_err.as<int>());
 		else
@@ -1560,7 +1573,7 @@ std::vector<uint64_t> derive_shard_bounds(Index& ix, const std::vector<uint64_t>
 }
 
 template <int KW>
-void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
+void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, DevBuf* packed = nullptr)
 {
 	const auto t_begin = std::chrono::steady_clock::now();
 	ix.st.build_scratch_peak_bytes = 0;
@@ -1576,7 +1589,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 	const uint32_t ngroups = ix.ngroups;
 	const int gshift = ix.gshift;
 	Chopped chopped;
-	chop_input<KW>(ix, d_ascii, d_offs, nseq, total_len, chopped, mark);
+	chop_input<KW>(ix, d_ascii, d_offs, nseq, total_len, chopped, mark, packed);
 	DevBuf& d_skpos = chopped.skpos;
 	DevBuf& d_sklast = chopped.sklast;
 	DevBuf& d_skmini = chopped.skmini;
@@ -2720,6 +2733,14 @@ void make_query_heads(Index& ix)
 	BLMX_HIP(hipMemcpyAsync(ix.qheads.p, h.data(), h.size() * sizeof(QueryHead), hipMemcpyHostToDevice, ix.stream));
 	BLMX_HIP(hipStreamSynchronize(ix.stream));
 	ix.has_qheads = true;
+}
+
+void build_from_device_packed(Index& ix, DevBuf& d_packed, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)
+{
+	if (ix.KW == 1)
+		build_impl<1>(ix, nullptr, d_offs, nseq, total_len, &d_packed);
+	else
+		build_impl<2>(ix, nullptr, d_offs, nseq, total_len, &d_packed);
 }
 
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len)

@@ -293,6 +293,8 @@ struct HostFront {
 	std::mutex comb_mu;                 // the combiner of small calls: requests that wait for a launch, and whether somebody leads
 	std::vector<SmallReq*> comb_wait;
 	bool comb_led = false;
+	std::atomic<int> comb_nwait{0};  // comb_wait.size(), readable without the lock
+	std::atomic<int> comb_peak{1};   // calls the recent launches carried (decays): what a new leader may expect to gather
 	DevBuf d_counts, d_carry;  // file streaming: found / not found, line carry between windows
 	// scratch of blmx_query_sequences_device (calls on different streams are ordered with an event)
 	FrontScratch dev_fs;
@@ -525,10 +527,12 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 	{
 		std::lock_guard<std::mutex> l(hf.comb_mu);
 		lead = !hf.comb_led;
-		if (lead)
+		if (lead) {
 			hf.comb_led = true;
-		else
+		} else {
 			hf.comb_wait.push_back(&me);
+			hf.comb_nwait.store((int)hf.comb_wait.size(), std::memory_order_relaxed);
+		}
 	}
 	if (!lead) {
 		for (int spin = 0;; spin++) {
@@ -546,6 +550,19 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 		}
 	}
 	if (lead) {
+		// Callers that were answered by the previous launch are on their way back with their next call: a leader that launched at once
+		// would carry only the calls that arrived while the previous launch was in flight (half of the callers, and each call would wait
+		// two launches).  So it gives the others a few microseconds -- as long as recent launches carried more calls than wait now;
+		// a lone caller never waits.
+		const int expect = hf.comb_peak.load(std::memory_order_relaxed) - 1;
+		if (expect > 0) {
+			const auto t0 = std::chrono::steady_clock::now();
+			for (int spin = 0; hf.comb_nwait.load(std::memory_order_relaxed) < expect; spin++) {
+				_mm_pause();
+				if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(5))
+					break;
+			}
+		}
 		std::vector<SmallReq*> batch;
 		batch.push_back(&me);
 		uint64_t chars = me.kind == SmallReq::kSequences ? me.nbytes : 0, seqs = me.kind == SmallReq::kSequences ? me.nseq : 0,
@@ -570,6 +587,9 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 				}
 			}
 			hf.comb_wait.resize(keep);
+			hf.comb_nwait.store((int)keep, std::memory_order_relaxed);
+			const int peak = hf.comb_peak.load(std::memory_order_relaxed);
+			hf.comb_peak.store(std::max<int>((int)batch.size(), peak - (peak > 1 && (int)batch.size() < peak ? 1 : 0)), std::memory_order_relaxed);
 		}
 		int code = BLMX_OK;
 		std::string msg;
@@ -587,6 +607,7 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 			} else {
 				SmallReq* next = hf.comb_wait.front();
 				hf.comb_wait.erase(hf.comb_wait.begin());
+				hf.comb_nwait.store((int)hf.comb_wait.size(), std::memory_order_relaxed);
 				next->state.store(3, std::memory_order_release);
 			}
 		}
@@ -1160,6 +1181,8 @@ void stream_file(Index& ix, const char* path, int mode, Payload* payload, uint32
 // there (front_seq_lines): the host only moves bytes.  Out: the sequences' characters back to back, nseq + 1 offsets, both in HBM.
 void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBuf& d_offs, uint64_t& nseq, uint64_t& total)
 {
+	// d_text holds the 2-bit text (one byte per four nucleotides: an ASCII copy of a human-scale input would cost more to allocate
+	// -- 4.4 GB of fresh HBM: 0.25 s -- than to parse)
 	RawFile rf(path);
 	if (!rf.ok())
 		throw StatusError{BLMX_EIO, "Problem with files opening"};  // blight.cpp:188-189
@@ -1171,20 +1194,22 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 	// every window's device work runs on ONE stream (the appends are ordered); the pinned slots rotate so that reading the next
 	// window overlaps the copy and the kernels of the previous ones
 	hipStream_t s = hf.win[0].s;
-	DevBuf d_state;  // [0..3] line carry (two generations), [4] sequences, [5] characters, [6] short flag
+	DevBuf d_state;  // [0..3] line carry (two generations), [4] sequences, [5] characters, [6] short flag, [7] invalid-character flag
 	BLMX_HIP(d_state.alloc(64, true, s));
 	uint64_t* carry = d_state.as<uint64_t>();
 	uint64_t* d_tot = carry + 4;
 	int* d_short = reinterpret_cast<int*>(carry + 6);
+	int* d_dna = reinterpret_cast<int*>(carry + 7);
 	const uint64_t W = window_positions(ix), k = ix.prm.k;
 	const uint64_t fsize = rf.size();  // 0 = unknown (gzip)
 	uint64_t cap_text = 0, cap_offs = 0, seen = 0;  // `seen` raw bytes bound what has been appended
 	auto reserve = [&](uint64_t more) {
-		const uint64_t need_text = seen + more + 64, need_offs = (seen + more) / (k + 1) + 4;
+		// bytes of packed text (four nucleotides each, + the words the build reads behind the end), offsets (a record holds k + 1 bytes or more)
+		const uint64_t need_text = (seen + more) / 4 + 64, need_offs = (seen + more) / (k + 1) + 4;
 		if (need_text > cap_text) {
 			DevBuf bigger;
-			const uint64_t nb = std::max<uint64_t>(need_text, fsize ? fsize + 64 : 2 * cap_text);
-			BLMX_HIP(bigger.alloc(nb, false, s));
+			const uint64_t nb = (std::max<uint64_t>(need_text, fsize ? fsize / 4 + 64 : 2 * cap_text) + 7) & ~7ull;
+			BLMX_HIP(bigger.alloc(nb, true, s));  // zeroed: the windows OR their words in
 			if (cap_text) {
 				BLMX_HIP(hipMemcpyAsync(bigger.p, d_text.p, cap_text, hipMemcpyDeviceToDevice, s));
 				BLMX_HIP(hipStreamSynchronize(s));
@@ -1247,7 +1272,7 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 		BLMX_HIP(hipMemcpyAsync(w.d_in.p, w.h_in.p, nbytes, hipMemcpyHostToDevice, s));
 		BLMX_HIP(hipEventRecord(copied[slot], s));
 		used[slot] = true;
-		front_seq_lines(ix, fs, w.d_in.as<uint8_t>(), nbytes, carry + 2 * (i & 1), carry + 2 * ((i + 1) & 1), d_short, d_tot, d_text.as<uint8_t>(),
+		front_seq_lines(ix, fs, w.d_in.as<uint8_t>(), nbytes, carry + 2 * (i & 1), carry + 2 * ((i + 1) & 1), d_short, d_tot, nullptr, d_text.as<uint64_t>(), d_dna,
 		                d_offs.as<uint64_t>(), s);
 		tr.lap("enqueue", i);
 	}
@@ -1255,6 +1280,8 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 	BLMX_HIP(hipMemcpyAsync(h_state, d_state.p, 64, hipMemcpyDeviceToHost, s));
 	BLMX_HIP(hipStreamSynchronize(s));
 	tr.lap("wait for the device", 0);
+	if (*reinterpret_cast<const int*>(&h_state[7]))
+		throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
 	if (*reinterpret_cast<const int*>(&h_state[6]))
 		throw StatusError{BLMX_ESHORT, "a sequence is shorter than k"};
 	nseq = h_state[4];

@@ -209,6 +209,7 @@ struct FrontScratch {
 	DevBuf vpre;   // k-mers that start before each 64-position word (the last entry = all of them)
 	DevBuf tmp;    // rocPRIM scan scratch
 	DevBuf lpre;   // raw, construction: per line, sequences and characters of the window's sequence lines before it
+	DevBuf stage;  // raw, construction: the window's sequence characters, compacted, on their way into the 2-bit text
 };
 struct HostFront;  // blmx_stream.hip: pinned staging, window slots, small-call slots and worker threads of one index
 void destroy_host_front(HostFront*);
@@ -463,9 +464,12 @@ void launch_read_query(const Index& ix, const FrontScratch* fs, const uint8_t* d
 unsigned int read_query_signal_units(uint64_t npos);  // what a launch_read_query over npos positions adds to DoneSignal::counter (its workgroups)
 bool read_query_fusable(const Index& ix);
 void front_seq_lines(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_carry_in, uint64_t* d_carry_out,
-                     int* d_short_flag, uint64_t* d_tot, uint8_t* d_text, uint64_t* d_offs, hipStream_t s);
-// construct_index(file) with the parse on the device (blmx_front.hip): raw bytes -> pinned windows -> HBM -> sequences + offsets
-void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBuf& d_offs, uint64_t& nseq, uint64_t& total);
+                     int* d_short_flag, uint64_t* d_tot, uint8_t* d_text, uint64_t* d_packed, int* d_dna_flag, uint64_t* d_offs, hipStream_t s);
+// construct_index(file) with the parse on the device (blmx_front.hip): raw bytes -> pinned windows -> HBM -> 2-bit text + offsets
+void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_packed, DevBuf& d_offs, uint64_t& nseq, uint64_t& total);
+// the build from a text that is already 2-bit packed in HBM (first nucleotide of a word most significant, zero behind the end;
+// (total + 31) / 32 + 4 words); d_packed is taken over
+void build_from_device_packed(Index& ix, DevBuf& d_packed, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
 // host-buffer entry points (blmx_stream.hip): pinned staging, windows in flight, small-call slots
 void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
 void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode);

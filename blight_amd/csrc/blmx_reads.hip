@@ -484,8 +484,31 @@ __global__ __launch_bounds__(256) void k_seq_copy(const uint8_t* __restrict__ by
 		return;
 	const unsigned long long m = mask[i >> 6];
 	const uint32_t lane = (uint32_t)i & 63u;
-	if ((m >> lane) & 1ull)
-		out[tot[1] + (uint64_t)mpre[i >> 6] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = bytes[i];
+	if ((m >> lane) & 1ull)  // tot == nullptr: the window's own sequence characters, from 0
+		out[(tot ? tot[1] : 0ull) + (uint64_t)mpre[i >> 6] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = bytes[i];
+}
+// The window's sequence characters (`chars`, *count of them) -> 2-bit codes appended to the packed text at nucleotide tot[1]: one lane
+// per 64-bit word of the packed text that the window touches (first nucleotide most significant, like k_encode_pack of the build);
+// the first and last word are shared with the neighbouring windows, so every word is ORed into the zeroed array.  A character
+// outside ACGTacgt raises *err (nuc2int throws, kmer.h:56-69).
+__global__ __launch_bounds__(256) void k_seq_pack(const uint8_t* __restrict__ chars, const uint32_t* __restrict__ count, const uint64_t* __restrict__ tot,
+                                                  unsigned long long* __restrict__ packed, int* __restrict__ err)
+{
+	const uint64_t base = tot[1], n = *count;
+	const uint64_t gw = (base >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (n == 0 || gw > (base + n - 1) >> 5)
+		return;
+	const uint64_t a = max(base, gw * 32), z = min(base + n, gw * 32 + 32);
+	uint64_t word = 0;
+	bool bad = false;
+	for (uint64_t p = a; p < z; p++) {
+		const uint32_t c = nuc_code(chars[p - base]);
+		bad |= c > 3;
+		word |= (uint64_t)(c & 3u) << (62 - 2 * (p & 31));
+	}
+	if (bad)
+		*err = 1;
+	atomicOr(&packed[gw], (unsigned long long)word);
 }
 
 struct PopcU64 {
@@ -569,8 +592,10 @@ void front_valid_raw(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, 
 // The sequences of a raw FASTA window (cut behind a newline unless it is the last one) appended to d_text / d_offs at the running
 // totals d_tot = [sequences, characters] (device-resident, advanced here).  d_carry as in front_valid_raw.  *d_short_flag is raised by
 // a sequence shorter than k.  The caller guarantees room for nbytes more characters and nbytes / (k + 1) + 1 more offsets.
+// The text is kept as characters (d_text) or -- d_packed != nullptr -- as the 2-bit words the build works on (a quarter of the bytes,
+// zeroed by the caller; *d_dna_flag is raised by a character outside ACGTacgt).
 void front_seq_lines(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, uint64_t nbytes, const uint64_t* d_carry_in, uint64_t* d_carry_out,
-                     int* d_short_flag, uint64_t* d_tot, uint8_t* d_text, uint64_t* d_offs, hipStream_t s)
+                     int* d_short_flag, uint64_t* d_tot, uint8_t* d_text, uint64_t* d_packed, int* d_dna_flag, uint64_t* d_offs, hipStream_t s)
 {
 	const uint64_t nwords = (nbytes + 63) / 64;
 	ensure_scratch(fs.marks, (nwords + 2) * 8, s);
@@ -599,8 +624,16 @@ void front_seq_lines(const Index& ix, FrontScratch& fs, const uint8_t* d_bytes, 
 	popcount_prefix(fs, d_ends, nwords, d_epre, s);
 	hipLaunchKernelGGL(k_seq_offsets, dim3(grid_for(nwords, 256)), dim3(256), 0, s, fs.valid.as<unsigned long long>(), fs.vpre.as<uint32_t>(), d_ends, d_epre, nwords,
 	                   d_tot, d_offs);
-	hipLaunchKernelGGL(k_seq_copy, dim3(grid_for(nbytes, 256)), dim3(256), 0, s, d_bytes, nbytes, fs.valid.as<unsigned long long>(), fs.vpre.as<uint32_t>(), d_tot,
-	                   d_text);
+	if (d_packed) {  // 2-bit text: the window's characters are compacted into a window-sized stage first, then packed at the running total
+		ensure_scratch(fs.stage, nbytes + 64, s);
+		hipLaunchKernelGGL(k_seq_copy, dim3(grid_for(nbytes, 256)), dim3(256), 0, s, d_bytes, nbytes, fs.valid.as<unsigned long long>(), fs.vpre.as<uint32_t>(),
+		                   (const uint64_t*)nullptr, fs.stage.as<uint8_t>());
+		hipLaunchKernelGGL(k_seq_pack, dim3(grid_for(nbytes / 32 + 2, 256)), dim3(256), 0, s, fs.stage.as<uint8_t>(), fs.vpre.as<uint32_t>() + nwords, d_tot,
+		                   reinterpret_cast<unsigned long long*>(d_packed), d_dna_flag);
+	} else {
+		hipLaunchKernelGGL(k_seq_copy, dim3(grid_for(nbytes, 256)), dim3(256), 0, s, d_bytes, nbytes, fs.valid.as<unsigned long long>(), fs.vpre.as<uint32_t>(), d_tot,
+		                   d_text);
+	}
 	hipLaunchKernelGGL(k_seq_advance, dim3(1), dim3(1), 0, s, fs.ok.as<uint8_t>(), fs.mpre.as<uint32_t>(), fs.vpre.as<uint32_t>(), d_epre, nwords, d_tot, d_offs);
 	BLMX_HIP(hipGetLastError());
 }

@@ -499,7 +499,10 @@ void build_from_fasta_streamed(Index& ix, const char* path)
 		BLMX_HIP(hipMemcpyAsync(d_offs.p, offs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
 		BLMX_HIP(hipStreamSynchronize(ix.stream));
 	} else {
-		load_fasta_raw_to_device(ix, path, d_ascii, d_offs, nseq, total);
+		load_fasta_raw_to_device(ix, path, d_ascii, d_offs, nseq, total);  // (d_ascii: the 2-bit text)
+		build_from_device_packed(ix, d_ascii, d_offs.as<uint64_t>(), nseq, total);
+		ix.built = true;
+		return;
 	}
 	build_from_device(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), nseq, total);
 	ix.built = true;

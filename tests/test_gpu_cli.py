@@ -118,3 +118,41 @@ def test_shard_query_cpp_world1(tmp_path):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert (res["number_kmer"], res["reads"], res["kmers"], res["found"], res["absent"], res["checksum"]) == (48462, len(reads), kmers, found, absent, checksum)
     assert found >= 48462
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_query_cpp_loopback_ranks(tmp_path, world):
+    """tools/shard_query --transport loopback --world N: the whole multi-GPU path from C++ (construct_index from each rank's part of
+    the file, halo exchange, query_sequences_hash through the native exchange) with N ranks as N threads of one process on the box's one
+    GPU.  The ranks' counts and (read, position, ID) checksums add up to the oracle's over all reads."""
+    import json
+
+    import numpy as np
+    from oracle import oracle as O
+    exe = os.path.join(ROOT, "tools", "shard_query")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "shard_query"])
+    c = G.Case("lambda_k31_m7_n5_b6")
+    rng = np.random.default_rng(5 + world)
+    reads = list(c.seqs) + ["".join("ACGT"[j] for j in rng.integers(0, 4, 120)) for _ in range(700)] + ["ACGT"]
+    rf = tmp_path / "reads.txt"
+    rf.write_text("\n".join(reads) + "\n")
+    orc = O.Oracle(c.k, c.m, c.n, c.b, c.seqs)
+    kmers = found = absent = checksum = 0
+    for i, r in enumerate(reads):
+        ids = orc.query_sequence(r) if len(r) >= c.k else np.zeros(0, np.int64)
+        kmers += ids.size
+        found += int((ids >= 0).sum())
+        absent += int((ids < 0).sum())
+        for j, v in enumerate(ids.tolist()):
+            checksum = (checksum + (i * 1000003 + j + 1) * ((v + 2) % (1 << 64))) % (1 << 64)
+    env = dict(os.environ, BLIGHT_LOOPBACK_TIMEOUT="90")
+    out = subprocess.run([exe, "-g", G.LAMBDA, "-q", str(rf), "-k", "31", "-m", "7", "-n", "5", "-b", "6", "--transport", "loopback", "--world", str(world)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(res) == world and sorted(r["rank"] for r in res) == list(range(world))
+    assert all(r["transport"] == "loopback" and r["number_kmer"] == 48462 for r in res)
+    assert sum(r["reads"] for r in res) == len(reads)
+    assert (sum(r["kmers"] for r in res), sum(r["found"] for r in res), sum(r["absent"] for r in res)) == (kmers, found, absent)
+    assert sum(r["checksum"] for r in res) % (1 << 64) == checksum
