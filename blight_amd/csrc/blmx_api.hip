@@ -80,6 +80,8 @@ void build_host(blmx_index* h, const char* concat, const uint64_t* offsets, uint
 	if (nseq)
 		BLMX_HIP(hipMemcpyAsync(d_offs.p, offsets, (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
 	build_from_device(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), nseq, total);
+	ix.free_after_filter(d_ascii);  // (a hipFree here would wait for the filter's passes)
+	ix.free_after_filter(d_offs);
 	ix.built = true;
 }
 

@@ -1404,19 +1404,31 @@ struct BuildPoolScope {
 	}
 };
 
-// BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream).
+// BLIGHT_BUILD_TRACE=1: wall time of every phase on stderr (each mark synchronises the stream); =2: host time between the marks
+// without synchronising (where does the HOST stall?)
 struct PhaseMarks {
 	hipStream_t s;
-	bool on;
+	bool on, host_only;
 	std::chrono::steady_clock::time_point t_last;
-	explicit PhaseMarks(hipStream_t st) : s(st), on(getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) != 0), t_last(std::chrono::steady_clock::now()) {}
+	explicit PhaseMarks(hipStream_t st)
+	    : s(st), on(getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) != 0),
+	      host_only(getenv("BLIGHT_BUILD_TRACE") && atoi(getenv("BLIGHT_BUILD_TRACE")) == 2), t_last(std::chrono::steady_clock::now())
+	{
+	}
 	void operator()(const char* what)
 	{
 		if (!on)
 			return;
-		(void)hipStreamSynchronize(s);
+		if (!host_only)
+			(void)hipStreamSynchronize(s);
 		const auto now = std::chrono::steady_clock::now();
-		fprintf(stderr, "[blmx build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		const BuildPool* pool = BuildPool::current();
+		size_t parked = 0;
+		if (pool)
+			for (const BuildPool::Block& b : pool->free_blocks)
+				parked += b.bytes;
+		fprintf(stderr, "[blmx build] %-28s %8.2f ms   scratch held %6.2f GB (parked %6.2f GB)\n", what,
+		        std::chrono::duration<double, std::milli>(now - t_last).count(), pool ? pool->held / 1e9 : 0.0, parked / 1e9);
 		t_last = now;
 	}
 };
@@ -1995,6 +2007,8 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 
 	// buffers of ONE pass: keys, two survivor lists, position fields, line popcounts
 	DevBuf d_keys, d_lA, d_lB, d_field, d_linepc, d_linepre;
+	if (npass > 1 && BuildPool::current() && !(getenv("BLIGHT_POOL_TRIM") && atoi(getenv("BLIGHT_POOL_TRIM")) == 0))
+		BuildPool::current()->drain();  // bounded memory was asked for: the blocks K1-K5 have parked go back before the pass buffers are taken
 	BLMX_HIP(d_keys.alloc((max_keys + 1) * 8 * KW, false, s));
 	if (n_small || n_sliced) {
 		BLMX_HIP(d_lA.alloc((max_keys + 1) * 4, false, s));

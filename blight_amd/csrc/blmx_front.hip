@@ -14,6 +14,7 @@
 //     come back.
 #include <fcntl.h>
 #include <immintrin.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -358,6 +359,7 @@ struct SmallLease {
 				std::unique_ptr<SmallSlot> n(new SmallSlot());
 				BLMX_HIP(hipSetDevice(ix.prm.device));
 				n->h.ensure(kSmallSlotBytes);
+				memset(n->h.p, 0, n->h.bytes);  // (a recycled pinned block: the completion flag must start below every target)
 				BLMX_HIP(hipStreamCreateWithFlags(&n->s, hipStreamNonBlocking));
 				BLMX_HIP(n->counter.alloc(64, true, n->s));
 				BLMX_HIP(hipStreamSynchronize(n->s));
@@ -988,6 +990,17 @@ public:
 		if (!gz && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode)) {
 			size_ = (uint64_t)st.st_size;
 			ok_ = true;
+			// The windows are copied out of a read-only mapping (8-16 threads: 55 GB/s with the H2D copies running, against 31-38 GB/s
+			// through pread, profiles/r03_readbench.txt).  BLIGHT_READ=pread keeps to pread (a file that another process truncates
+			// while it is being read raises SIGBUS through a mapping, a short read through pread).
+			const char* e = getenv("BLIGHT_READ");
+			if (size_ && !(e && strcmp(e, "pread") == 0)) {
+				void* m = mmap(nullptr, size_, PROT_READ, MAP_SHARED, fd_, 0);
+				if (m != MAP_FAILED) {
+					map_ = static_cast<const char*>(m);
+					(void)madvise(m, size_, MADV_SEQUENTIAL);
+				}
+			}
 			return;
 		}
 		close(fd_);
@@ -998,12 +1011,18 @@ public:
 			ok_ = true;
 		}
 	}
-	~RawFile()
+	~RawFile() { shut(); }
+	void shut()
 	{
+		if (map_)
+			munmap(const_cast<char*>(map_), size_);
 		if (fd_ >= 0)
 			close(fd_);
 		if (gz_)
 			gzclose(gz_);
+		map_ = nullptr;
+		fd_ = -1;
+		gz_ = nullptr;
 	}
 	RawFile(const RawFile&) = delete;
 	RawFile& operator=(const RawFile&) = delete;
@@ -1052,9 +1071,14 @@ private:
 			std::atomic<bool> bad{false};
 			const uint64_t pos = pos_;
 			const int fd = fd_;
+			const char* map = map_;
 			pool.run(pieces, [&](size_t i) {
 				uint64_t a = (uint64_t)i * kCopyPiece;
 				const uint64_t z = std::min(n, a + kCopyPiece);
+				if (map) {
+					memcpy(dst + a, map + pos + a, z - a);
+					return;
+				}
 				while (a < z) {
 					const ssize_t r = pread(fd, dst + a, z - a, (off_t)(pos + a));
 					if (r <= 0) {
@@ -1081,6 +1105,7 @@ private:
 		return n;
 	}
 	int fd_ = -1;
+	const char* map_ = nullptr;
 	gzFile gz_ = nullptr;
 	uint64_t size_ = 0, pos_ = 0;
 	std::vector<char> tail_;
@@ -1183,6 +1208,7 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 {
 	// d_text holds the 2-bit text (one byte per four nucleotides: an ASCII copy of a human-scale input would cost more to allocate
 	// -- 4.4 GB of fresh HBM: 0.25 s -- than to parse)
+	Trace tr;
 	RawFile rf(path);
 	if (!rf.ok())
 		throw StatusError{BLMX_EIO, "Problem with files opening"};  // blight.cpp:188-189
@@ -1235,7 +1261,7 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 			cap_offs = no;
 		}
 	};
-	Trace tr;
+	tr.lap("open + slots", 0);
 	reserve(0);
 	tr.lap("allocate text+offsets", 0);
 	hipEvent_t copied[kWindowSlots] = {};
@@ -1286,6 +1312,8 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 		throw StatusError{BLMX_ESHORT, "a sequence is shorter than k"};
 	nseq = h_state[4];
 	total = h_state[5];
+	rf.shut();
+	tr.lap("close", 0);
 }
 
 // file_query: returns good / erroneous k-mer counts (the reference prints them: "Good kmer", "Erroneous kmers").

@@ -12,6 +12,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
+#include <exception>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -371,20 +373,78 @@ void launch_narrow_ids(const int64_t* d_ids, uint64_t n, uint32_t* d_out, hipStr
 	BLMX_HIP(hipGetLastError());
 }
 
+// Pinning host memory costs about 0.7 ms per MiB here (3 x 128 MiB: 285 ms, profiles/r03_readbench.txt): the window slots of an index
+// that is destroyed are parked (up to kPinnedCacheBytes per process and device) and serve the next index instead of being unpinned.
+namespace {
+constexpr size_t kPinnedCacheBytes = 1ull << 30, kPinnedCacheMin = 1u << 20;
+struct PinnedCache {
+	struct Block {
+		void* p;
+		size_t bytes;
+		int device;
+	};
+	std::mutex mu;
+	std::vector<Block> blocks;
+	size_t held = 0;
+	static PinnedCache& get()
+	{
+		static PinnedCache* c = new PinnedCache();  // never destroyed: the HIP runtime may be gone when static destructors run
+		return *c;
+	}
+};
+}  // namespace
+
+void Pinned::release()
+{
+	if (!p)
+		return;
+	PinnedCache& c = PinnedCache::get();
+	int dev = 0;
+	bool parked = false;
+	// (while an exception unwinds, copies may still be in flight: hipHostFree waits for them, a parked block would not)
+	if (bytes >= kPinnedCacheMin && std::uncaught_exceptions() == 0 && hipGetDevice(&dev) == hipSuccess) {
+		std::lock_guard<std::mutex> lock(c.mu);
+		if (c.held + bytes <= kPinnedCacheBytes) {
+			c.blocks.push_back({p, bytes, dev});
+			c.held += bytes;
+			parked = true;
+		}
+	}
+	if (!parked)
+		(void)hipHostFree(p);
+	p = nullptr;
+	bytes = 0;
+}
+
 void Pinned::ensure(size_t n, size_t keep)
 {
 	if (n <= bytes)
 		return;
 	const size_t nb = n + n / 4 + 4096;
 	void* q = nullptr;
-	BLMX_HIP(hipHostMalloc(&q, nb, hipHostMallocDefault));
-	if (p) {
-		if (keep)
-			memcpy(q, p, std::min(keep, bytes));
-		(void)hipHostFree(p);
+	size_t qb = nb;
+	int dev = 0;
+	if (n >= kPinnedCacheMin && hipGetDevice(&dev) == hipSuccess) {
+		PinnedCache& c = PinnedCache::get();
+		std::lock_guard<std::mutex> lock(c.mu);
+		size_t best = c.blocks.size();
+		for (size_t i = 0; i < c.blocks.size(); i++)
+			if (c.blocks[i].device == dev && c.blocks[i].bytes >= n && (best == c.blocks.size() || c.blocks[i].bytes < c.blocks[best].bytes))
+				best = i;
+		if (best != c.blocks.size()) {
+			q = c.blocks[best].p;
+			qb = c.blocks[best].bytes;
+			c.held -= qb;
+			c.blocks.erase(c.blocks.begin() + (long)best);
+		}
 	}
+	if (!q)
+		BLMX_HIP(hipHostMalloc(&q, nb, hipHostMallocDefault));
+	if (p && keep)
+		memcpy(q, p, std::min(keep, bytes));
+	release();
 	p = q;
-	bytes = nb;
+	bytes = qb;
 }
 
 // ---- streaming ingest for construction (reference blight.cpp:212-229 reads line by line) ---------------------
@@ -499,12 +559,24 @@ void build_from_fasta_streamed(Index& ix, const char* path)
 		BLMX_HIP(hipMemcpyAsync(d_offs.p, offs.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ix.stream));
 		BLMX_HIP(hipStreamSynchronize(ix.stream));
 	} else {
+		const bool trace = getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) != 0;
+		const auto t0 = std::chrono::steady_clock::now();
 		load_fasta_raw_to_device(ix, path, d_ascii, d_offs, nseq, total);  // (d_ascii: the 2-bit text)
+		const auto t1 = std::chrono::steady_clock::now();
 		build_from_device_packed(ix, d_ascii, d_offs.as<uint64_t>(), nseq, total);
+		const auto t2 = std::chrono::steady_clock::now();
+		ix.free_after_filter(d_ascii);
+		ix.free_after_filter(d_offs);
 		ix.built = true;
+		if (trace)
+			fprintf(stderr, "[blmx front] construct_index(file): load %.1f ms, build %.1f ms, free %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+			        std::chrono::duration<double, std::milli>(t2 - t1).count(),
+			        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
 		return;
 	}
 	build_from_device(ix, d_ascii.as<uint8_t>(), d_offs.as<uint64_t>(), nseq, total);
+	ix.free_after_filter(d_ascii);
+	ix.free_after_filter(d_offs);
 	ix.built = true;
 }
 
