@@ -127,6 +127,7 @@ def load_library():
     lib.blmx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_partition_stats.argtypes = [C.c_void_p, _u64p, C.c_int]
+    lib.blmx_release_scratch.argtypes = [_u64p, _u64p]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     lib.blmx_export.restype = C.c_int64
     lib.blmx_primitive.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
@@ -469,6 +470,14 @@ class kmer_Set_Light:
             if r < 0:
                 _raise(int(r), self._lib.blmx_last_error(self._h).decode())
         return out
+
+
+def release_scratch():
+    """blmx_release_scratch: build scratch and pinned buffers the library keeps for the next build -> back to the driver;
+    returns (device bytes, pinned bytes) released"""
+    d, p = C.c_uint64(0), C.c_uint64(0)
+    load_library().blmx_release_scratch(C.byref(d), C.byref(p))
+    return int(d.value), int(p.value)
 
 
 def comm_unique_id():

@@ -826,6 +826,17 @@ int blmx_partition_stats(blmx_index* h, uint64_t* out4, int reset)
 	});
 }
 
+int blmx_release_scratch(uint64_t* device_bytes, uint64_t* pinned_bytes)
+{
+	(void)hipDeviceSynchronize();
+	const uint64_t d = ScratchCache::get().release_all(), p = release_pinned_cache();
+	if (device_bytes)
+		*device_bytes = d;
+	if (pinned_bytes)
+		*pinned_bytes = p;
+	return BLMX_OK;
+}
+
 int blmx_stats(const blmx_index* h, blmx_stats_t* out)
 {
 	if (!h || !out)

@@ -2008,7 +2008,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	// buffers of ONE pass: keys, two survivor lists, position fields, line popcounts
 	DevBuf d_keys, d_lA, d_lB, d_field, d_linepc, d_linepre;
 	if (npass > 1 && BuildPool::current() && !(getenv("BLIGHT_POOL_TRIM") && atoi(getenv("BLIGHT_POOL_TRIM")) == 0))
-		BuildPool::current()->drain();  // bounded memory was asked for: the blocks K1-K5 have parked go back before the pass buffers are taken
+		BuildPool::current()->drain(true);  // bounded memory was asked for: the blocks K1-K5 have parked go back before the pass buffers are taken
 	BLMX_HIP(d_keys.alloc((max_keys + 1) * 8 * KW, false, s));
 	if (n_small || n_sliced) {
 		BLMX_HIP(d_lA.alloc((max_keys + 1) * 4, false, s));
@@ -2025,11 +2025,35 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	int levels_used = 0;
 	mark("passes: setup");
 
+	// several passes: the filter's key pass of a pass runs on the background stream next to the pass's level and position kernels (it
+	// only reads the keys); the next pass's keys wait for it
+	const bool filter_in_passes = have_filter && npass > 1;
+	hipEvent_t ev_keys = nullptr, ev_filtered = nullptr;
+	struct PassEvents {
+		hipEvent_t &a, &b;
+		~PassEvents()
+		{
+			if (a)
+				(void)hipEventDestroy(a);
+			if (b)
+				(void)hipEventDestroy(b);
+		}
+	} pass_events{ev_keys, ev_filtered};
+	if (filter_in_passes) {
+		ix.filter_wait();
+		if (!ix.bg_stream)
+			BLMX_HIP(hipStreamCreateWithFlags(&ix.bg_stream, hipStreamNonBlocking));
+		BLMX_HIP(hipEventCreateWithFlags(&ev_keys, hipEventDisableTiming));
+		BLMX_HIP(hipEventCreateWithFlags(&ev_filtered, hipEventDisableTiming));
+	}
+	bool filter_pending_on_bg = false;
 	for (uint32_t p = 0; p < npass; p++) {
 		const uint32_t g0 = pg[p], g1 = pg[p + 1];
 		const uint64_t kb0 = key_at(g0), kb1 = key_at(g1), Np = kb1 - kb0, j0 = pj[p], j1 = pj[p + 1];
 		if (Np == 0)
 			continue;
+		if (filter_pending_on_bg)
+			BLMX_HIP(hipStreamWaitEvent(s, ev_filtered, 0));  // the previous pass's keys are still being read
 		// absolute key numbers index the pass buffers: pointers shifted by the pass's first key
 		uint64_t* keys_p = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(d_keys.p) - (uintptr_t)kb0 * 8 * KW);
 		uint32_t* lA_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(d_lA.p) - (uintptr_t)kb0 * 4);
@@ -2039,6 +2063,15 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		hipLaunchKernelGGL((k_expand_keys<KW>), dim3(grid_for(j1 - j0, kSkPerBlock)), dim3(kBlock), 0, s, d_src.as<uint64_t>(), d_order.as<uint32_t>(),
 		                   d_skpos.as<uint64_t>(), d_keystart.as<uint64_t>(), j0, j1, k, keys_p);
 		BLMX_HIP(hipGetLastError());
+		if (filter_in_passes) {
+			BLMX_HIP(hipEventRecord(ev_keys, s));
+			BLMX_HIP(hipStreamWaitEvent(ix.bg_stream, ev_keys, 0));
+			hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(j1 - j0, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, ix.bg_stream, v, d_smini.as<uint32_t>(),
+			                   d_keystart.as<uint64_t>(), j0, j1, keys_p, d_filter);
+			BLMX_HIP(hipGetLastError());
+			BLMX_HIP(hipEventRecord(ev_filtered, ix.bg_stream));
+			filter_pending_on_bg = true;
+		}
 		if (npass == 1)
 			mark("K6 expand_keys");
 		// ---- K7: BBHash levels.  Groups whose level-0 array fits the LDS budget are built by one workgroup each
@@ -2281,10 +2314,6 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			                   field_p);
 		hipLaunchKernelGGL(k_pack_positions, dim3(g1 - g0), dim3(kPackThreads), 0, s, ix.groups.as<GroupDesc>(), g0, id_base, field_p,
 		                   ix.positions.as<unsigned long long>());
-		// the filter's first pass needs the keys: with several passes it runs here, pass by pass (with one pass: in the background, below)
-		if (have_filter && npass > 1)
-			hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(j1 - j0, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, s, v, d_smini.as<uint32_t>(),
-			                   d_keystart.as<uint64_t>(), j0, j1, keys_p, d_filter);
 		BLMX_HIP(hipGetLastError());
 		BLMX_HIP(hipStreamSynchronize(s));  // the pass's temporaries go out of scope
 		F += Fp;
@@ -2294,6 +2323,8 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			mark(what);
 		}
 	}
+	if (filter_pending_on_bg)
+		BLMX_HIP(hipEventSynchronize(ev_filtered));  // the last pass's keys
 	levels_used = std::max(levels_used, read_scalar(d_lvmax.as<int>(), s));
 	d_src.release();
 	d_skpos.release();
@@ -2364,7 +2395,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			}
 			BLMX_HIP(hipGetLastError());
 			BLMX_HIP(hipEventRecord(ix.filter_ready, ix.bg_stream));
-			if (mark.on) {
+			if (mark.on && !mark.host_only) {
 				BLMX_HIP(hipEventSynchronize(ix.filter_ready));
 				mark("K9c filter: keys + junctions (in the background when not traced)");
 			}

@@ -14,7 +14,6 @@
 //     come back.
 #include <fcntl.h>
 #include <immintrin.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -990,17 +989,6 @@ public:
 		if (!gz && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode)) {
 			size_ = (uint64_t)st.st_size;
 			ok_ = true;
-			// The windows are copied out of a read-only mapping (8-16 threads: 55 GB/s with the H2D copies running, against 31-38 GB/s
-			// through pread, profiles/r03_readbench.txt).  BLIGHT_READ=pread keeps to pread (a file that another process truncates
-			// while it is being read raises SIGBUS through a mapping, a short read through pread).
-			const char* e = getenv("BLIGHT_READ");
-			if (size_ && !(e && strcmp(e, "pread") == 0)) {
-				void* m = mmap(nullptr, size_, PROT_READ, MAP_SHARED, fd_, 0);
-				if (m != MAP_FAILED) {
-					map_ = static_cast<const char*>(m);
-					(void)madvise(m, size_, MADV_SEQUENTIAL);
-				}
-			}
 			return;
 		}
 		close(fd_);
@@ -1014,13 +1002,10 @@ public:
 	~RawFile() { shut(); }
 	void shut()
 	{
-		if (map_)
-			munmap(const_cast<char*>(map_), size_);
 		if (fd_ >= 0)
 			close(fd_);
 		if (gz_)
 			gzclose(gz_);
-		map_ = nullptr;
 		fd_ = -1;
 		gz_ = nullptr;
 	}
@@ -1066,19 +1051,17 @@ private:
 	uint64_t read_more(char* dst, uint64_t want, WorkerPool& pool)
 	{
 		if (fd_ >= 0) {
+			constexpr uint64_t kReadPiece = 2u << 20;  // a 32-MiB window keeps 16 workers busy
 			const uint64_t n = pos_ < size_ ? std::min(want, size_ - pos_) : 0;
-			const size_t pieces = (size_t)((n + kCopyPiece - 1) / kCopyPiece);
+			const size_t pieces = (size_t)((n + kReadPiece - 1) / kReadPiece);
 			std::atomic<bool> bad{false};
 			const uint64_t pos = pos_;
 			const int fd = fd_;
-			const char* map = map_;
+			// (pread by 16 workers in 2-MiB pieces: 44 GB/s from tmpfs / the page cache with the H2D copies running; copying out of a
+			// mapping is faster per byte, but tearing its page tables down costs as much again, profiles/r03_readbench.txt)
 			pool.run(pieces, [&](size_t i) {
-				uint64_t a = (uint64_t)i * kCopyPiece;
-				const uint64_t z = std::min(n, a + kCopyPiece);
-				if (map) {
-					memcpy(dst + a, map + pos + a, z - a);
-					return;
-				}
+				uint64_t a = (uint64_t)i * kReadPiece;
+				const uint64_t z = std::min(n, a + kReadPiece);
 				while (a < z) {
 					const ssize_t r = pread(fd, dst + a, z - a, (off_t)(pos + a));
 					if (r <= 0) {
@@ -1105,7 +1088,6 @@ private:
 		return n;
 	}
 	int fd_ = -1;
-	const char* map_ = nullptr;
 	gzFile gz_ = nullptr;
 	uint64_t size_ = 0, pos_ = 0;
 	std::vector<char> tail_;
@@ -1217,9 +1199,9 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 	std::lock_guard<std::mutex> lock(ix.mu);
 	for (auto& w : hf.win)
 		prepare_window_slot(w);
-	// every window's device work runs on ONE stream (the appends are ordered); the pinned slots rotate so that reading the next
-	// window overlaps the copy and the kernels of the previous ones
-	hipStream_t s = hf.win[0].s;
+	// every window's kernels run on ONE stream (the appends are ordered) and the H2D copies on a second one, so that a window's copy
+	// overlaps the kernels of the window before it; the pinned slots rotate so that reading the next window overlaps both
+	hipStream_t s = hf.win[0].s, s_copy = hf.win[1].s;
 	DevBuf d_state;  // [0..3] line carry (two generations), [4] sequences, [5] characters, [6] short flag, [7] invalid-character flag
 	BLMX_HIP(d_state.alloc(64, true, s));
 	uint64_t* carry = d_state.as<uint64_t>();
@@ -1264,19 +1246,21 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 	tr.lap("open + slots", 0);
 	reserve(0);
 	tr.lap("allocate text+offsets", 0);
-	hipEvent_t copied[kWindowSlots] = {};
+	hipEvent_t copied[2 * kWindowSlots] = {};  // [slot]: the slot's H2D copy has left the pinned buffer; [slots + slot]: its kernels are done
+	hipEvent_t* parsed = copied + kWindowSlots;
 	struct EvGuard {
 		hipEvent_t* e;
-		hipStream_t s;
+		hipStream_t s, s_copy;
 		~EvGuard()
 		{
-			(void)hipStreamSynchronize(s);  // no copy out of a pinned slot may still be in flight when the caller unwinds
-			for (int i = 0; i < kWindowSlots; i++)
+			(void)hipStreamSynchronize(s_copy);  // no copy out of a pinned slot may still be in flight when the caller unwinds
+			(void)hipStreamSynchronize(s);
+			for (int i = 0; i < 2 * kWindowSlots; i++)
 				if (e[i])
 					(void)hipEventDestroy(e[i]);
 		}
-	} guard{copied, s};
-	for (int i = 0; i < kWindowSlots; i++)
+	} guard{copied, s, s_copy};
+	for (int i = 0; i < 2 * kWindowSlots; i++)
 		BLMX_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
 	bool used[kWindowSlots] = {};
 	FrontScratch& fs = hf.win[0].fs;
@@ -1294,12 +1278,18 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 			throw StatusError{BLMX_ELIMIT, "a line of 4 GiB or more"};
 		reserve(nbytes);
 		seen += nbytes;
+		if (nbytes + 64 > w.d_in.bytes && used[slot])
+			BLMX_HIP(hipEventSynchronize(parsed[slot]));  // (the slot's device buffer is about to be replaced)
 		grow(w.d_in, nbytes + 64, s);
-		BLMX_HIP(hipMemcpyAsync(w.d_in.p, w.h_in.p, nbytes, hipMemcpyHostToDevice, s));
-		BLMX_HIP(hipEventRecord(copied[slot], s));
+		if (used[slot])
+			BLMX_HIP(hipStreamWaitEvent(s_copy, parsed[slot], 0));  // the kernels of the slot's previous window have read its device buffer
+		BLMX_HIP(hipMemcpyAsync(w.d_in.p, w.h_in.p, nbytes, hipMemcpyHostToDevice, s_copy));
+		BLMX_HIP(hipEventRecord(copied[slot], s_copy));
 		used[slot] = true;
+		BLMX_HIP(hipStreamWaitEvent(s, copied[slot], 0));
 		front_seq_lines(ix, fs, w.d_in.as<uint8_t>(), nbytes, carry + 2 * (i & 1), carry + 2 * ((i + 1) & 1), d_short, d_tot, nullptr, d_text.as<uint64_t>(), d_dna,
 		                d_offs.as<uint64_t>(), s);
+		BLMX_HIP(hipEventRecord(parsed[slot], s));
 		tr.lap("enqueue", i);
 	}
 	uint64_t h_state[8] = {};

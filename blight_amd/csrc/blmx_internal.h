@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -80,18 +83,100 @@ struct DeviceIndexView {
 // buffers whose lifetimes barely overlap: blocks released by a temporary are kept here and handed to the next request
 // they fit (all work of a build is on one stream, so reuse is ordered), and everything goes back to the driver when
 // the build ends.  Index arrays (DevBuf::persistent) never come from the pool.
+// Scratch blocks a finished build would give back to the driver are parked here for the NEXT build of the process (up to
+// `cap` bytes per process, default 1/8 of the device's memory, BLIGHT_SCRATCH_CACHE_GB / blmx_release_scratch): once a process
+// has allocated as much as the card holds, hipMalloc has to wait for VRAM the driver has not finished reclaiming -- 2.9-3.4 s per
+// call measured on every fourth or fifth C4-size build in a row (profiles/r03_exp_slow_hipmalloc.txt) -- and a build's scratch is
+// the bulk of that churn.
+struct ScratchCache {
+	struct Block {
+		void* p;
+		size_t bytes;
+		int device;
+	};
+	std::mutex mu;
+	std::vector<Block> blocks;
+	size_t held = 0;
+	long long cap = -1;  // -1 = not decided yet
+	static ScratchCache& get()
+	{
+		static ScratchCache* c = new ScratchCache();  // never destroyed (the HIP runtime may be gone when static destructors run)
+		return *c;
+	}
+	void give(void* p, size_t bytes)
+	{
+		int dev = 0;
+		if (hipGetDevice(&dev) == hipSuccess) {
+			std::lock_guard<std::mutex> lock(mu);
+			if (cap < 0) {
+				const char* e = getenv("BLIGHT_SCRATCH_CACHE_GB");
+				size_t fr = 0, tot = 0;
+				if (e)
+					cap = (long long)(atof(e) * 1e9);
+				else
+					cap = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 8) : 0;
+			}
+			if ((long long)(held + bytes) <= cap) {
+				blocks.push_back({p, bytes, dev});
+				held += bytes;
+				return;
+			}
+		}
+		(void)hipFree(p);
+	}
+	bool take(size_t n, void** p, size_t* bytes)
+	{
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess)
+			return false;
+		std::lock_guard<std::mutex> lock(mu);
+		size_t best = blocks.size();
+		for (size_t i = 0; i < blocks.size(); i++)
+			if (blocks[i].device == dev && blocks[i].bytes >= n && blocks[i].bytes <= 2 * n + (64u << 20) &&
+			    (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
+				best = i;
+		if (best == blocks.size())
+			return false;
+		*p = blocks[best].p;
+		*bytes = blocks[best].bytes;
+		held -= blocks[best].bytes;
+		blocks.erase(blocks.begin() + (long)best);
+		return true;
+	}
+	size_t release_all()  // everything back to the driver; returns the bytes released
+	{
+		std::vector<Block> mine;
+		{
+			std::lock_guard<std::mutex> lock(mu);
+			mine.swap(blocks);
+			held = 0;
+		}
+		size_t n = 0;
+		for (const Block& b : mine) {
+			(void)hipFree(b.p);
+			n += b.bytes;
+		}
+		return n;
+	}
+};
+
 struct BuildPool {
 	struct Block {
 		void* p;
 		size_t bytes;
 	};
 	std::vector<Block> free_blocks;
-	size_t held = 0, peak_held = 0;  // bytes this pool holds from the driver (live temporaries + parked blocks), and their high-water mark
+	size_t held = 0, peak_held = 0;  // bytes this pool holds (live temporaries + parked blocks), and their high-water mark
 	~BuildPool() { drain(); }
-	void drain()
+	void drain(bool to_driver = false)  // parked blocks -> the process-wide cache (or straight back to the driver)
 	{
+		if (!to_driver && !free_blocks.empty())
+			(void)hipDeviceSynchronize();  // (what hipFree did implicitly: the next owner may run on another stream)
 		for (const Block& b : free_blocks) {
-			(void)hipFree(b.p);
+			if (to_driver)
+				(void)hipFree(b.p);
+			else
+				ScratchCache::get().give(b.p, b.bytes);
 			held -= std::min(held, b.bytes);
 		}
 		free_blocks.clear();
@@ -109,10 +194,20 @@ struct BuildPool {
 			free_blocks.erase(free_blocks.begin() + (long)best);
 			return hipSuccess;
 		}
+		if (ScratchCache::get().take(n, p, bytes)) {
+			held += *bytes;
+			peak_held = std::max(peak_held, held);
+			return hipSuccess;
+		}
+		const auto t0 = std::chrono::steady_clock::now();
 		hipError_t e = hipMalloc(p, n);
-		if (e != hipSuccess) {  // out of memory with blocks parked here: give them back and retry
+		const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		if (ms > 20.0 && getenv("BLIGHT_BUILD_TRACE"))
+			fprintf(stderr, "[blmx build] hipMalloc of %.2f GB took %.1f ms\n", n / 1e9, ms);
+		if (e != hipSuccess) {  // out of memory with blocks parked here or in the process-wide cache: give them back and retry
 			(void)hipGetLastError();
-			drain();
+			drain(true);
+			ScratchCache::get().release_all();
 			e = hipMalloc(p, n);
 		}
 		*bytes = n;
@@ -163,6 +258,10 @@ struct DevBuf {
 			owner = e == hipSuccess ? pool : nullptr;
 		} else {
 			e = hipMalloc(&p, n);
+			if (e == hipErrorOutOfMemory && ScratchCache::get().release_all()) {
+				(void)hipGetLastError();
+				e = hipMalloc(&p, n);
+			}
 			bytes = n;
 		}
 		if (e != hipSuccess) {
@@ -184,6 +283,7 @@ struct StatusError {
 };
 
 // ---- pinned host staging buffer (grow-only; `keep` bytes survive a grow) -----------------------------------------------------
+size_t release_pinned_cache();  // blmx_stream.hip: parked pinned blocks back to the driver; returns their bytes
 struct Pinned {
 	void* p = nullptr;
 	size_t bytes = 0;
@@ -261,7 +361,7 @@ struct Index {
 			for (DevBuf& b : filter_pending)
 				b.release();
 			for (const BuildPool::Block& b : deferred_blocks)
-				(void)hipFree(b.p);
+				ScratchCache::get().give(b.p, b.bytes);
 			deferred_blocks.clear();
 			std::lock_guard<std::mutex> lock(late_mu);
 			for (void* q : late_free)

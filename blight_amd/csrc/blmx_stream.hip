@@ -394,6 +394,23 @@ struct PinnedCache {
 };
 }  // namespace
 
+size_t release_pinned_cache()
+{
+	PinnedCache& c = PinnedCache::get();
+	std::vector<PinnedCache::Block> mine;
+	{
+		std::lock_guard<std::mutex> lock(c.mu);
+		mine.swap(c.blocks);
+		c.held = 0;
+	}
+	size_t n = 0;
+	for (const PinnedCache::Block& b : mine) {
+		(void)hipHostFree(b.p);
+		n += b.bytes;
+	}
+	return n;
+}
+
 void Pinned::release()
 {
 	if (!p)

@@ -332,6 +332,12 @@ int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
  * k-mers that did not fit their bin's region and went through the overflow region (they are answered all the same, only without
  * locality), the largest such count of one batch]; reset != 0 clears the counters.  Synchronises the device. */
 int blmx_partition_stats(blmx_index* ix, uint64_t* out4, int reset);
+/* Memory the library keeps between calls, per process: the scratch blocks of a finished build (up to 1/8 of the device's memory, or
+ * BLIGHT_SCRATCH_CACHE_GB; they serve the next build of the process -- on this driver a hipMalloc that has to wait for reclaimed VRAM
+ * takes ~3 s) and the pinned window buffers of destroyed indexes (up to 1 GiB; pinning costs ~0.7 ms per MiB).  This call returns all
+ * of it to the driver; *device_bytes / *pinned_bytes (either may be NULL) receive what was released.  Safe at any time: the caches
+ * also empty themselves when an allocation fails. */
+int blmx_release_scratch(uint64_t* device_bytes, uint64_t* pinned_bytes);
 
 /* Copy index arrays back to the host for array-level parity checks (tests only; not needed by callers).
  * which: 0 bucket_nt u32[nbuckets] | 1 bucket_start u64[nbuckets] | 2 packed sequence u64[ceil(total_nt/32)]

@@ -507,3 +507,25 @@ def test_build_passes_do_not_change_the_index(B, O, k, kb, m, n, b, fat):
                 ld.load_disk(td + "/p.blmx")
                 assert np.array_equal(ld.query_kmer_hash(rq.reshape(-1)), ix.query_kmer_hash(rq.reshape(-1)))
         ix.close()
+
+
+def test_scratch_cache_is_reused_and_released(B, O):
+    """blmx_release_scratch: the scratch blocks of a finished build and the pinned window buffers of a destroyed index wait for the next
+    build of the process; the call hands them back to the driver, and an index built from recycled blocks is the same index."""
+    rng = np.random.default_rng(5)
+    seqs = [_rand_seq(rng, 200) for _ in range(3000)]
+    B.release_scratch()
+    arrays = []
+    for rep in range(2):
+        ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+        ix.construct_index_from_sequences(seqs)
+        ix.set_tuning("absent_filter", 1)  # waits for the filter's passes: the build's temporaries are parked afterwards
+        ix.query_sequences_hash(seqs[:1500])  # host-buffer calls take pinned buffers: window slots ...
+        ix.query_sequences_hash(seqs[:1])     # ... and the 1-MiB slot of the small calls
+        arrays.append({name: ix.export(name) for name in B.EXPORT})
+        ix.close()
+    for name in B.EXPORT:
+        assert np.array_equal(arrays[0][name], arrays[1][name]), name
+    dev, pinned = B.release_scratch()
+    assert dev > 0 and pinned > 0
+    assert B.release_scratch() == (0, 0)
