@@ -295,6 +295,9 @@ struct HostFront {
 	bool comb_led = false;
 	std::atomic<int> comb_nwait{0};  // comb_wait.size(), readable without the lock
 	std::atomic<int> comb_peak{1};   // calls the recent launches carried (decays): what a new leader may expect to gather
+	// BLIGHT_TRACE: what the combiner's rounds carried and where their time went (printed when the index is destroyed)
+	const bool comb_trace = getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) != 0;
+	std::atomic<uint64_t> cs_rounds{0}, cs_calls{0}, cs_gather_ns{0}, cs_pack_ns{0}, cs_launch_ns{0}, cs_wait_ns{0}, cs_hand_ns{0};
 	DevBuf d_counts, d_carry;  // file streaming: found / not found, line carry between windows
 	// scratch of blmx_query_sequences_device (calls on different streams are ordered with an event)
 	FrontScratch dev_fs;
@@ -305,6 +308,12 @@ struct HostFront {
 	bool dev_used = false;
 	~HostFront()
 	{
+		if (comb_trace && cs_rounds.load()) {
+			const double r = (double)cs_rounds.load();
+			fprintf(stderr, "[blmx front] small calls: %llu launches carried %llu calls (%.2f each); per launch: gather %.2f us, pack %.2f us, launch %.2f us, wait %.2f us, hand out %.2f us\n",
+			        (unsigned long long)cs_rounds.load(), (unsigned long long)cs_calls.load(), cs_calls.load() / r, cs_gather_ns.load() / r / 1e3, cs_pack_ns.load() / r / 1e3,
+			        cs_launch_ns.load() / r / 1e3, cs_wait_ns.load() / r / 1e3, cs_hand_ns.load() / r / 1e3);
+		}
 		if (dev_done)
 			(void)hipEventDestroy(dev_done);
 	}
@@ -429,12 +438,16 @@ void wait_small(SmallSlot& sl, volatile unsigned int* flag, unsigned int ticket)
 }
 
 // answer everything in `batch` with (at most) one fused read launch and one k-mer launch on one pinned slot
-void serve_small(Index& ix, HostFront& hf, std::vector<SmallReq*>& batch)
+template <typename AfterLaunch>
+void serve_small(Index& ix, HostFront& hf, std::vector<SmallReq*>& batch, AfterLaunch&& after_launch)
 {
 	SmallLease lease(ix, hf);
 	SmallSlot& sl = *lease.sl;
 	char* base = sl.h.as<char>();
 	const size_t kb = (size_t)ix.KW * 8;
+	const bool tr = hf.comb_trace;
+	auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const uint64_t t_begin = tr ? now_ns() : 0;
 	uint64_t nbytes = 0, nseq = 0, nk_seq = 0, nkm = 0;
 	for (const SmallReq* r : batch) {
 		if (r->kind == SmallReq::kSequences) {
@@ -479,13 +492,17 @@ void serve_small(Index& ix, HostFront& hf, std::vector<SmallReq*>& batch)
 	sl.target += units;
 	sl.ticket++;
 	const DoneSignal done{sl.counter.as<unsigned int>(), flag, sl.target, sl.ticket};
+	const uint64_t t_packed = tr ? now_ns() : 0;
 	if (nk_seq)
 		launch_read_query(ix, nullptr, reinterpret_cast<const uint8_t*>(base + o_chars), nbytes, nbytes, h_offs, h_koffs, nseq,
 		                  reinterpret_cast<int64_t*>(base + o_ids), nullptr, h_err, sl.s, done);
 	if (nkm)
 		launch_query(ix, base + o_kmers, nullptr, nkm, base + o_kids, kQueryIds, sl.s, done);
+	after_launch();  // (the next leader may gather, pack and launch on another slot while this launch is in flight)
+	const uint64_t t_launched = tr ? now_ns() : 0;
 	if (units)
 		wait_small(sl, flag, sl.ticket);
+	const uint64_t t_done = tr ? now_ns() : 0;
 	// hand the answers out.  An invalid character fails the sequence calls of this launch that hold one (the reference throws per call).
 	const bool bad_char = *h_err != 0;
 	ck = cm = 0;
@@ -516,6 +533,14 @@ void serve_small(Index& ix, HostFront& hf, std::vector<SmallReq*>& batch)
 		}
 	}
 	ix.number_query.fetch_add(nk_seq + nkm, std::memory_order_relaxed);
+	if (tr) {
+		hf.cs_rounds.fetch_add(1, std::memory_order_relaxed);
+		hf.cs_calls.fetch_add(batch.size(), std::memory_order_relaxed);
+		hf.cs_pack_ns.fetch_add(t_packed - t_begin, std::memory_order_relaxed);
+		hf.cs_launch_ns.fetch_add(t_launched - t_packed, std::memory_order_relaxed);
+		hf.cs_wait_ns.fetch_add(t_done - t_launched, std::memory_order_relaxed);
+		hf.cs_hand_ns.fetch_add(now_ns() - t_done, std::memory_order_relaxed);
+	}
 }
 
 // what one launch may carry (one pinned slot of kSmallSlotBytes)
@@ -555,14 +580,18 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 		// would carry only the calls that arrived while the previous launch was in flight (half of the callers, and each call would wait
 		// two launches).  So it gives the others a few microseconds -- as long as recent launches carried more calls than wait now;
 		// a lone caller never waits.
+		static const int gather_us = getenv("BLIGHT_COMBINE_GATHER_US") ? atoi(getenv("BLIGHT_COMBINE_GATHER_US")) : 5;
 		const int expect = hf.comb_peak.load(std::memory_order_relaxed) - 1;
-		if (expect > 0) {
+		if (expect > 0 && gather_us > 0) {
 			const auto t0 = std::chrono::steady_clock::now();
 			for (int spin = 0; hf.comb_nwait.load(std::memory_order_relaxed) < expect; spin++) {
 				_mm_pause();
-				if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(5))
+				if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(gather_us))
 					break;
 			}
+			if (hf.comb_trace)
+				hf.cs_gather_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+				                          std::memory_order_relaxed);
 		}
 		std::vector<SmallReq*> batch;
 		batch.push_back(&me);
@@ -594,14 +623,13 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 		}
 		int code = BLMX_OK;
 		std::string msg;
-		try {
-			serve_small(ix, hf, batch);
-		} catch (const StatusError& e) {
-			code = e.code;
-			msg = e.msg;
-		}
-		{
-			// leadership goes to a caller that is still waiting (it will observe state 3), or nobody leads
+		bool handed = false;
+		auto hand_over = [&] {
+			// leadership goes to a caller that is still waiting (it will observe state 3), or nobody leads.  This happens as soon as the
+			// launch has been enqueued: rounds overlap (each on its own pinned slot and stream), a call waits for ITS round only.
+			if (handed)
+				return;
+			handed = true;
 			std::lock_guard<std::mutex> l(hf.comb_mu);
 			if (hf.comb_wait.empty()) {
 				hf.comb_led = false;
@@ -611,7 +639,14 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 				hf.comb_nwait.store((int)hf.comb_wait.size(), std::memory_order_relaxed);
 				next->state.store(3, std::memory_order_release);
 			}
+		};
+		try {
+			serve_small(ix, hf, batch, hand_over);
+		} catch (const StatusError& e) {
+			code = e.code;
+			msg = e.msg;
 		}
+		hand_over();  // (a launch that failed before it was enqueued)
 		for (SmallReq* r : batch) {
 			if (code != BLMX_OK && r->code == BLMX_OK) {
 				r->code = code;
