@@ -9,6 +9,9 @@
 #include <memory>
 #include <new>
 
+#include <execinfo.h>
+#include <signal.h>
+
 #include "blmx_internal.h"
 
 using namespace blmx;
@@ -108,6 +111,26 @@ void with_staged_sequences(Index& ix, const char* concat, const uint64_t* offset
 extern "C" {
 
 const char* blmx_version(void) { return "blight-mi355x 0.1 (gfx950)"; }
+// BLIGHT_SEGV_TRACE=1: print the native stack of the faulting thread on SIGSEGV (debugging aid: Python's faulthandler stops at the ctypes call)
+namespace {
+void segv_trace(int sig)
+{
+	void* frames[64];
+	const int n = backtrace(frames, 64);
+	backtrace_symbols_fd(frames, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
+struct SegvTraceInit {
+	SegvTraceInit()
+	{
+		const char* e = getenv("BLIGHT_SEGV_TRACE");
+		if (e && atoi(e) != 0)
+			signal(SIGSEGV, segv_trace);
+	}
+} segv_trace_init;
+}  // namespace
+
 int blmx_abi_version(void) { return BLMX_ABI_VERSION; }
 const char* blmx_create_error(void) { return g_create_err.c_str(); }
 const char* blmx_last_error(const blmx_index* ix) { return ix ? g_last_err.c_str() : g_create_err.c_str(); }

@@ -382,13 +382,22 @@ struct LoopbackTransport final : Transport {
 			hub->cv.notify_all();
 			hub->wait(l, [&] { return hub->colls[seq].finished == world; }, "end of a collective");
 			evs = hub->colls[seq].done;
-			if (++hub->colls[seq].left == world)
-				hub->colls.erase(seq);
 		}
 		for (uint32_t r = 0; r < world; r++)  // nobody overwrites its contribution before everybody has copied it
 			BLMX_HIP(hipStreamWaitEvent(s, evs[r], 0));
-		retired.push_back(ready);
-		retired.push_back(done);
+		{
+			// every rank waits on every rank's events: they are retired by the LAST rank to have enqueued its waits (a rank that retired
+			// its own events on leaving could destroy them -- in the sweep of its next call -- before a slower peer has used them)
+			std::lock_guard<std::mutex> l(hub->mu);
+			LoopHub::Coll& c = hub->colls[seq];
+			if (++c.left == world) {
+				for (uint32_t r = 0; r < world; r++) {
+					retired.push_back(c.ready[r]);
+					retired.push_back(c.done[r]);
+				}
+				hub->colls.erase(seq);
+			}
+		}
 	}
 
 	void all_reduce_sum(uint64_t* inout, uint64_t n, hipStream_t s) override

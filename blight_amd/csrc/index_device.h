@@ -90,6 +90,21 @@ __device__ __forceinline__ GroupHead load_bucket_and_head(const BucketDesc* __re
 	return unpack_group_head(a, b, c, d);
 }
 
+__device__ __forceinline__ GroupHead unpack_query_head(const uint4& a, const uint4& b)
+{
+	GroupHead h;
+	h.prefix = (uint64_t)a.x | ((uint64_t)a.y << 32);
+	h.posstart = (uint64_t)a.z | ((uint64_t)(a.w & 0x00ffffffu) << 32);
+	h.nbits = a.w >> 24;
+	h.line_base = b.x;
+	h.size0 = b.y;
+	h.size1 = b.z;
+	h.size2 = b.w;
+	h.fb_start = 0;
+	h.fb_count = 0;
+	return h;
+}
+
 // The same round trip with the compact QueryHead (32 B): three 16-B loads instead of five.  fb_* are not part of it
 // (the lookup reads them from the GroupDesc when all levels missed).
 __device__ __forceinline__ GroupHead load_bucket_and_qhead(const BucketDesc* __restrict__ bp, const QueryHead* __restrict__ qp, uint64_t& bstart,
@@ -106,17 +121,7 @@ __device__ __forceinline__ GroupHead load_bucket_and_qhead(const BucketDesc* __r
 	    : "memory");
 	bstart = (uint64_t)bd.x | ((uint64_t)bd.y << 32);
 	bnt = bd.z;
-	GroupHead h;
-	h.prefix = (uint64_t)a.x | ((uint64_t)a.y << 32);
-	h.posstart = (uint64_t)a.z | ((uint64_t)(a.w & 0x00ffffffu) << 32);
-	h.nbits = a.w >> 24;
-	h.line_base = b.x;
-	h.size0 = b.y;
-	h.size1 = b.z;
-	h.size2 = b.w;
-	h.fb_start = 0;
-	h.fb_count = 0;
-	return h;
+	return unpack_query_head(a, b);
 }
 
 // ---- absent-key filter ---------------------------------------------------------------------------------------------------------
@@ -166,6 +171,8 @@ __device__ __forceinline__ uint32_t fat_filter_word(uint64_t fh) { return (uint3
 // the first
 __device__ __forceinline__ void load_fat_head_and_filter(const uint4* __restrict__ line, uint32_t word, uint4& head, uint64_t& fw)
 {
+	// (default cache policy: `nt` makes the slot kernel 40 % slower -- the bin's lines no longer stay in the Infinity Cache -- and `sc1`
+	// 11 %: the two loads of one line then cost two L2 requests; profiles/r03_exp_fat_line_cache_policy_c4.txt)
 	const uint64_t* fp = reinterpret_cast<const uint64_t*>(line) + 2 + word;
 	uint2 f;
 	asm volatile(

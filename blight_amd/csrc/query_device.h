@@ -221,17 +221,29 @@ __device__ __forceinline__ DeviceIndexView gated_view(DeviceIndexView v)
 	return v;
 }
 
+// the query body behind the bucket descriptor and the group head (query_one loads them from HBM, k_query_slots from LDS)
+template <int KW, int LOGP, bool WANT_POS>
+__device__ __forceinline__ void query_one_with(const DeviceIndexView& v, Kmer<KW> x, Kmer<KW> xr, const GroupDesc* gd, const GroupHead& gh, uint64_t bstart,
+                                               uint32_t bnt, int64_t& id, int32_t& posj);
+
 template <int KW, int LOGP, bool WANT_POS>
 __device__ __forceinline__ void query_one(const DeviceIndexView& v, Kmer<KW> x, Kmer<KW> xr, uint32_t mini, int64_t& id, int32_t& posj)
 {
-	id = -1;
-	posj = -1;
 	// bucket descriptor + group head: one round trip (both addresses depend only on the minimizer)
 	uint64_t bstart;
 	uint32_t bnt;
 	const GroupDesc* gd = &v.groups[mini >> v.gshift];
 	const GroupHead gh = v.qheads ? load_bucket_and_qhead(&v.buckets[mini], &v.qheads[mini >> v.gshift], bstart, bnt)
 	                              : load_bucket_and_head(&v.buckets[mini], gd, bstart, bnt);
+	query_one_with<KW, LOGP, WANT_POS>(v, x, xr, gd, gh, bstart, bnt, id, posj);
+}
+
+template <int KW, int LOGP, bool WANT_POS>
+__device__ __forceinline__ void query_one_with(const DeviceIndexView& v, Kmer<KW> x, Kmer<KW> xr, const GroupDesc* gd, const GroupHead& gh, uint64_t bstart,
+                                               uint32_t bnt, int64_t& id, int32_t& posj)
+{
+	id = -1;
+	posj = -1;
 	if (bnt == 0)  // blight.cpp:719-720
 		return;
 	if (v.filter && !v.fat) {  // absent-key filter (index_device.h): one 8-B load instead of the levels, the position and the window
