@@ -2467,14 +2467,14 @@ void shard_build_abort(Index& ix)
 namespace {
 
 template <int KW>
-void shard_begin_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out)
+void shard_begin_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out, DevBuf* packed)
 {
 	shard_build_abort(ix);
 	std::unique_ptr<ShardExchange> x(new ShardExchange());
 	x->t_begin = std::chrono::steady_clock::now();
 	BuildPoolScope scope(&x->pool);
 	PhaseMarks mark(ix.stream);
-	chop_input<KW>(ix, d_ascii, d_offs, nseq, total_len, x->local, mark);
+	chop_input<KW>(ix, d_ascii, d_offs, nseq, total_len, x->local, mark, packed);
 	const std::vector<uint64_t> h = group_histogram(ix, x->local);
 	memcpy(hist_out, h.data(), (size_t)ix.ngroups * 8);
 	hist_out[ix.ngroups] = x->local.nsk;
@@ -2484,14 +2484,56 @@ void shard_begin_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs,
 
 }  // namespace
 
-void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out)
+void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out, DevBuf* packed)
 {
 	if (ix.built)
 		throw StatusError{BLMX_ESTATE, "index already built"};
 	if (ix.KW == 1)
-		shard_begin_impl<1>(ix, d_ascii, d_offs, nseq, total_len, hist_out);
+		shard_begin_impl<1>(ix, d_ascii, d_offs, nseq, total_len, hist_out, packed);
 	else
-		shard_begin_impl<2>(ix, d_ascii, d_offs, nseq, total_len, hist_out);
+		shard_begin_impl<2>(ix, d_ascii, d_offs, nseq, total_len, hist_out, packed);
+}
+
+// ---- a consecutive part of a 2-bit text (the file loader's output) as a text of its own: sequences [u0, u1) --------------------------
+namespace {
+__global__ void k_slice_text(const uint64_t* __restrict__ in, uint64_t start_nt, uint64_t len_nt, uint64_t nwords, uint64_t* __restrict__ out)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords)
+		return;
+	const uint64_t p0 = w * 32;
+	uint64_t v = 0;
+	if (p0 < len_nt) {
+		const uint64_t q = start_nt + p0;
+		v = funnel_left(in[q >> 5], in[(q >> 5) + 1], 2 * (int)(q & 31));
+		const uint64_t rem = len_nt - p0;
+		if (rem < 32)
+			v &= ~0ull << (64 - 2 * rem);  // what follows the part belongs to the next rank
+	}
+	out[w] = v;
+}
+__global__ void k_slice_offsets(const uint64_t* __restrict__ offs, uint64_t u0, uint64_t n, uint64_t* __restrict__ out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		out[i] = offs[u0 + i] - offs[u0];
+}
+}  // namespace
+
+void slice_packed_text(const DevBuf& d_text, const uint64_t* d_offs_all, uint64_t u0, uint64_t u1, DevBuf& out_text, DevBuf& out_offs, uint64_t& total_len,
+                       hipStream_t s)
+{
+	uint64_t h[2] = {0, 0};
+	BLMX_HIP(hipMemcpyAsync(&h[0], d_offs_all + u0, 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipMemcpyAsync(&h[1], d_offs_all + u1, 8, hipMemcpyDeviceToHost, s));
+	BLMX_HIP(hipStreamSynchronize(s));
+	total_len = h[1] - h[0];
+	const uint64_t nwords = (total_len + 31) / 32 + 4;
+	BLMX_HIP(out_text.alloc(nwords * 8, false, s));
+	BLMX_HIP(out_offs.alloc((u1 - u0 + 1) * 8, false, s));
+	hipLaunchKernelGGL(k_slice_text, dim3(grid_for(nwords)), dim3(kBlock), 0, s, d_text.as<uint64_t>(), h[0], total_len, nwords, out_text.as<uint64_t>());
+	hipLaunchKernelGGL(k_slice_offsets, dim3(grid_for(u1 - u0 + 1)), dim3(kBlock), 0, s, d_offs_all, u0, u1 - u0 + 1, out_offs.as<uint64_t>());
+	BLMX_HIP(hipGetLastError());
 }
 
 void shard_build_plan(Index& ix, const uint64_t* global_hist, uint32_t world_of_caller, uint64_t* send_sk, uint64_t* send_words, const void** d_meta,

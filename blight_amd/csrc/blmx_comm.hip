@@ -822,7 +822,8 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 // finishes its shard -> all-gather of the heads of the shards' sequences: every shard keeps, behind its own sequence, what the single
 // index holds there (shard_halo_set).  A rank whose input is invalid -- or whose index / communicator do not fit -- still takes
 // part in the first all-reduce with a failure flag, and all ranks fail together.
-void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, const StatusError* already_failed)
+void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, const StatusError* already_failed,
+                   DevBuf* packed_text)
 {
 	std::lock_guard<std::mutex> lock(c.mu);
 	BLMX_HIP(hipSetDevice(c.device));
@@ -843,7 +844,7 @@ void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d
 	StatusError local = already_failed ? *already_failed : precondition(ix, c, false);  // e.g. this rank could not open its input: it still takes part
 	if (local.code == BLMX_OK) {
 		try {
-			shard_build_begin(ix, d_ascii, d_offs, nseq, total_len, hist.data());
+			shard_build_begin(ix, d_ascii, d_offs, nseq, total_len, hist.data(), packed_text);
 		} catch (const StatusError& e) {
 			local = e;
 		}
@@ -920,14 +921,21 @@ void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d
 // sequences: rank r of w takes sequences [nseq * r / w, nseq * (r + 1) / w)
 void build_sharded_from_fasta(Index& ix, Comm& c, const char* path)
 {
+	// Every rank streams the whole file through the device parser (the host only moves bytes: ~0.1 s for 3.5 GB) and keeps the rank-th
+	// consecutive part of its sequences -- which sequences a rank contributes does not change the index (blmx_build.hip: slices).
 	BLMX_HIP(hipSetDevice(c.device));
-	DevBuf d_ascii, d_offs;
-	std::vector<uint64_t> offs(1, 0);
-	uint64_t total = 0;
+	DevBuf d_text, d_offs_all, d_mine, d_offs;
+	uint64_t nseq = 0, total = 0, mine_total = 0, u0 = 0, u1 = 0;
 	StatusError local = precondition(ix, c, false);
 	if (local.code == BLMX_OK) {
 		try {
-			load_fasta_to_device(ix, path, d_ascii, offs, total);
+			load_fasta_raw_to_device(ix, path, d_text, d_offs_all, nseq, total);
+			u0 = nseq * c.rank / c.world;
+			u1 = nseq * (c.rank + 1) / c.world;
+			slice_packed_text(d_text, d_offs_all.as<uint64_t>(), u0, u1, d_mine, d_offs, mine_total, ix.stream);
+			BLMX_HIP(hipStreamSynchronize(ix.stream));
+			d_text.release();
+			d_offs_all.release();
 		} catch (const StatusError& e) {
 			local = e;
 		}
@@ -936,15 +944,7 @@ void build_sharded_from_fasta(Index& ix, Comm& c, const char* path)
 		build_sharded(ix, c, nullptr, nullptr, 0, 0, &local);  // throws `local` after the all-reduce
 		throw local;
 	}
-	const uint64_t nseq = offs.size() - 1;
-	const uint64_t u0 = nseq * c.rank / c.world, u1 = nseq * (c.rank + 1) / c.world;
-	std::vector<uint64_t> mine(u1 - u0 + 1);
-	for (uint64_t i = 0; i <= u1 - u0; i++)
-		mine[i] = offs[u0 + i] - offs[u0];
-	BLMX_HIP(d_offs.alloc(mine.size() * 8, false, ix.stream));
-	BLMX_HIP(hipMemcpyAsync(d_offs.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, ix.stream));
-	BLMX_HIP(hipStreamSynchronize(ix.stream));
-	build_sharded(ix, c, d_ascii.as<uint8_t>() + offs[u0], d_offs.as<uint64_t>(), u1 - u0, mine.back(), nullptr);
+	build_sharded(ix, c, nullptr, d_offs.as<uint64_t>(), u1 - u0, mine_total, nullptr, &d_mine);
 }
 
 // host buffers in and out around the device exchange (collective)

@@ -505,7 +505,11 @@ void init_filter_gate(Index& ix, hipStream_t s);  // with the filter (build and 
 void positions_to_reference_layout(const Index& ix, DevBuf& out, hipStream_t s);  // `positions` with the reference's field width (export)
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
 // sharded build from slices, phase by phase (blmx_build.hip); hist_out holds ngroups + 1 words: key histogram, local super-k-mers
-void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out);
+// packed != nullptr: the slice's text is already 2-bit packed (taken over; d_ascii unused)
+void shard_build_begin(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len, uint64_t* hist_out, DevBuf* packed = nullptr);
+// sequences [u0, u1) of a 2-bit text with device offsets -> a text of their own (offsets relative to its start)
+void slice_packed_text(const DevBuf& d_text, const uint64_t* d_offs_all, uint64_t u0, uint64_t u1, DevBuf& out_text, DevBuf& out_offs, uint64_t& total_len,
+                       hipStream_t s);
 void shard_build_plan(Index& ix, const uint64_t* global_hist, uint32_t world, uint64_t* send_sk, uint64_t* send_words, const void** d_meta,
                       const void** d_words);
 void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in, const uint64_t* recv_sk, const uint64_t* recv_words);
@@ -609,7 +613,7 @@ void comm_loopback_id(void* id_out);
 void comm_set_tuning(Comm& c, const char* key, int64_t value);
 const char* comm_transport(const Comm* c);
 void build_sharded(Index& ix, Comm& c, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len,
-                   const StatusError* already_failed = nullptr);
+                   const StatusError* already_failed = nullptr, DevBuf* packed = nullptr);
 void build_sharded_from_fasta(Index& ix, Comm& c, const char* path);
 void query_kmers_sharded_host(Index& ix, Comm& c, const void* kmers, uint64_t nq, int64_t* ids_out);
 void query_sequences_sharded_device(Index& ix, Comm& c, const uint8_t* d_chars, const uint64_t* d_offs, uint64_t nseq, uint64_t total, uint64_t nk,

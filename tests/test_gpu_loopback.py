@@ -36,7 +36,7 @@ def run_ranks(world, fn):
 
 
 @pytest.mark.parametrize("world,k,m,n,b", [(2, 31, 9, 7, 6), (3, 31, 7, 5, 4), (8, 31, 9, 9, 6), (3, 63, 9, 7, 8)])
-def test_native_exchange_on_the_loopback_transport(world, k, m, n, b):
+def test_native_exchange_on_the_loopback_transport(world, k, m, n, b, tmp_path):
     import torch
     import blight_amd as B
     import shard_util as S
@@ -154,6 +154,40 @@ def test_native_exchange_on_the_loopback_transport(world, k, m, n, b):
     for r in range(world):
         assert np.array_equal(got[r][0], want[qcuts[r]:qcuts[r + 1]]), r
         assert np.array_equal(got[r][1], np.concatenate(rwant[r::world])), r
+
+    # ---- many small collectives back to back: ranks leave a collective at different times and enter the next one at once (the events
+    # of a collective must outlive its slowest rank)
+    small = [q[qcuts[r]:qcuts[r] + 40 + r] for r in range(world)]
+
+    def many_small(r):
+        out = []
+        for it in range(60):
+            out.append(comms[r].query_kmers_sharded(ixs[r], small[r].reshape(-1)))
+        return out
+
+    got, err = run_ranks(world, many_small)
+    assert not any(err), err
+    for r in range(world):
+        for a in got[r]:
+            assert np.array_equal(a, want[qcuts[r]:qcuts[r] + len(small[r])]), r
+
+    # ---- construction from ONE FASTA file named on every rank (device parser; each rank keeps its consecutive part of the sequences)
+    fa = tmp_path / "u.fa"
+    fa.write_text("".join(">u%d\n%s\n" % (i, s_) for i, s_ in enumerate(seqs)))
+    from_file = [None] * world
+
+    def build_from_file(r):
+        ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
+        ix.set_shard(r, world)
+        comms[r].build_sharded_from_fasta(ix, str(fa))
+        from_file[r] = ix
+
+    _, err = run_ranks(world, build_from_file)
+    assert not any(err), err
+    for r in range(world):
+        for name in B.EXPORT:
+            assert np.array_equal(from_file[r].export(name), ref[r].export(name)), (r, name)
+        from_file[r].close()
 
     # ---- failures are collective: one rank's input is rejected / one rank's index is not built -> nobody hangs, everybody fails
     fresh = [B.kmer_Set_Light(k, m, n, min(n, 3), 1, b) for _ in range(world)]
