@@ -1479,9 +1479,7 @@ void chop_input(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		if (packed->bytes < (src_words + 4) * 8)
 			throw StatusError{BLMX_EINVAL, "internal: packed text too small"};
 		d_src.release();
-		std::swap(d_src.p, packed->p);
-		std::swap(d_src.bytes, packed->bytes);
-		std::swap(d_src.owner, packed->owner);
+		d_src.swap(*packed);
 	} else {
 		BLMX_HIP(d_src.alloc((src_words + 4) * 8, true, s));
 	}
@@ -1688,15 +1686,9 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		}
 		DevBuf d_pos2, d_last2, d_mini2;
 		const uint64_t kept = select_groups(glo, ghi, d_pos2, d_last2, d_mini2);
-		std::swap(d_skpos.p, d_pos2.p);
-		std::swap(d_skpos.bytes, d_pos2.bytes);
-		std::swap(d_skpos.owner, d_pos2.owner);
-		std::swap(d_sklast.p, d_last2.p);
-		std::swap(d_sklast.bytes, d_last2.bytes);
-		std::swap(d_sklast.owner, d_last2.owner);
-		std::swap(d_skmini.p, d_mini2.p);
-		std::swap(d_skmini.bytes, d_mini2.bytes);
-		std::swap(d_skmini.owner, d_mini2.owner);
+		d_skpos.swap(d_pos2);
+		d_sklast.swap(d_last2);
+		d_skmini.swap(d_mini2);
 		nsk = kept;
 	}
 
@@ -2376,11 +2368,13 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 					continue;  // only the super-k-mer starts are still needed
 				ix.filter_pending[i].p = hand_over[i]->p;
 				ix.filter_pending[i].bytes = hand_over[i]->bytes;
+				ix.filter_pending[i].cap = hand_over[i]->cap;
 				ix.filter_pending[i].owner = nullptr;
 				if (hand_over[i]->owner)
 					hand_over[i]->owner->held -= std::min(hand_over[i]->owner->held, hand_over[i]->bytes);
 				hand_over[i]->p = nullptr;
 				hand_over[i]->bytes = 0;
+				hand_over[i]->cap = 0;
 				hand_over[i]->owner = nullptr;
 			}
 			ix.filter_state.store(0);

@@ -1257,9 +1257,7 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 				BLMX_HIP(hipMemcpyAsync(bigger.p, d_text.p, cap_text, hipMemcpyDeviceToDevice, s));
 				BLMX_HIP(hipStreamSynchronize(s));
 			}
-			std::swap(bigger.p, d_text.p);
-			std::swap(bigger.bytes, d_text.bytes);
-			std::swap(bigger.owner, d_text.owner);
+			bigger.swap(d_text);
 			cap_text = nb;
 		}
 		if (need_offs > cap_offs) {
@@ -1272,9 +1270,7 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 			} else {
 				BLMX_HIP(hipMemsetAsync(bigger.p, 0, 8, s));  // offs[0] = 0
 			}
-			std::swap(bigger.p, d_offs.p);
-			std::swap(bigger.bytes, d_offs.bytes);
-			std::swap(bigger.owner, d_offs.owner);
+			bigger.swap(d_offs);
 			cap_offs = no;
 		}
 	};

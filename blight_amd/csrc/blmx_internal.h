@@ -84,7 +84,7 @@ struct DeviceIndexView {
 // they fit (all work of a build is on one stream, so reuse is ordered), and everything goes back to the driver when
 // the build ends.  Index arrays (DevBuf::persistent) never come from the pool.
 // Scratch blocks a finished build would give back to the driver are parked here for the NEXT build of the process (up to
-// `cap` bytes per process, default 1/8 of the device's memory, BLIGHT_SCRATCH_CACHE_GB / blmx_release_scratch): once a process
+// `cap` bytes per process, default 1/6 of the device's memory, BLIGHT_SCRATCH_CACHE_GB / blmx_release_scratch): once a process
 // has allocated as much as the card holds, hipMalloc has to wait for VRAM the driver has not finished reclaiming -- 2.9-3.4 s per
 // call measured on every fourth or fifth C4-size build in a row (profiles/r03_exp_slow_hipmalloc.txt) -- and a build's scratch is
 // the bulk of that churn.
@@ -114,7 +114,7 @@ struct ScratchCache {
 				if (e)
 					cap = (long long)(atof(e) * 1e9);
 				else
-					cap = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 8) : 0;
+					cap = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 6) : 0;
 			}
 			if ((long long)(held + bytes) <= cap) {
 				blocks.push_back({p, bytes, dev});
@@ -124,15 +124,17 @@ struct ScratchCache {
 		}
 		(void)hipFree(p);
 	}
-	bool take(size_t n, void** p, size_t* bytes)
+	// tight: index arrays and staging buffers (what they hold is what the index reports) take a block at most 1/8 larger
+	bool take(size_t n, void** p, size_t* bytes, bool tight = false)
 	{
 		int dev = 0;
 		if (hipGetDevice(&dev) != hipSuccess)
 			return false;
+		const size_t most = tight ? n + n / 8 + (1u << 20) : 2 * n + (64u << 20);
 		std::lock_guard<std::mutex> lock(mu);
 		size_t best = blocks.size();
 		for (size_t i = 0; i < blocks.size(); i++)
-			if (blocks[i].device == dev && blocks[i].bytes >= n && blocks[i].bytes <= 2 * n + (64u << 20) &&
+			if (blocks[i].device == dev && blocks[i].bytes >= n && blocks[i].bytes <= most &&
 			    (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
 				best = i;
 		if (best == blocks.size())
@@ -143,6 +145,18 @@ struct ScratchCache {
 		blocks.erase(blocks.begin() + (long)best);
 		return true;
 	}
+	// a buffer that did not come from a build's pool (index array, staging, query scratch): kernels that use it may still be running
+	// -- hipFree would wait for them, so does this
+	void give_synced(void* p, size_t bytes)
+	{
+		if (bytes < kMinBytes) {
+			(void)hipFree(p);
+			return;
+		}
+		(void)hipDeviceSynchronize();
+		give(p, bytes);
+	}
+	static constexpr size_t kMinBytes = 1u << 20;
 	size_t release_all()  // everything back to the driver; returns the bytes released
 	{
 		std::vector<Block> mine;
@@ -230,6 +244,7 @@ struct DevBuf {
 	size_t bytes = 0;
 	bool persistent = false;     // index array: exact hipMalloc, never pooled
 	BuildPool* owner = nullptr;  // pool the current block came from (build temporaries)
+	size_t cap = 0;              // outside a pool: size of the block behind p when it came from the process-wide cache (0: bytes)
 	DevBuf() = default;
 	DevBuf(const DevBuf&) = delete;
 	DevBuf& operator=(const DevBuf&) = delete;
@@ -240,11 +255,19 @@ struct DevBuf {
 			if (owner)
 				owner->put(p, bytes);
 			else
-				(void)hipFree(p);
+				ScratchCache::get().give_synced(p, cap ? cap : bytes);
 		}
 		p = nullptr;
 		bytes = 0;
+		cap = 0;
 		owner = nullptr;
+	}
+	void swap(DevBuf& o)  // (persistent stays with the object: it says what the object is, not what it holds)
+	{
+		std::swap(p, o.p);
+		std::swap(bytes, o.bytes);
+		std::swap(cap, o.cap);
+		std::swap(owner, o.owner);
 	}
 	hipError_t alloc(size_t n, bool zero, hipStream_t s)
 	{
@@ -257,16 +280,26 @@ struct DevBuf {
 			e = pool->get(n, &p, &bytes);
 			owner = e == hipSuccess ? pool : nullptr;
 		} else {
-			e = hipMalloc(&p, n);
-			if (e == hipErrorOutOfMemory && ScratchCache::get().release_all()) {
-				(void)hipGetLastError();
+			if (n >= ScratchCache::kMinBytes && ScratchCache::get().take(n, &p, &cap, true)) {
+				e = hipSuccess;
+				bytes = n;  // (what was asked for: the index reports and writes exactly that)
+			} else {
+				const auto t0 = std::chrono::steady_clock::now();
 				e = hipMalloc(&p, n);
+				const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+				if (ms > 20.0 && getenv("BLIGHT_BUILD_TRACE"))
+					fprintf(stderr, "[blmx] hipMalloc of %.2f GB (index array / staging) took %.1f ms\n", n / 1e9, ms);
+				if (e == hipErrorOutOfMemory && ScratchCache::get().release_all()) {
+					(void)hipGetLastError();
+					e = hipMalloc(&p, n);
+				}
+				bytes = n;
 			}
-			bytes = n;
 		}
 		if (e != hipSuccess) {
 			p = nullptr;
 			bytes = 0;
+			cap = 0;
 			owner = nullptr;
 			return e;
 		}
@@ -364,22 +397,23 @@ struct Index {
 				ScratchCache::get().give(b.p, b.bytes);
 			deferred_blocks.clear();
 			std::lock_guard<std::mutex> lock(late_mu);
-			for (void* q : late_free)
-				(void)hipFree(q);
+			for (const BuildPool::Block& q : late_free)
+				ScratchCache::get().give(q.p, q.bytes);
 			late_free.clear();
 			filter_state.store(2, std::memory_order_release);
 		});
 	}
 	// Input buffers of a build whose owner returns while the filter's passes still run: hipFree would wait for them.
 	std::mutex late_mu;
-	std::vector<void*> late_free;
+	std::vector<BuildPool::Block> late_free;
 	void free_after_filter(DevBuf& b)
 	{
 		std::lock_guard<std::mutex> lock(late_mu);
 		if (b.p && !b.owner && filter_state.load(std::memory_order_acquire) == 0) {
-			late_free.push_back(b.p);
+			late_free.push_back(BuildPool::Block{b.p, b.cap ? b.cap : b.bytes});
 			b.p = nullptr;
 			b.bytes = 0;
+			b.cap = 0;
 		} else
 			b.release();
 	}

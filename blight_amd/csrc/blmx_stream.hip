@@ -521,8 +521,7 @@ void load_fasta_to_device(Index& ix, const char* path, DevBuf& d_ascii, std::vec
 			BLMX_HIP(bigger.alloc(std::max<uint64_t>(2 * d_ascii.bytes, total + fill + 64), false, s));
 			BLMX_HIP(hipMemcpyAsync(bigger.p, d_ascii.p, total, hipMemcpyDeviceToDevice, s));
 			BLMX_HIP(hipStreamSynchronize(s));
-			std::swap(bigger.p, d_ascii.p);
-			std::swap(bigger.bytes, d_ascii.bytes);
+			bigger.swap(d_ascii);
 		}
 		BLMX_HIP(hipMemcpyAsync((char*)d_ascii.p + total, pin[cur].p, fill, hipMemcpyHostToDevice, s));
 		BLMX_HIP(hipEventRecord(sent[cur], s));

@@ -332,9 +332,10 @@ int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
  * k-mers that did not fit their bin's region and went through the overflow region (they are answered all the same, only without
  * locality), the largest such count of one batch]; reset != 0 clears the counters.  Synchronises the device. */
 int blmx_partition_stats(blmx_index* ix, uint64_t* out4, int reset);
-/* Memory the library keeps between calls, per process: the scratch blocks of a finished build (up to 1/8 of the device's memory, or
- * BLIGHT_SCRATCH_CACHE_GB; they serve the next build of the process -- on this driver a hipMalloc that has to wait for reclaimed VRAM
- * takes ~3 s) and the pinned window buffers of destroyed indexes (up to 1 GiB; pinning costs ~0.7 ms per MiB).  This call returns all
+/* Memory the library keeps between calls, per process: device blocks of 1 MiB and more that a finished build or a destroyed index
+ * gave up (scratch, index arrays, staging; up to 1/6 of the device's memory, or BLIGHT_SCRATCH_CACHE_GB; they serve the next build
+ * or index of the process -- on this driver hipMalloc of VRAM the process has used before costs 25-100 ms per GB, and ~3 s when the
+ * driver has not finished reclaiming it) and the pinned window buffers of destroyed indexes (up to 1 GiB; pinning costs ~0.7 ms per MiB).  This call returns all
  * of it to the driver; *device_bytes / *pinned_bytes (either may be NULL) receive what was released.  Safe at any time: the caches
  * also empty themselves when an allocation fails. */
 int blmx_release_scratch(uint64_t* device_bytes, uint64_t* pinned_bytes);
