@@ -859,6 +859,8 @@ def main():
         dist.all_reduce(same, op=dist.ReduceOp.MIN)
         slice_build = {"seconds": float(ts.item()), "whole_input_build_seconds_rank0": t_build, "unitigs_of_rank0": u1 - u0,
                        "ids_equal_to_whole_input_build": bool(same.item()),
+                       "build_scratch_peak_bytes_rank0": int(st2["build_scratch_peak_bytes"]),
+                       "whole_input_build_scratch_peak_bytes_rank0": int(st["build_scratch_peak_bytes"]),
                        "what": "every rank chops 1/%d of the unitigs; all-reduce of the group histograms, all-to-all-v of the super-k-mers" % world}
         del ids2, chars, so
         ix2.close()
