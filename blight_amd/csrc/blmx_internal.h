@@ -77,17 +77,19 @@ struct DeviceIndexView {
 	uint32_t* filter_gate;
 };
 
-// ---- tiny RAII device buffer ---------------------------------------------------------------------------------------
-// Cache of device blocks for the temporaries of ONE build.  On this driver hipMalloc of recycled VRAM costs 30-50 ms per GB
-// (pages are cleared when they are handed out again), and a human-scale build allocates ~70 GB of temporaries in ~60
-// buffers whose lifetimes barely overlap: blocks released by a temporary are kept here and handed to the next request
-// they fit (all work of a build is on one stream, so reuse is ordered), and everything goes back to the driver when
-// the build ends.  Index arrays (DevBuf::persistent) never come from the pool.
-// Scratch blocks a finished build would give back to the driver are parked here for the NEXT build of the process (up to
-// `cap` bytes per process, default 1/6 of the device's memory, BLIGHT_SCRATCH_CACHE_GB / blmx_release_scratch): once a process
-// has allocated as much as the card holds, hipMalloc has to wait for VRAM the driver has not finished reclaiming -- 2.9-3.4 s per
-// call measured on every fourth or fifth C4-size build in a row (profiles/r03_exp_slow_hipmalloc.txt) -- and a build's scratch is
-// the bulk of that churn.
+// ---- device memory: blocks are recycled, within a build and across builds -----------------------------------------------------------
+// On this driver hipMalloc of VRAM the process has used before costs 25-100 ms per GB (pages are cleared when they are handed out
+// again), and once a process has allocated as much as the card holds a call has to wait for VRAM the driver has not finished
+// reclaiming: 2.9-3.4 s, measured on every fourth or fifth C4-size build in a row (profiles/r03_exp_slow_hipmalloc.txt).
+//
+// ScratchCache (process-wide): device blocks of 1 MiB and more that a finished build, a destroyed index or a staging buffer gave up
+// are parked here -- up to `cap` bytes, default 1/6 of the device's memory, BLIGHT_SCRATCH_CACHE_GB -- and serve the next request
+// they fit: a build's temporaries with a loose fit, index arrays and staging buffers (DevBuf outside a pool) with a tight one, so
+// that an index reports and writes the sizes it asked for.  blmx_release_scratch, and any allocation that fails, empty it.
+//
+// BuildPool (below): the cache of ONE build.  A human-scale build allocates ~60 temporaries whose lifetimes barely overlap; blocks
+// released by one are handed to the next request they fit (all work of a build is on one stream, so reuse is ordered), and what is
+// left when the build ends goes to the ScratchCache.
 struct ScratchCache {
 	struct Block {
 		void* p;

@@ -34,6 +34,10 @@ def sweep(runs, seed, verbose=True):
         tag = "run %d: k=%d m=%d n=%d b=%d kb=%d nseq=%d alpha=%s" % (it, k, m, n, b, kb, len(seqs), alpha)
         try:
             ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+            if rng.random() < 0.5:
+                ix.set_tuning("build_passes", int(rng.integers(1, 9)))  # passes over ranges of MPHF groups: the arrays must not depend on them
+            if rng.random() < 0.3:
+                ix.set_tuning("fat_lines", 0)                           # separate filter array instead of 64-B level-0 lines
             ix.construct_index_from_sequences(seqs)
             if rng.random() < 0.8:
                 ix.set_tuning("absent_filter", 1)  # queries through the armed absent-key filter (else: maybe before its passes are done)
@@ -76,6 +80,21 @@ def sweep(runs, seed, verbose=True):
                 direct = ix.query_kmer_hash(rq.reshape(-1))
                 raise AssertionError((tag, "readable k-mers", len(bad), [(int(i), [hex(int(x)) for x in rq.reshape(len(got), -1)[i]], int(got[i]), int(rwant[i]),
                                                                          int(nofilter[i]), int(direct[i])) for i in bad[:5]]))
+            # the same k-mers through whole-input SHARDS of a random world: the halo makes every shard cut invisible
+            if rng.random() < 0.15 and n >= 1:
+                import shard_util
+                world = int(rng.integers(2, 7))
+                shards = []
+                for r in range(world):
+                    sx = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+                    sx.set_shard(r, world)
+                    sx.construct_index_from_sequences(seqs)
+                    sx.set_tuning("absent_filter", int(rng.integers(0, 2)))
+                    shards.append(sx)
+                sgot = shard_util.answers_through_shards(shards, rq.reshape(len(rwant), -1))
+                assert np.array_equal(sgot, rwant), (tag, "shards", world, int((sgot != rwant).sum()))
+                for sx in shards:
+                    sx.close()
             # reads cut from the packed sequence itself (junctions and padding included) through the sequence front end
             step = max(1, len(nts) // 40)
             rd = ["".join("ACTG"[c] for c in nts[a0:a0 + k + int(rng.integers(0, 2 * k))].tolist()) for a0 in range(0, max(1, len(nts) - k), step)]
