@@ -2019,7 +2019,12 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 
 	// several passes: the filter's key pass of a pass runs on the background stream next to the pass's level and position kernels (it
 	// only reads the keys); the next pass's keys wait for it
-	const bool filter_in_passes = have_filter && npass > 1;
+	// Several passes: the keys of a pass are gone when the next pass starts, so the filter's key pass either runs inside the passes
+	// (BLIGHT_FILTER_IN_PASSES=1: next to the pass's level and position kernels, on the background stream) or -- default -- AFTER the
+	// build has returned, like the one-pass build's: the background stream expands the keys of every pass once more (4 ms per 6e8 keys)
+	// into the pass's key buffer, which leaves the build's pool together with what the expansion reads.
+	const bool filter_in_passes = have_filter && npass > 1 && getenv("BLIGHT_FILTER_IN_PASSES") && atoi(getenv("BLIGHT_FILTER_IN_PASSES")) != 0;
+	const bool filter_keys_later = have_filter && npass > 1 && !filter_in_passes;
 	hipEvent_t ev_keys = nullptr, ev_filtered = nullptr;
 	struct PassEvents {
 		hipEvent_t &a, &b;
@@ -2318,9 +2323,11 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	if (filter_pending_on_bg)
 		BLMX_HIP(hipEventSynchronize(ev_filtered));  // the last pass's keys
 	levels_used = std::max(levels_used, read_scalar(d_lvmax.as<int>(), s));
-	d_src.release();
-	d_skpos.release();
-	d_order.release();
+	if (!filter_keys_later) {
+		d_src.release();
+		d_skpos.release();
+		d_order.release();
+	}
 	d_bits.release();
 	d_coll.release();
 	d_lA.release();
@@ -2361,11 +2368,13 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			if (!ix.filter_ready)
 				BLMX_HIP(hipEventCreateWithFlags(&ix.filter_ready, hipEventDisableTiming));
 			// what the passes read leaves the build's pool with them (the helper thread frees it)
-			DevBuf* hand_over[4] = {&d_ntstart, &d_smini, &d_keystart, &d_keys};
-			for (int i = 0; i < 4; i++) {
+			DevBuf* hand_over[7] = {&d_ntstart, &d_smini, &d_keystart, &d_keys, &d_src, &d_order, &d_skpos};
+			for (int i = 0; i < 7; i++) {
 				ix.filter_pending[i].release();
-				if (i > 0 && npass > 1)
-					continue;  // only the super-k-mer starts are still needed
+				if (i > 0 && filter_in_passes)
+					continue;  // the keys went in pass by pass: only the super-k-mer starts are still needed (junctions)
+				if (i > 3 && !filter_keys_later)
+					continue;  // (already released: the keys of a one-pass build are all there)
 				ix.filter_pending[i].p = hand_over[i]->p;
 				ix.filter_pending[i].bytes = hand_over[i]->bytes;
 				ix.filter_pending[i].cap = hand_over[i]->cap;
@@ -2381,6 +2390,17 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			if (npass == 1)
 				hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(nsk, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, ix.bg_stream, v,
 				                   ix.filter_pending[1].as<uint32_t>(), ix.filter_pending[2].as<uint64_t>(), (uint64_t)0, nsk, ix.filter_pending[3].as<uint64_t>(), d_filter);
+			if (filter_keys_later)
+				for (uint32_t p = 0; p < npass; p++) {
+					const uint64_t kb0 = key_at(pg[p]), j0 = pj[p], j1 = pj[p + 1];
+					if (key_at(pg[p + 1]) == kb0)
+						continue;
+					uint64_t* keys_p = reinterpret_cast<uint64_t*>(reinterpret_cast<uintptr_t>(ix.filter_pending[3].p) - (uintptr_t)kb0 * 8 * KW);
+					hipLaunchKernelGGL((k_expand_keys<KW>), dim3(grid_for(j1 - j0, kSkPerBlock)), dim3(kBlock), 0, ix.bg_stream, ix.filter_pending[4].as<uint64_t>(),
+					                   ix.filter_pending[5].as<uint32_t>(), ix.filter_pending[6].as<uint64_t>(), ix.filter_pending[2].as<uint64_t>(), j0, j1, k, keys_p);
+					hipLaunchKernelGGL((k_filter_keys<KW>), dim3((grid_for(j1 - j0, kSkPerBlock) + 7u) & ~7u), dim3(kBlock), 0, ix.bg_stream, v,
+					                   ix.filter_pending[1].as<uint32_t>(), ix.filter_pending[2].as<uint64_t>(), j0, j1, keys_p, d_filter);
+				}
 			if (ix.tune_filter_junctions) {
 				const uint64_t cand = (nsk - 1) * (uint64_t)(k - 1) + (uint64_t)(k - 1) + (1ull << b), blocks = (cand + kBlock - 1) / kBlock;
 				const unsigned gx = (unsigned)std::min<uint64_t>(blocks, 1u << 22), gy = (unsigned)((blocks + gx - 1) / gx);

@@ -380,7 +380,8 @@ struct Index {
 	// own stream AFTER the build has returned, and a helper thread waits for it, gives the build's temporaries back to the driver (hipFree waits for the
 	// device, so the build itself must not do it) and arms the filter.  0 = pass pending, 2 = filter usable.
 	mutable std::atomic<int> filter_state{2};
-	DevBuf filter_pending[4];                         // what the passes read: super-k-mer starts, their minimizers, key offsets, keys
+	DevBuf filter_pending[7];                         // what the passes read: super-k-mer starts, their minimizers, key offsets, keys (buffer of
+	                                                  // one build pass), and -- several build passes -- what re-expands the keys: text, order, positions
 	std::vector<BuildPool::Block> deferred_blocks;    // temporaries of the build, freed by the helper thread
 	std::thread filter_thread;
 	hipStream_t bg_stream = nullptr;
