@@ -489,9 +489,11 @@ void serve_small(Index& ix, HostFront& hf, std::vector<SmallReq*>& batch, AfterL
 		units += read_query_signal_units(nbytes);
 	if (nkm)
 		units += query_signal_units(nkm);
-	sl.target += units;
 	sl.ticket++;
-	const DoneSignal done{sl.counter.as<unsigned int>(), flag, sl.target, sl.ticket};
+	if (units > 1)
+		sl.target += units;
+	// a round of ONE wave / workgroup (a k-mer, a read) signals by itself: no device-side count
+	const DoneSignal done{units > 1 ? sl.counter.as<unsigned int>() : nullptr, flag, sl.target, sl.ticket};
 	const uint64_t t_packed = tr ? now_ns() : 0;
 	if (nk_seq)
 		launch_read_query(ix, nullptr, reinterpret_cast<const uint8_t*>(base + o_chars), nbytes, nbytes, h_offs, h_koffs, nseq,
@@ -645,6 +647,12 @@ void combine_small(Index& ix, HostFront& hf, SmallReq& me)
 		} catch (const StatusError& e) {
 			code = e.code;
 			msg = e.msg;
+		} catch (const std::bad_alloc&) {  // whatever ends the leader's round: the callers that ride along must not wait for ever
+			code = BLMX_ENOMEM;
+			msg = "out of host memory";
+		} catch (const std::exception& e) {
+			code = BLMX_EHIP;
+			msg = e.what();
 		}
 		hand_over();  // (a launch that failed before it was enqueued)
 		for (SmallReq* r : batch) {

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_query(DeviceIndexView v, const uint64_t
 		reinterpret_cast<uint8_t*>(out)[o] = id >= 0 ? 1 : 0;
 	if (done.flag) {  // small launches: the last wave that has stored its answers tells the host (waves without a k-mer left above)
 		__threadfence_system();
-		if (lane_id() == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1) && atomicAdd(done.counter, 1u) + 1u == done.target)
+		// (counter == nullptr: this wave is the whole round -- one k-mer, a few k-mers -- and needs nobody's count)
+		if (lane_id() == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1) && (!done.counter || atomicAdd(done.counter, 1u) + 1u == done.target))
 			*done.flag = done.ticket;
 	}
 }

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kFrontBlock) void k_read_query(DeviceIndexView v, c
 	if (done.flag) {  // small launches: the last workgroup that has stored its answers tells the host
 		__threadfence_system();
 		__syncthreads();
-		if (threadIdx.x == 0 && atomicAdd(done.counter, 1u) + 1u == done.target)
+		if (threadIdx.x == 0 && (!done.counter || atomicAdd(done.counter, 1u) + 1u == done.target))  // (nullptr: the only workgroup of the round)
 			*done.flag = done.ticket;
 	}
 }
