@@ -352,7 +352,9 @@ def test_sharded_build_from_slices(world, k, m, n, b):
         some = seqs[::7] + [_rand_seq(rng, 3 * k) for _ in range(50)]
         got = ixs[r].query_sequences_hash(some)
         assert np.array_equal(got, ref[r].query_sequences_hash(some)), r
-        assert (got >= 0).any() or s1["local_number_kmer"] < 50, r  # (a shard may own next to nothing when there are fewer groups than ranks)
+        # (sanity only -- `some` holds a seventh of the input: a shard that owns next to nothing, as happens with fewer groups than ranks
+        # or a handful of minimizer values, may well see none of its k-mers there)
+        assert (got >= 0).any() or s1["local_number_kmer"] < 2000, r
     # EVERY k-mer readable anywhere in the SINGLE index's packed sequence (junctions of super-k-mers, of buckets -- also the ones
     # that are shard cuts now -- and the padding behind the end): both kinds of shards answer like the single index and the oracle
     full = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b)
