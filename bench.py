@@ -79,6 +79,8 @@ def parse_args():
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-buffer / file / per-read-call measurements")
     ap.add_argument("--batches", type=int, default=4, help="independently seeded query batches rotated through the timed loop")
     ap.add_argument("--no-fasta-leg", action="store_true", help="skip construct_index(file) on files written to tmpfs")
+    ap.add_argument("--no-excursion", action="store_true", help="skip the all-absent / all-indexed batches after the timed steps (profiling runs: "
+                                                                "every launch of the query kernels is then a headline step)")
     return ap.parse_args()
 
 
@@ -797,7 +799,7 @@ def main():
     # ---- excursion (single GPU): a batch with no indexed k-mer, then one with only indexed k-mers, each followed by a headline batch
     # that is timed alone: the filter gate and the learnt plan were set by a batch of a different kind
     excursion = None
-    if not multi:
+    if not multi and not args.no_excursion:
         excursion = {}
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         scratch_ids = torch.empty(nq, device=dev, dtype=torch.int64)

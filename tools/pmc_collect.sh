@@ -9,7 +9,7 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$R/gpurun_out/pmc_$LABEL"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="${*:---cpu-seconds 0 --reads 0 --steps 4 --warmup 1 --no-fasta-leg}"
+ARGS="${*:---cpu-seconds 0 --reads 0 --steps 4 --warmup 1 --no-fasta-leg --no-excursion}"
 RE="k_query|k_bin_hist|k_bin_scatter|k_bin_onepass|k_plan_|k_gather_ids|k_gather_runs|k_read_front|k_read_query"
 i=0
 while read -r counters; do
