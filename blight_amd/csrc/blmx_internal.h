@@ -305,8 +305,15 @@ struct DevBuf {
 			owner = nullptr;
 			return e;
 		}
-		if (zero)
+		if (zero) {
 			e = hipMemsetAsync(p, 0, n, s);
+		} else {
+			// BLIGHT_POISON=1 (test hook): a buffer that is not asked to be zero starts as 0xA5 bytes -- recycled blocks hold arbitrary
+			// data, fresh ones happen to be zero: nothing may depend on either
+			static const bool poison = getenv("BLIGHT_POISON") && atoi(getenv("BLIGHT_POISON")) != 0;
+			if (poison)
+				e = hipMemsetAsync(p, 0xA5, cap ? cap : bytes, s);
+		}
 		return e;
 	}
 	template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
