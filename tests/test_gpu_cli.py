@@ -86,6 +86,72 @@ def test_per_read_calls_from_openmp_threads(tmp_path):
         assert res["number_query"] == kmers + max(0, len(reads[0]) - 31 + 1)  # + the warm-up call
 
 
+def test_scalar_and_per_read_calls_from_openmp_threads():
+    """kmer_Set_Light::query_kmer_hash(kmer_t) -- ONE k-mer per call (reference blight.cpp:545-550) -- from 8 OpenMP threads through the
+    C++ facade (tools/libbench_calls.so attaches it to a handle of this process): every answer equals the oracle's, also while a
+    second team of threads issues one query_sequence_hash call per read on the same index, so that k-mer and read requests share
+    launches of the small-call combiner."""
+    import ctypes
+    import threading
+
+    import numpy as np
+    import blight_amd as B
+    from oracle import oracle as O
+    libpath = os.path.join(ROOT, "tools", "libbench_calls.so")
+    if not os.path.exists(libpath):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "libbench_calls.so"])
+    lib = ctypes.CDLL(libpath)
+    u64p, i64p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int64)
+    lib.blight_bench_kmer_calls.argtypes = [ctypes.c_void_p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64p]
+    lib.blight_bench_read_calls.argtypes = [ctypes.c_void_p, ctypes.c_char_p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    c = G.Case("lambda_k31_m7_n5_b6")
+    orc = O.Oracle(c.k, c.m, c.n, c.b, c.seqs)
+    ix = B.kmer_Set_Light(c.k, c.m, c.n, 3, 1, c.b)
+    ix.construct_index_from_sequences(c.seqs)
+    ix.set_tuning("absent_filter", 1)
+    rng = np.random.default_rng(5)
+    pos = orc.canonical_kmers(c.seqs[3])[::7][:6000]
+    neg = np.array([min(x, O.p_rc(x, c.k, 8)) for x in (int(v) & ((1 << 62) - 1) for v in rng.integers(0, 1 << 62, 6000))], dtype=np.uint64)
+    q = np.ascontiguousarray(np.concatenate([pos, neg])[rng.permutation(len(pos) + len(neg))])
+    want = orc.query_kmers(q)
+    assert (want >= 0).sum() >= len(pos)
+
+    def scalar(threads, out):
+        got = np.empty(len(q), dtype=np.int64)
+        secs, found, cs = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = lib.blight_bench_kmer_calls(ix._h, q.ctypes.data_as(u64p), len(q), threads, ctypes.byref(secs), ctypes.byref(found), ctypes.byref(cs),
+                                         got.ctypes.data_as(i64p))
+        out.append((rc, got, found.value))
+
+    for threads in (8, 1):
+        res = []
+        scalar(threads, res)
+        rc, got, found = res[0]
+        assert rc == 0 and np.array_equal(got, want) and found == int((want >= 0).sum()), threads
+    # both kinds of call at once
+    genome = c.seqs[3]
+    reads = [genome[a:a + 150] for a in rng.integers(0, len(genome) - 150, 3000).tolist()] + ["".join("ACGT"[j] for j in rng.integers(0, 4, 150)) for _ in range(1000)]
+    chars = "".join(reads).encode()
+    offs = (np.arange(len(reads) + 1, dtype=np.uint64) * 150)
+    rwant = np.concatenate([orc.query_sequence(r) for r in reads])
+    res, rres = [], []
+
+    def per_read():
+        secs = ctypes.c_double()
+        r = [ctypes.c_uint64() for _ in range(4)]
+        rc = lib.blight_bench_read_calls(ix._h, chars, offs.ctypes.data_as(u64p), len(reads), 4, 1, ctypes.byref(secs), *[ctypes.byref(x) for x in r])
+        rres.append((rc, r[0].value, r[1].value, r[2].value))
+
+    th = [threading.Thread(target=scalar, args=(4, res)), threading.Thread(target=per_read)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert res[0][0] == 0 and np.array_equal(res[0][1], want)
+    assert rres[0] == (0, rwant.size, int((rwant >= 0).sum()), int((rwant < 0).sum()))
+    ix.close()
+
+
 def test_shard_query_cpp_world1(tmp_path):
     """tools/shard_query: the multi-GPU path from C++ only (kmer_Set_Light::communicator of include/blight.h: construct_index from
     this rank's part of the file over RCCL, query_sequences_hash through the native exchange), here with a world of one rank.
