@@ -642,7 +642,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 		BLMX_HIP(hipMemcpyAsync(c.h_dense.as<uint64_t>() + (size_t)p * world, c.counts.as<uint64_t>() + (size_t)p * world, 8 * (size_t)world, hipMemcpyDeviceToHost, s));
 		BLMX_HIP(hipEventRecord(c.ev_part[p], s));
 	};
-	if (local.code == BLMX_OK) {
+	if (local.code == BLMX_OK) try {  // (a rank whose partition fails -- out of memory, a HIP error -- still joins the all-gather below, with its flag set)
 		for (int p = 0; p < pieces; p++) {
 			const uint64_t n = cut[p + 1] - cut[p];
 			slots_fmt[p] = slot_piece_possible(ix, n);
@@ -663,6 +663,8 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 			}
 		if (again)
 			BLMX_HIP(hipStreamSynchronize(s));
+	} catch (const StatusError& err) {
+		local = err;
 	}
 	// ---- formats and per-owner counts of all pieces (+ one "cannot take part" flag) in one all-gather
 	const size_t per_piece = (size_t)world + 1, per_rank = (size_t)pieces * per_piece + 1;
