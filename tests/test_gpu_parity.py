@@ -529,3 +529,40 @@ def test_scratch_cache_is_reused_and_released(B, O):
     dev, pinned = B.release_scratch()
     assert dev > 0 and pinned > 0
     assert B.release_scratch() == (0, 0)
+
+
+@pytest.mark.parametrize("env", [{"BLIGHT_SCRATCH_CACHE_GB": "0"}, {"BLIGHT_POISON": "1"}, {"BLIGHT_POISON": "1", "BLIGHT_BUILD_PASSES": "3"}])
+def test_allocation_hooks_do_not_change_answers(env):
+    """A fresh process with the block cache switched off (every buffer straight from / back to the driver), and one in which every
+    device buffer that is not asked to be zero starts as 0xA5 bytes (recycled blocks hold arbitrary data, fresh ones happen to be
+    zero): a golden case builds and answers like the reference, through the k-mer, sequence and file paths."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, tempfile
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import numpy as np
+import blight_amd as B
+import golden_util as G
+c = G.Case("lambda_k31_m7_n5_b6")
+for rep in range(3):
+    ix = B.kmer_Set_Light(31, 7, 5, 3, 1, 6)
+    if rep == 1:
+        ix.construct_index(G.LAMBDA)
+    else:
+        ix.construct_index_from_sequences(c.seqs)
+    ix.set_tuning("absent_filter", 1)
+    assert np.array_equal(ix.query_sequences_hash(c.seqs), c.ids)
+    assert np.array_equal(ix.query_kmer_hash(c.neg_kmers.reshape(-1)), c.neg_ids)
+    assert ix.file_query(G.LAMBDA) == (48462, 0)
+    ix.close()
+dev, pinned = B.release_scratch()
+if os.environ.get("BLIGHT_SCRATCH_CACHE_GB") == "0":
+    assert dev == 0, dev
+print("HOOKS-OK")
+'''
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "HOOKS-OK" in out.stdout, out.stderr[-2000:]
