@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-buffer / file / per-read-call measurements")
     ap.add_argument("--batches", type=int, default=4, help="independently seeded query batches rotated through the timed loop")
     ap.add_argument("--no-fasta-leg", action="store_true", help="skip construct_index(file) on files written to tmpfs")
+    ap.add_argument("--exp-sort", type=int, default=-1, help=argparse.SUPPRESS)  # experiment: order every batch by (MPHF group, top N bits of the level-0 hash)
     ap.add_argument("--no-excursion", action="store_true", help="skip the all-absent / all-indexed batches after the timed steps (profiling runs: "
                                                                 "every launch of the query kernels is then a headline step)")
     return ap.parse_args()
@@ -702,6 +703,41 @@ def main():
     # learnt from
     nbatch = max(1, args.batches)
     batches = [synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, args.seed * 11 + rank + 1000 * j, kw, args.present) for j in range(nbatch)]
+    if args.exp_sort >= 0 and kw == 1:
+        # (experiment, profiles/r04_exp_sorted_batch_c4.txt: what would a partition that also orders a bin's k-mers by the place of their
+        # level-0 line buy?  The order is made here, outside the timed region: the pipeline keeps it at tile granularity.)
+        M = (1 << 64) - 1
+        seed = 0xAAAAAAAA55555555
+
+        def s64(v):
+            v &= M
+            return v - (1 << 64) if v >> 63 else v
+
+        def shr(x, sft):
+            return (x >> sft) & ((1 << (64 - sft)) - 1)
+
+        def hash_bis0(key):  # SingleHashFunctor::hash_bis with the level-0 seed (bbhash.h:172-185), int64 wrap-around arithmetic
+            h = (key * s64(seed >> 3)) ^ s64(seed ^ ((seed << 7) & M))
+            h = h ^ ~(s64((seed << 11) & M) + (key ^ s64(seed >> 5)))
+            h = (~h) + (h << 21)
+            h = h ^ shr(h, 24)
+            h = (h + (h << 3)) + (h << 8)
+            h = h ^ shr(h, 14)
+            h = (h + (h << 2)) + (h << 4)
+            h = h ^ shr(h, 28)
+            return h + (h << 31)
+        sorted_batches = []
+        for (qq, pp) in batches:
+            grp = torch.empty(nq, device=dev, dtype=torch.int32)
+            ix.kmer_groups_device(qq.data_ptr(), nq, grp.data_ptr(), stream)
+            torch.cuda.synchronize()
+            key = grp.to(torch.int64) << args.exp_sort
+            if args.exp_sort:
+                key |= shr(hash_bis0(qq[:, 0]), 64 - args.exp_sort)
+            order = torch.argsort(key)
+            sorted_batches.append((qq[:, 0].contiguous()[order].reshape(-1, 1).contiguous(), pp[order]))
+            del grp, key, order
+        batches = sorted_batches
     q, is_pos = batches[0]
     ids_all = [torch.empty(nq, device=dev, dtype=torch.int64) for _ in range(nbatch)]
     ids = ids_all[0]

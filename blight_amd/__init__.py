@@ -46,8 +46,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("libblight_mi355x.so is missing: run `python -m blight_amd.build` (hipcc, gfx950)")
+    path = os.environ.get("BLIGHT_LIB_PATH", LIB_PATH)  # (experiments: a variant build of the same sources, blight_amd.build --variant)
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `python -m blight_amd.build` (hipcc, gfx950)" % path)
     # One HIP runtime per process: torch bundles its own libamdhip64 (same soname); whichever is loaded first is shared.
     # Import torch first when it is available so that torch tensors / streams and this library use the same runtime.
     if "torch" not in sys.modules and os.environ.get("BLIGHT_NO_TORCH") != "1":
@@ -55,7 +56,7 @@ def load_library():
             import torch  # noqa: F401
         except Exception:  # pragma: no cover - torch is optional plumbing
             pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.blmx_version.restype = C.c_char_p
     lib.blmx_create_error.restype = C.c_char_p
     lib.blmx_last_error.restype = C.c_char_p

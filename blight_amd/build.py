@@ -51,5 +51,28 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines):
+    """An experimental build of the same sources with extra -D flags -> scratch/lib_<name>.so (git-ignored; travels to the GPU box;
+    BLIGHT_LIB_PATH selects it).  For A/B measurements only: nothing in the tree loads it."""
+    out_dir = os.path.join("/tmp", "blmx_variant_" + name)
+    os.makedirs(out_dir, exist_ok=True)
+    os.makedirs(os.path.join(ROOT, "scratch"), exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:
+        o = os.path.join(out_dir, src.replace(".hip", ".o"))
+        objs.append(o)
+        procs.append((src, subprocess.Popen([HIPCC] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, src), "-o", o])))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    lib = os.path.join(ROOT, "scratch", "lib_%s.so" % name)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lz", "-ldl", "-lpthread"])
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -50,6 +50,8 @@ template <typename F> int guarded(blmx_index* h, F&& f)
 {
 	try {
 		f();
+		if (h)
+			h->ix.check_dropped();  // (a partition pass that lost k-mers: host-buffer calls have finished here, device calls tell the next call)
 		return BLMX_OK;
 	} catch (const StatusError& e) {
 		return fail(h, e.code, e.msg);
@@ -204,7 +206,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.tune_reads_mode = env_int("BLIGHT_READS_MODE", 0);
 	h->ix.tune_partition = env_int("BLIGHT_PARTITION", 0);
 	h->ix.tune_window_kb = env_int("BLIGHT_WINDOW_KB", 0);
-	h->ix.tune_fat_lines = env_int("BLIGHT_FAT_LINES", 1);
+	h->ix.tune_fat_lines = env_int("BLIGHT_FAT_LINES", -1);
 	h->ix.tune_build_passes = env_int("BLIGHT_BUILD_PASSES", 0);
 	if (hipSetDevice(prm.device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
 		g_create_err = "hipStreamCreate failed";
@@ -234,6 +236,8 @@ void blmx_destroy(blmx_index* h)
 			(void)hipEventDestroy(e);
 	if (h->ix.bin_done)
 		(void)hipEventDestroy(h->ix.bin_done);
+	if (h->ix.h_dropped)
+		(void)hipHostFree(h->ix.h_dropped);
 	if (h->ix.stream) {
 		(void)hipStreamSynchronize(h->ix.stream);
 		(void)hipStreamDestroy(h->ix.stream);
@@ -795,8 +799,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_bin_bits = value;
 	else if (k == "filter_bits")  // bits per key of the absent-key filter built at construction (0 = none); set before building
 		ix.tune_filter_bits = value < 0 ? -1 : (value > 32 ? 32 : value);  // -1 = automatic
-	else if (k == "pos_hint")  // before building: 0 = position fields as wide as the reference's (no sub-window hint)
-		ix.tune_pos_hint = value != 0;
+	else if (k == "pos_hint")  // before building: 0 = position fields as wide as the reference's (no sub-window hint), 1 = hint at b >= 7, 2 = at b = 6 too
+		ix.tune_pos_hint = value < 0 ? 0 : (int)std::min<int64_t>(value, 2);
 	else if (k == "filter_gate")  // 0: large batches never switch the filter off for their successors
 		ix.tune_filter_gate = value != 0;
 	else if (k == "filter_junctions")  // test hook, before building
@@ -822,8 +826,10 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_window_kb = value;
 	else if (k == "slot_piece_min")
 		ix.tune_slot_piece_min = value;
-	else if (k == "fat_lines")  // before building
-		ix.tune_fat_lines = value != 0;
+	else if (k == "test_ovf_cap")  // test hook: slots of the one-pass partition's overflow region (0 = a whole batch)
+		ix.tune_test_ovf_cap = (int)value;
+	else if (k == "fat_lines")  // before building: 0 = 16-B lines + filter array, 1 = fat level-0 lines, 2 = level-0 records, -1 = automatic
+		ix.tune_fat_lines = value < 0 ? -1 : (int)std::min<int64_t>(value, 2);
 	else if (k == "build_passes")  // before building: 0 = automatic
 		ix.tune_build_passes = value < 0 ? 0 : (value > 64 ? 64 : value);
 	else if (k == "query_binning")
@@ -971,12 +977,14 @@ int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
 			std::vector<uint64_t> v((size_t)ix.total_logical_words);
 			for (uint32_t g = 0; g < ng; g++) {
 				const GroupDesc& gd = ix.h_groups[g];
-				const uint64_t w0 = gd.size[0] >> 5, F = (w0 + kLineData32 - 1) / kLineData32;  // fat layout: level 0 in 64-B lines of its own
+				// fat layout: level 0 in 64-B units of its own -- 96 bits each, or (records) 32
+				const uint64_t w0 = gd.size[0] >> 5, per = ix.rec_lines ? 1 : kLineData32, F = (w0 + per - 1) / per;
 				for (uint64_t w32 = 0; w32 < 2 * gd.nwords; w32++) {
 					uint64_t unit = gd.line_base + w32 / kLineData32, slot = w32 % kLineData32;
-					if (ix.fat_lines) {
-						unit = w32 < w0 ? gd.line_base + 4 * (w32 / kLineData32) : gd.line_base + 4 * F + (w32 - w0) / kLineData32;
-						slot = w32 < w0 ? w32 % kLineData32 : (w32 - w0) % kLineData32;
+					if (ix.fat_lines) {  // (cross-paired 128-B blocks of two units)
+						const uint64_t u = w32 / per;
+						unit = w32 < w0 ? gd.line_base + 8 * (u >> 1) + 4 * (u & 1) : gd.line_base + 8 * ((F + 1) / 2) + (w32 - w0) / kLineData32;
+						slot = w32 < w0 ? w32 % per : (w32 - w0) % kLineData32;
 					}
 					const uint64_t x = hl[unit * kLineWords32 + 1 + slot];
 					v[gd.wbase + (w32 >> 1)] |= x << (32 * (w32 & 1));

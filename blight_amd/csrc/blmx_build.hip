@@ -974,32 +974,35 @@ __device__ __forceinline__ uint32_t line_data_word(const GroupDesc* __restrict__
 }
 
 // A group's lines in rank order ("logical lines"): without fat lines, line l covers the 32-bit words 3l .. 3l+2 of all levels back to
-// back; with fat lines (index_device.h) the first F = fat_lines_of(size0) lines cover level 0 alone -- the last of them padded with
-// zeros -- and the lines behind them the deeper levels.  line_base[] counts LOGICAL lines (rank bookkeeping); GroupDesc::line_base
-// counts 16-B units of the line array (a fat line takes four).
+// back; with fat lines (index_device.h) the first F = level0_units64(size0) lines cover level 0 alone -- 96 bits each, the last of
+// them padded with zeros, or 32 bits each when they are records -- and the lines behind them the deeper levels.  line_base[] counts
+// LOGICAL lines (rank bookkeeping); GroupDesc::line_base counts 16-B units of the line array (a fat line or record takes four).
+// layout: 0 = 16-B lines only, 1 = fat level-0 lines, 2 = level-0 records
 __device__ __forceinline__ uint32_t logical_line_word(const GroupDesc* __restrict__ gd, const unsigned long long* __restrict__ bits,
-                                                      const unsigned long long* __restrict__ coll, uint64_t lrel, int s, bool fat)
+                                                      const unsigned long long* __restrict__ coll, uint64_t lrel, int s, int layout)
 {
-	if (!fat)
+	if (layout == 0)
 		return line_data_word(gd, bits, coll, lrel * kLineData32 + s);
-	const uint64_t w0 = gd->size[0] >> 5, F = fat_lines_of(gd->size[0]);
+	const uint64_t w0 = gd->size[0] >> 5, F = level0_units64(gd->size[0], layout == 2);
 	if (lrel < F) {
+		if (layout == 2)
+			return s == 0 ? line_data_word(gd, bits, coll, lrel) : 0u;
 		const uint64_t w32 = lrel * kLineData32 + s;
 		return w32 < w0 ? line_data_word(gd, bits, coll, w32) : 0u;
 	}
 	return line_data_word(gd, bits, coll, w0 + (lrel - F) * kLineData32 + s);
 }
-__device__ __forceinline__ uint64_t logical_line_unit(const GroupDesc* __restrict__ gd, uint64_t lrel, bool fat)
+__device__ __forceinline__ uint64_t logical_line_unit(const GroupDesc* __restrict__ gd, uint64_t lrel, int layout)
 {
-	if (!fat)
+	if (layout == 0)
 		return gd->line_base + lrel;
-	const uint64_t F = fat_lines_of(gd->size[0]);
-	return lrel < F ? gd->line_base + lrel * kFatUnits : gd->line_base + F * kFatUnits + (lrel - F);
+	const uint64_t F = level0_units64(gd->size[0], layout == 2);  // (cross-paired 128-B blocks of two units: index_device.h)
+	return lrel < F ? gd->line_base + (lrel >> 1) * kBlockUnits + (lrel & 1) * 4 : gd->line_base + level0_block_units(gd->size[0], layout == 2) + (lrel - F);
 }
 
 __global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t L0, uint64_t nlines,
                             const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
-                            uint64_t* __restrict__ linepc, bool fat)
+                            uint64_t* __restrict__ linepc, int layout)
 {
 	const uint64_t L = L0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // the logical lines [L0, nlines) (a pass of the build)
 	linepc -= L0;
@@ -1013,13 +1016,13 @@ __global__ void k_line_popc(const GroupDesc* __restrict__ groups, const uint64_t
 	const GroupDesc* gd = &groups[g];
 	uint64_t pc = 0;
 	for (int s = 0; s < kLineData32; s++)
-		pc += (uint64_t)__popc(logical_line_word(gd, bits, coll, L - line_base[g], s, fat));
+		pc += (uint64_t)__popc(logical_line_word(gd, bits, coll, L - line_base[g], s, layout));
 	linepc[L] = pc;
 }
 
 __global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t L0, uint64_t nlines,
                              const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ coll,
-                             const uint64_t* __restrict__ linepre, uint4* __restrict__ lines, bool fat)
+                             const uint64_t* __restrict__ linepre, uint4* __restrict__ lines, int layout)
 {
 	const uint64_t L = L0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	linepre -= L0;
@@ -1030,10 +1033,46 @@ __global__ void k_line_write(const GroupDesc* __restrict__ groups, const uint64_
 	const uint64_t lrel = L - line_base[g];
 	uint4 o;
 	o.x = (uint32_t)(linepre[L] - linepre[line_base[g]]);  // rank restarts at 0 in every group (bbhash.h:447-465)
-	o.y = logical_line_word(gd, bits, coll, lrel, 0, fat);
-	o.z = logical_line_word(gd, bits, coll, lrel, 1, fat);
-	o.w = logical_line_word(gd, bits, coll, lrel, 2, fat);
-	lines[logical_line_unit(gd, lrel, fat)] = o;  // (a fat line's filter words stay zero here: the filter passes set them)
+	o.y = logical_line_word(gd, bits, coll, lrel, 0, layout);
+	o.z = logical_line_word(gd, bits, coll, lrel, 1, layout);
+	o.w = logical_line_word(gd, bits, coll, lrel, 2, layout);
+	// (a fat line's filter words stay zero here: the filter passes set them; a record's position fields -- o.z, o.w are the first two
+	// words of them, zero here -- are written by k_record_positions once the pass's positions are packed)
+	lines[logical_line_unit(gd, lrel, layout)] = o;
+}
+
+// Level-0 records: copy the position fields of the keys a record ranks from `positions` into the record (index_device.h).  One lane
+// per logical line of the pass (the deeper-level lines leave at once); runs behind k_pack_positions of the same groups.
+__global__ void k_record_positions(const GroupDesc* __restrict__ groups, const uint64_t* __restrict__ line_base, uint32_t ngroups, uint64_t L0, uint64_t nlines,
+                                   const uint64_t* __restrict__ positions, uint4* __restrict__ lines)
+{
+	const uint64_t L = L0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (L >= nlines)
+		return;
+	const uint32_t g = group_of_line(line_base, ngroups, L);
+	const GroupDesc* gd = &groups[g];
+	const uint64_t lrel = L - line_base[g];
+	if (lrel >= (gd->size[0] >> 5))
+		return;
+	uint32_t* recp = reinterpret_cast<uint32_t*>(lines + gd->line_base + (lrel >> 1) * kBlockUnits + (lrel & 1) * 4);
+	const uint32_t rank = recp[0], nset = (uint32_t)__popc(recp[1]), nbits = gd->nbits;
+	const uint32_t nf = min(nset, rec_fields(nbits));
+	uint32_t w[kRecPosBits / 32];
+	for (int i = 0; i < kRecPosBits / 32; i++)
+		w[i] = 0;
+	for (uint32_t j = 0; j < nf; j++) {
+		const uint64_t f = read_position_field(positions, gd->posstart, nbits, (uint64_t)rank + j);
+		const uint32_t o = j * nbits, wi = o >> 5, sh = o & 31u;
+		const uint64_t v = f << sh;
+		for (int i = 0; i < kRecPosBits / 32; i++) {  // (constant indices: w stays in registers)
+			if ((uint32_t)i == wi)
+				w[i] |= (uint32_t)v;
+			if ((uint32_t)i == wi + 1)
+				w[i] |= (uint32_t)(v >> 32);
+		}
+	}
+	for (int i = 0; i < kRecPosBits / 32; i++)
+		recp[kRecPosWord + i] = w[i];
 }
 
 // total set bits per group (= first fallback rank, bbhash.h:554)
@@ -1805,7 +1844,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	uint32_t largest_bucket = 0;
 	// physical position fields: the reference's nbits plus `hint` low bits (the sub-window of the key inside its 2^b window), when
 	// every group's field still fits 32 bits; the reference's own offsets (total_pos) are kept for the counters and the export
-	uint32_t hint = (ix.tune_pos_hint && b <= 8) ? (uint32_t)position_hint_bits(b) : 0u;
+	uint32_t hint = (ix.tune_pos_hint && b <= 8 && (b >= 7 || ix.tune_pos_hint == 2)) ? (uint32_t)position_hint_bits(b) : 0u;
 	for (uint32_t g = 0; g < ngroups && hint; g++)
 		if ((int)(ceil(log2((double)(uint32_t)(h_gmax[g] + 1))) - (double)b) + (int)hint > 32)
 			hint = 0;
@@ -1817,6 +1856,13 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	const uint32_t bpk = ix.tune_filter_bits < 0 ? (hint ? 16u : 8u) : (uint32_t)std::min(ix.tune_filter_bits, 32);
 	const bool fat = bpk == 8 && ix.tune_fat_lines != 0;
 	ix.fat_lines = fat;
+	// ... as level-0 RECORDS (32 level bits + filter + the position fields of their keys: 64 B per 16 keys instead of per 48) only when
+	// asked for (fat_lines = 2): a level-0 key's position then comes with its rank, but the records of a human-scale index are 10 GB
+	// instead of 3.3, a batch touches every line of them, and the slot kernel pays per line: all-indexed batches 4 % faster, 50/50
+	// batches 8 % slower, all-absent ones 8 % slower (profiles/r04_exp_level0_layouts_c4.txt)
+	const bool rec = fat && ix.tune_fat_lines == 2;
+	ix.rec_lines = rec;
+	const int layout = rec ? 2 : (fat ? 1 : 0);
 	uint64_t ubase = 0;  // 16-B units of the line array (lbase below counts logical lines)
 	for (uint32_t g = 0; g < ngroups; g++) {
 		GroupDesc& gd = ix.h_groups[g];
@@ -1844,9 +1890,12 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 				throw StatusError{BLMX_ELIMIT, "an MPHF group holds more than 2^37 level bits"};
 			wbase += gd.nwords;
 			if (fat) {
-				const uint64_t F = ((gd.size[0] >> 5) + kLineData32 - 1) / kLineData32, T = (2 * gd.nwords - (gd.size[0] >> 5) + kLineData32 - 1) / kLineData32;
+				// (the level-0 units in cross-paired 128-B blocks: the group's lines start on a multiple of eight 16-B units)
+				const uint64_t F = level0_units64(gd.size[0], rec), T = (2 * gd.nwords - (gd.size[0] >> 5) + kLineData32 - 1) / kLineData32;
+				ubase = (ubase + kBlockUnits - 1) / kBlockUnits * kBlockUnits;
+				gd.line_base = ubase;
 				lbase += F + T;
-				ubase += 4 * F + T;
+				ubase += level0_block_units(gd.size[0], rec) + T;
 			} else {
 				const uint64_t L = (2 * gd.nwords + kLineData32 - 1) / kLineData32;
 				lbase += L;
@@ -1876,7 +1925,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 
 	mark("host descriptors");
 	// ---- K5: packed bucket sequence.  Padding: the 2^b scan may read NW words past the last k-mer (blight.cpp:738)
-	const uint64_t pad_words = ((1ull << std::min(b, 20)) + 64 * (uint64_t)KW + 64) / 32 + 4;
+	const uint64_t pad_words = ((1ull << std::min(b, 20)) + 64 * (uint64_t)KW + 64) / 32 + 4 + 16;  // (+ 128 B: whole-line reads, index_device.h)
 	ix.seq_words = total_nt / 32 + pad_words;
 	BLMX_HIP(ix.seq.alloc(ix.seq_words * 8, true, s));
 	if (nsk)
@@ -1948,7 +1997,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	BLMX_HIP(d_gpopc.alloc(((size_t)ngroups + 1) * 8, true, s));
 	BLMX_HIP(d_gfbstart.alloc((size_t)ngroups * 8, true, s));
 	BLMX_HIP(d_gfbcount.alloc((size_t)ngroups * 4, true, s));
-	BLMX_HIP(ix.lines.alloc((total_units + 1) * kLineBytes, true, s));
+	BLMX_HIP(ix.lines.alloc((total_units + 1 + kBlockUnits) * kLineBytes, true, s));
 	std::vector<uint8_t> h_small(ngroups, 0);  // 1 = one workgroup builds all levels in LDS, 2 = one workgroup per (level, slice), 0 = global kernels
 	uint64_t n_small = 0, n_sliced = 0;
 	const char* lds_env = getenv("BLIGHT_BUILD_NO_LDS");  // test hook: 1 = global level kernels for every group, 2 = for the groups above the
@@ -1975,7 +2024,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			ix.h_groups[g].prefix += id_base;
 	BLMX_HIP(ix.groups.alloc((size_t)ngroups * sizeof(GroupDesc), false, s));
 	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
-	ix.positions_words = phys_pos / 64 + 3;
+	ix.positions_words = phys_pos / 64 + 3 + 16;  // (+ 128 B: whole-line reads, index_device.h)
 	BLMX_HIP(ix.positions.alloc(ix.positions_words * 8, true, s));
 	ix.st.total_nt = total_nt;
 	// absent-key filter: a separate array (filter_bits per key), or -- fat lines -- the six words behind every level-0 line
@@ -2210,12 +2259,12 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		// ---- K8: collisions cleared + ranks -> lines [u32 rank | 96 bits] of this pass's groups
 		const uint64_t L0 = h_line_base[g0], L1 = h_line_base[g1];
 		hipLaunchKernelGGL(k_line_popc, dim3(grid_for(L1 - L0 + 1)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(), ngroups, L0, L1,
-		                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>(), fat);
+		                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepc.as<uint64_t>(), layout);
 		BLMX_HIP(hipGetLastError());
 		exclusive_scan_u64(sc, d_linepc.as<uint64_t>(), d_linepre.as<uint64_t>(), L1 - L0 + 1, s);
 		if (L1 > L0)
 			hipLaunchKernelGGL(k_line_write, dim3(grid_for(L1 - L0)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(), ngroups, L0, L1,
-			                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepre.as<uint64_t>(), ix.lines.as<uint4>(), fat);
+			                   d_bits.as<unsigned long long>(), d_coll.as<unsigned long long>(), d_linepre.as<uint64_t>(), ix.lines.as<uint4>(), layout);
 		hipLaunchKernelGGL(k_group_popc, dim3(grid_for(g1 - g0)), dim3(kBlock), 0, s, d_line_base.as<uint64_t>(), d_linepre.as<uint64_t>(), g0, g1, L0,
 		                   d_gpopc.as<uint64_t>());
 		BLMX_HIP(hipGetLastError());
@@ -2311,6 +2360,9 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 			                   field_p);
 		hipLaunchKernelGGL(k_pack_positions, dim3(g1 - g0), dim3(kPackThreads), 0, s, ix.groups.as<GroupDesc>(), g0, id_base, field_p,
 		                   ix.positions.as<unsigned long long>());
+		if (rec && L1 > L0)  // level-0 records: the fields of the keys they rank, next to the rank
+			hipLaunchKernelGGL(k_record_positions, dim3(grid_for(L1 - L0)), dim3(kBlock), 0, s, d_bgroups.as<GroupDesc>(), d_line_base.as<uint64_t>(), ngroups, L0, L1,
+			                   ix.positions.as<uint64_t>(), ix.lines.as<uint4>());
 		BLMX_HIP(hipGetLastError());
 		BLMX_HIP(hipStreamSynchronize(s));  // the pass's temporaries go out of scope
 		F += Fp;

@@ -72,6 +72,7 @@ struct DeviceIndexView {
 	uint64_t id_base;     // ID of the first key this index holds (0 unless sharded): group regions of the filter follow local IDs
 	uint32_t filter_bpk;  // filter bits per key
 	bool fat;             // level-0 lines are 64 B and carry the filter (index_device.h); `filter` is then only a flag (non-null = consult it)
+	bool rec;             // (implies fat) the 64-B level-0 units are RECORDS of 32 level bits that also carry their keys' position fields
 	// one word: 1 = consult the filter, 0 = skip it (the last large batch had almost no absent k-mers: the filter would only cost its
 	// load; k_gate_sample decides after every large batch).  nullptr = always use.
 	uint32_t* filter_gate;
@@ -383,6 +384,7 @@ struct Index {
 	uint64_t filter_words = 0;
 	uint32_t filter_bpk = 0;   // bits per key the filter was built with (0 = none)
 	bool fat_lines = false;    // level-0 lines carry the filter (64-B lines; no separate filter array)
+	bool rec_lines = false;    // ... as records of 32 level bits with the position fields of their keys (index_device.h); implies fat_lines
 	// The filter's passes (k_filter_keys: every key; k_filter_junctions: the few non-keys the reference's scan can find) run on their
 	// own stream AFTER the build has returned, and a helper thread waits for it, gives the build's temporaries back to the driver (hipFree waits for the
 	// device, so the build itself must not do it) and arms the filter.  0 = pass pending, 2 = filter usable.
@@ -448,6 +450,32 @@ struct Index {
 	DevBuf q_in, q_aux, q_out;
 	// scratch of the locality-binned batch query (grow-only; guarded by bin_mu)
 	DevBuf b_bins, b_minis, b_sorted, b_inv, b_ids, b_hist, b_offs, b_tmp, b_plan, b_frac, b_pstats;
+	// k-mers a partition pass could not place (k_bin_onepass: cannot happen -- the overflow region holds a whole batch -- but a k-mer
+	// without a slot would come back as "absent", so it is counted): a word in pinned host memory the device adds to, looked at by
+	// every later call on this index.  test_ovf_cap (test hook) shrinks the overflow region to provoke it.
+	unsigned long long* h_dropped = nullptr;
+	int tune_test_ovf_cap = 0;
+	unsigned long long* dropped_word()
+	{
+		if (!h_dropped) {
+			if (hipHostMalloc(reinterpret_cast<void**>(&h_dropped), 64, hipHostMallocDefault) != hipSuccess) {
+				h_dropped = nullptr;
+				(void)hipGetLastError();
+			} else
+				*h_dropped = 0;
+		}
+		return h_dropped;
+	}
+	void check_dropped()
+	{
+		if (h_dropped) {
+			const unsigned long long n = __atomic_load_n(h_dropped, __ATOMIC_RELAXED);
+			if (n) {
+				__atomic_store_n(h_dropped, 0ull, __ATOMIC_RELAXED);
+				throw StatusError{BLMX_EHIP, "internal: " + std::to_string(n) + " k-mers of an earlier batch found no slot in the partition (their answers were -1)"};
+			}
+		}
+	}
 	int plan_bits = -1;  // bin count (log2) the learnt shares in b_frac belong to, -1 = nothing learnt yet
 	uint32_t plan_nbins_sharded = 0;  // the same for the sharded exchange (bins split at the shard boundaries): bins of b_frac_sharded
 	DevBuf b_frac_sharded, b_foreign;  // b_foreign: workgroup layout of the owner's slot kernel (k_foreign_plan)
@@ -479,7 +507,9 @@ struct Index {
 	int tune_filter_bits = -1;   // bits per key of the filter built at construction (0 = build none, -1 = automatic: 8, or 16 with the
 	                             // position hint of the wide windows; BLIGHT_FILTER_BITS)
 	int tune_window_kb = 0;      // characters per front-end window in KiB (0 = default: 32 MiB)
-	int tune_fat_lines = 1;      // build: with 8 filter bits per key the filter lives inside 64-B level-0 lines (0 = separate filter array, 16-B lines)
+	int tune_fat_lines = -1;     // build: with 8 filter bits per key the filter lives inside 64-B level-0 units: 0 = separate filter array and 16-B
+	                             // lines, 1 = fat lines (96 level bits + filter), 2 = records (32 level bits + filter + position fields),
+	                             // -1 = automatic = fat lines (records measured slower on a 50/50 batch, profiles/r04_exp_level0_layouts_c4.txt)
 	int tune_build_passes = 0;   // build: passes over ranges of MPHF groups (0 = automatic: at most 2^log2_superbuckets, <= 2^30 keys per pass)
 	int tune_slot_piece_min = 0; // sharded exchange: pieces of at least this many k-mers travel as bin regions (0 = default 2^19; tests lower it)
 
@@ -525,6 +555,7 @@ struct Index {
 		v.fb_ranks = fb_ranks.as<uint64_t>();
 		v.total_nt = st.total_nt;
 		v.fat = fat_lines;
+		v.rec = rec_lines;
 		v.filter = (filter_bpk && tune_absent_filter && filter_usable()) ? (fat_lines ? lines.as<uint64_t>() : filter.as<uint64_t>()) : nullptr;
 		v.filter_bpk = filter_bpk;
 		v.filter_gate = (v.filter && tune_filter_gate) ? filter_gate.as<uint32_t>() : nullptr;

@@ -575,31 +575,43 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const uint64_t* __r
 // device); the first batch of an index goes through the exact partition and leaves its shares behind.  A batch distributed unlike
 // its predecessor (tests: a few k-mers repeated a thousand times after a uniform batch) only loses locality for what overflows.
 // C4: 1.63 ms for this pass instead of 0.92 + 0.04 + 0.86, and 1024 bins become affordable.
+// The one-pass kernels hold up to 2^kBinBitsSlots bins: BPT bins per thread of their 1024-thread workgroups (BPT = 1: up to 1024 bins,
+// the sharded exchange and 128-bit k-mers; BPT = 2: 2048 bins for 64-bit k-mers, r04 -- a bin's slice of a human-scale index is then
+// 5 MB instead of 10 against the 4 MB of the XCD's L2 that serves it, and the slot kernel is bound by the requests its L2 misses send
+// to the fabric).
+constexpr int kBinBitsSlots = 11;
 struct SlotPlan {            // lives in HBM (written by k_plan_make, read by the slot kernels): no host round trip per batch
 	uint32_t nbins;
 	uint32_t main_slots;     // slots of all bin regions, rounded up to a multiple of 2048 (8 XCDs x 256-slot blocks)
 	uint32_t ovf_cap;        // slots of the overflow region behind them
 	uint32_t ovf_blocks;     // looping blocks that answer the overflow region
-	uint32_t base[(1 << kBinBitsMax) + 1];  // first slot of every bin region (multiples of 256); base[nbins] = end of the last one
+	uint32_t base[(1 << kBinBitsSlots) + 1];  // first slot of every bin region (multiples of 256); base[nbins] = end of the last one
 	__device__ uint64_t ovf_base() const { return main_slots; }
 	__device__ uint64_t total_slots() const { return (uint64_t)main_slots + ovf_cap; }
 };
 
 // Capacities of the bin regions for a batch of nq k-mers: the share every bin had of the PREVIOUS batch (frac, learnt by k_plan_learn*)
 // plus slack_pct percent plus one block, or equal shares when nothing has been learnt.  One workgroup, one thread per bin.
+template <int BPT>
 __global__ __launch_bounds__(1 << kBinBitsMax) void k_plan_make(const float* __restrict__ frac, uint64_t nq, uint32_t nbins, uint32_t slack_pct,
                                                               uint32_t max_main_slots, uint32_t ovf_cap, uint32_t ovf_blocks, SlotPlan* __restrict__ sp,
                                                               uint32_t* __restrict__ cursors)
 {
 	__shared__ uint32_t s_wsum[(1 << kBinBitsMax) / 64];
 	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-	uint32_t cap = 0;
-	if (t < nbins) {
-		const double share = frac ? (double)frac[t] * (double)nq : (double)nq / (double)nbins;
-		const double want = share * (100.0 + (double)slack_pct) / 100.0 + 256.0;
-		cap = (uint32_t)(((uint64_t)want + 255u) & ~255ull);
+	uint32_t cap[BPT], mine = 0;
+#pragma unroll
+	for (int j = 0; j < BPT; j++) {
+		const uint32_t b = t * BPT + j;
+		cap[j] = 0;
+		if (b < nbins) {
+			const double share = frac ? (double)frac[b] * (double)nq : (double)nq / (double)nbins;
+			const double want = share * (100.0 + (double)slack_pct) / 100.0 + 256.0;
+			cap[j] = (uint32_t)(((uint64_t)want + 255u) & ~255ull);
+		}
+		mine += cap[j];
 	}
-	uint32_t v = cap;
+	uint32_t v = mine;
 	for (int o = 1; o < 64; o <<= 1) {
 		const uint32_t u = __shfl_up(v, o);
 		if ((int)lane >= o)
@@ -611,37 +623,51 @@ __global__ __launch_bounds__(1 << kBinBitsMax) void k_plan_make(const float* __r
 	uint32_t wbase = 0;
 	for (uint32_t w = 0; w < wave; w++)
 		wbase += s_wsum[w];
-	uint32_t start = wbase + v - cap;
-	start = min(start, max_main_slots);  // what does not fit the region goes to the overflow slots
-	const uint32_t end = min(start + cap, max_main_slots);
-	if (t < nbins)
-		sp->base[t] = start;
-	if (t + 1 == nbins) {
-		sp->base[nbins] = end;
-		sp->nbins = nbins;
-		sp->main_slots = (end + 2047u) & ~2047u;  // <= max_main_slots, itself a multiple of 2048
-		sp->ovf_cap = ovf_cap;
-		sp->ovf_blocks = ovf_blocks;
+	uint32_t at = wbase + v - mine;
+#pragma unroll
+	for (int j = 0; j < BPT; j++) {
+		const uint32_t b = t * BPT + j;
+		const uint32_t start = min(at, max_main_slots);  // what does not fit the region goes to the overflow slots
+		const uint32_t end = min(start + cap[j], max_main_slots);
+		if (b < nbins) {
+			sp->base[b] = start;
+			cursors[b] = 0;
+		}
+		if (b + 1 == nbins) {
+			sp->base[nbins] = end;
+			sp->nbins = nbins;
+			sp->main_slots = (end + 2047u) & ~2047u;  // <= max_main_slots, itself a multiple of 2048
+			sp->ovf_cap = ovf_cap;
+			sp->ovf_blocks = ovf_blocks;
+		}
+		at += cap[j];
 	}
-	if (t < nbins)
-		cursors[t] = 0;
-	if (t == 0)
-		cursors[nbins] = 0;  // the overflow cursor (with 1024 bins there is no thread number nbins)
+	if (t == 0) {
+		cursors[nbins] = 0;      // the overflow cursor
+		cursors[nbins + 1] = 0;  // k-mers that found no slot (must stay 0)
+	}
 }
 // what the capacities of the next batch are made from: this batch's k-mers per bin
 // stats (may be null): [0] one-pass batches, [1] their k-mers, [2] k-mers that went through the overflow region, [3] the largest
 // overflow of a batch -- what blmx_partition_stats reports (a learnt plan applied to a batch it was not learnt from overflows a little)
-__global__ void k_plan_learn(const uint32_t* __restrict__ cursors, uint64_t nq, uint32_t nbins, float* __restrict__ frac, unsigned long long* __restrict__ stats)
+// [4] k-mers that found no slot at all (the overflow region holds a whole batch: always 0 unless the partition is broken); those also
+// go to `dropped_host`, a word in pinned host memory that every later call on the index looks at (Index::check_dropped): a k-mer
+// without a slot would otherwise come back as "absent"
+__global__ void k_plan_learn(const uint32_t* __restrict__ cursors, uint64_t nq, uint32_t nbins, float* __restrict__ frac, unsigned long long* __restrict__ stats,
+                             unsigned long long* __restrict__ dropped_host)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t < nbins && nq)
 		frac[t] = (float)((double)cursors[t] / (double)nq);
 	if (t == 0 && stats) {
-		const unsigned long long ovf = cursors[nbins];
+		const unsigned long long ovf = cursors[nbins], dropped = cursors[nbins + 1];
 		stats[0] += 1;
 		stats[1] += nq;
 		stats[2] += ovf;
 		stats[3] = max(stats[3], ovf);
+		stats[4] += dropped;
+		if (dropped && dropped_host)
+			atomicAdd_system(dropped_host, dropped);
 	}
 }
 __global__ void k_plan_learn_offs(const uint32_t* __restrict__ offs, uint32_t nblk, uint64_t nq, uint32_t nbins, float* __restrict__ frac)
@@ -662,7 +688,7 @@ struct RunTable {
 	uint32_t* count;
 };
 
-template <int KW>
+template <int KW, int BPT>
 __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, const SlotPlan* __restrict__ sp, const uint64_t* __restrict__ kmers,
                                                              const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
                                                              uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint16_t* __restrict__ lpos,
@@ -670,30 +696,38 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 {
 	constexpr int kTile = BinTile<KW>::value;
 	constexpr int kPer = kTile / kBinThreads;
-	constexpr int kNB = 1 << kBinBitsMax;
+	constexpr int kNB = BPT << kBinBitsMax;  // BPT bins per thread
 	__shared__ uint64_t s_keys[kTile * KW];
 	__shared__ uint32_t s_mini[kTile];
-	__shared__ uint32_t s_cnt[kNB];     // k-mers of this tile per bin, then the tile-local start of the bin
+	__shared__ uint32_t s_cnt2[2][kNB];  // k-mers of this tile per bin, then the tile-local start of the bin; tiles alternate between the two
 	__shared__ uint32_t s_gbase[kNB];   // first slot (inside the bin) of this tile's run
 	__shared__ uint32_t s_obase[kNB];   // first overflow slot of the part of the run that does not fit the bin
 	__shared__ uint32_t s_rbase[kNB];   // the bin's region: first slot ...
 	__shared__ uint32_t s_rcap[kNB];    // ... and slots
 	__shared__ uint32_t s_wsum[kBinThreads / 64];
-	static_assert(kBinThreads == kNB, "one bin per thread");
+	static_assert(kBinThreads == (1 << kBinBitsMax), "BPT bins per thread");
 	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	{
 		const uint32_t nb = sp->nbins;
-		const uint32_t rb = t < nb ? sp->base[t] : 0u;
-		s_rbase[t] = rb;
-		s_rcap[t] = t < nb ? sp->base[t + 1] - rb : 0u;
+#pragma unroll
+		for (int j = 0; j < BPT; j++) {
+			const uint32_t b = t * BPT + j;
+			const uint32_t rb = b < nb ? sp->base[b] : 0u;
+			s_rbase[b] = rb;
+			s_rcap[b] = b < nb ? sp->base[b + 1] - rb : 0u;
+			s_cnt2[0][b] = 0;
+		}
 	}
 	const uint32_t ovf_at = sp->main_slots, all_slots = sp->main_slots + sp->ovf_cap, nbins_p = sp->nbins;
 	// A workgroup walks over tiles (grid = one workgroup per CU, or one per tile): the stores of one tile drain while the minimizers
 	// of the next are computed, the region table is loaded once, and there is no dispatch gap between tiles on a CU whose LDS holds
-	// only one of these workgroups.
-	for (uint64_t tile = blockIdx.x; tile * kTile < nq; tile += gridDim.x) {
-	s_cnt[t] = 0;
+	// only one of these workgroups.  r04: the counters are double-buffered, so that no barrier separates the copy-out of tile t from
+	// the minimizer phase of tile t + 1 (a wave that has issued its stores goes on hashing; 6 -> 4 barriers per tile): the barrier
+	// behind the minimizer phase of t + 1 is the one that says "tile t has been read".
 	__syncthreads();
+	uint32_t par = 0;
+	for (uint64_t tile = blockIdx.x; tile * kTile < nq; tile += gridDim.x, par ^= 1u) {
+	uint32_t* const s_cnt = s_cnt2[par];
 	const uint64_t base = tile * kTile;
 	Kmer<KW> x[kPer];
 	uint32_t mini[kPer], rank[kPer];
@@ -709,10 +743,15 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		}
 	}
 	__syncthreads();
-	// one thread per bin: tile-local exclusive scan of the counts, slot reservation in the bin and in the overflow region
+	// BPT bins per thread: tile-local exclusive scan of the counts, slot reservation in the bin and in the overflow region
 	{
-		const uint32_t c = s_cnt[t];
-		uint32_t v = c;
+		uint32_t c[BPT], mine = 0;
+#pragma unroll
+		for (int j = 0; j < BPT; j++) {
+			c[j] = s_cnt[t * BPT + j];
+			mine += c[j];
+		}
+		uint32_t v = mine;
 		for (int o = 1; o < 64; o <<= 1) {
 			const uint32_t u = __shfl_up(v, o);
 			if ((int)lane >= o)
@@ -720,27 +759,35 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		}
 		if (lane == 63)
 			s_wsum[wave] = v;
-		uint32_t g = 0, ob = 0;
-		if (c) {
-			const uint32_t capb = s_rcap[t];
-			g = atomicAdd(&cursors[t], c);
-			const uint32_t over = g + c > capb ? g + c - max(g, capb) : 0u;
-			if (over)
-				ob = atomicAdd(&cursors[nbins_p], over);
-		}
-		s_gbase[t] = g;
-		s_obase[t] = ob;
-		{
-			const size_t ri = (size_t)tile * kNB + t;
+#pragma unroll
+		for (int j = 0; j < BPT; j++) {
+			const uint32_t b = t * BPT + j;
+			uint32_t g = 0, ob = 0;
+			if (c[j]) {
+				const uint32_t capb = s_rcap[b];
+				g = atomicAdd(&cursors[b], c[j]);
+				const uint32_t over = g + c[j] > capb ? g + c[j] - max(g, capb) : 0u;
+				if (over)
+					ob = atomicAdd(&cursors[nbins_p], over);
+			}
+			s_gbase[b] = g;
+			s_obase[b] = ob;
+			s_cnt2[par ^ 1u][b] = 0;  // the next tile's counters (last read by the copy-out of the tile before this one)
+			const size_t ri = (size_t)tile * kNB + b;
 			rt.gbase[ri] = g;
 			rt.obase[ri] = ob;
-			rt.count[ri] = c;
+			rt.count[ri] = c[j];
 		}
 		__syncthreads();
 		uint32_t wbase = 0;
 		for (uint32_t w = 0; w < wave; w++)
 			wbase += s_wsum[w];
-		s_cnt[t] = wbase + v - c;  // tile-local start of bin t
+		uint32_t at = wbase + v - mine;  // tile-local start of this thread's first bin
+#pragma unroll
+		for (int j = 0; j < BPT; j++) {
+			s_cnt[t * BPT + j] = at;
+			at += c[j];
+		}
 	}
 	__syncthreads();
 	auto slot_of = [&](uint32_t b, uint32_t r) -> uint64_t {  // r-th k-mer of this tile's run of bin b
@@ -765,12 +812,15 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	}
 	__syncthreads();
 	const uint32_t count = (uint32_t)min((uint64_t)kTile, nq - base);
+	uint32_t dropped = 0;
 	for (uint32_t sidx = t; sidx < count; sidx += kBinThreads) {
 		const uint32_t mi = s_mini[sidx];
 		const uint32_t b = bm.bin_of(mi);
 		const uint64_t dst = slot_of(b, sidx - s_cnt[b]);
-		if (dst >= all_slots)
-			continue;  // cannot happen: the overflow region holds a whole batch
+		if (dst >= all_slots) {  // cannot happen (the overflow region holds a whole batch) -- but if it ever does it must not pass for an
+			dropped++;           // absent k-mer: counted, and the call fails (k_plan_learn -> Index::check_dropped)
+			continue;
+		}
 		if (slot_minis)
 			slot_minis[dst] = mi;
 		if constexpr (KW == 1) {
@@ -780,7 +830,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 			slots[2 * dst + 1] = s_keys[2 * sidx + 1];
 		}
 	}
-	__syncthreads();  // the staged tile has been read: the next one may overwrite it
+	if (dropped)
+		atomicAdd(&cursors[nbins_p + 1], dropped);
 	}
 }
 
@@ -790,16 +841,20 @@ template <int KW, int LOGP>
 __device__ __forceinline__ void query_slot(const DeviceIndexView& v, const uint64_t* __restrict__ slots, const uint32_t* __restrict__ slot_minis,
                                            void* __restrict__ ids, bool narrow, uint64_t slot)
 {
-	const Kmer<KW> x = load_kmer<KW>(slots, slot);
+	Kmer<KW> x;
+	if constexpr (KW == 1 && (BLMX_EXP_NT & 1))
+		x.lo = exp_load<0>(&slots[slot]);
+	else
+		x = load_kmer<KW>(slots, slot);
 	const Kmer<KW> xr = kmer_rc<KW>(x, v.k);
-	const uint32_t mini = slot_minis ? slot_minis[slot] : kmer_minimizer<KW>(x, xr, v.k, v.m);
+	const uint32_t mini = slot_minis ? exp_load<0>(&slot_minis[slot]) : kmer_minimizer<KW>(x, xr, v.k, v.m);
 	int64_t id;
 	int32_t posj;
 	query_one<KW, LOGP, false>(v, x, xr, mini, id, posj);
 	if (narrow)
-		reinterpret_cast<uint32_t*>(ids)[slot] = (uint32_t)id;
+		exp_store<3>(&reinterpret_cast<uint32_t*>(ids)[slot], (uint32_t)id);
 	else
-		reinterpret_cast<int64_t*>(ids)[slot] = id;
+		exp_store<3>(&reinterpret_cast<int64_t*>(ids)[slot], id);
 }
 // the grid covers the largest region the plan may describe; workgroups behind the actual one leave at once
 template <int KW, int LOGP>
@@ -883,24 +938,28 @@ __global__ __launch_bounds__(kBinThreads) void k_gather_ids(const void* __restri
 // the slot of every tile-local sorted position (LDS), the lanes then fetch the IDs of CONSECUTIVE sorted positions -- consecutive
 // slots inside a run: 64 lanes touch ~8 lines instead of 64 -- into LDS, and out[i] = ids_tile[lpos[i]] goes out fully coalesced.
 // (k_gather_ids chased a 4-B slot number per query with one random 4-B load per lane: 0.76 ms per 1e8 at C4, request-bound.)
-template <int TILE, bool NARROW>
+template <int TILE, bool NARROW, int BPT>
 __global__ __launch_bounds__(kBinThreads) void k_gather_runs(const SlotPlan* __restrict__ sp, RunTable rt, const uint16_t* __restrict__ lpos,
                                                              const void* __restrict__ ids, uint64_t nq, int64_t* __restrict__ out)
 {
-	constexpr int kNB = 1 << kBinBitsMax;
+	constexpr int kNB = BPT << kBinBitsMax;
 	constexpr int kPer = TILE / kBinThreads;
 	__shared__ uint32_t s_slot[TILE];  // slot of every sorted position, then (NARROW) its ID
 	__shared__ uint32_t s_hi[NARROW ? 1 : TILE];
 	__shared__ uint32_t s_wsum[kBinThreads / 64];
-	static_assert(kBinThreads == kNB, "one bin per thread");
 	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const uint64_t base = (uint64_t)blockIdx.x * TILE;
 	const uint32_t count = (uint32_t)min((uint64_t)TILE, nq - base);
 	const uint32_t nb = sp->nbins, ovf_at = sp->main_slots, all_slots = sp->main_slots + sp->ovf_cap;
-	// tile-local start of every bin's run
-	const size_t ri = (size_t)blockIdx.x * kNB + t;
-	const uint32_t c = t < nb ? rt.count[ri] : 0u;
-	uint32_t v = c;
+	// tile-local start of every bin's run (BPT bins per thread)
+	uint32_t c[BPT], mine = 0;
+#pragma unroll
+	for (int j = 0; j < BPT; j++) {
+		const uint32_t b = t * BPT + j;
+		c[j] = b < nb ? rt.count[(size_t)blockIdx.x * kNB + b] : 0u;
+		mine += c[j];
+	}
+	uint32_t v = mine;
 	for (int o = 1; o < 64; o <<= 1) {
 		const uint32_t u = __shfl_up(v, o);
 		if ((int)lane >= o)
@@ -912,14 +971,20 @@ __global__ __launch_bounds__(kBinThreads) void k_gather_runs(const SlotPlan* __r
 	uint32_t wbase = 0;
 	for (uint32_t w = 0; w < wave; w++)
 		wbase += s_wsum[w];
-	const uint32_t lstart = wbase + v - c;
-	if (c) {
-		const uint32_t g = rt.gbase[ri], ob = rt.obase[ri], rb = sp->base[t], capb = sp->base[t + 1] - rb;
-		for (uint32_t r = 0; r < c; r++) {
-			const uint32_t gs = g + r;
-			const uint64_t sl = gs < capb ? (uint64_t)rb + gs : (uint64_t)ovf_at + ob + (gs - max(g, capb));
-			s_slot[lstart + r] = sl < all_slots ? (uint32_t)sl : 0xffffffffu;
+	uint32_t lstart = wbase + v - mine;
+#pragma unroll
+	for (int j = 0; j < BPT; j++) {
+		const uint32_t b = t * BPT + j;
+		if (c[j]) {
+			const size_t ri = (size_t)blockIdx.x * kNB + b;
+			const uint32_t g = rt.gbase[ri], ob = rt.obase[ri], rb = sp->base[b], capb = sp->base[b + 1] - rb;
+			for (uint32_t r = 0; r < c[j]; r++) {
+				const uint32_t gs = g + r;
+				const uint64_t sl = gs < capb ? (uint64_t)rb + gs : (uint64_t)ovf_at + ob + (gs - max(g, capb));
+				s_slot[lstart + r] = sl < all_slots ? (uint32_t)sl : 0xffffffffu;
+			}
 		}
+		lstart += c[j];
 	}
 	__syncthreads();
 	for (uint32_t sidx = t; sidx < count; sidx += kBinThreads) {
@@ -1143,10 +1208,14 @@ static uint32_t onepass_grid(uint32_t nblk)
 // region, and with the histogram pass gone the query kernel's gain from finer bins (3.9 -> 3.5 ms at C4) is no longer eaten by the
 // passes around it (C4: 6.14 -> 5.73 ms per step)
 constexpr int kBinBitsOnepass = 10;
+// 2048 bins (bin_bits = 11, 64-bit k-mers, two bins per thread in the one-pass kernels; r04) are there to be asked for: measured at C4
+// the slot kernel gains 2.5 % (3.35 -> 3.26 ms) and the passes around it lose more (partition 1.41 -> 1.58, gather 0.47 -> 0.56 ms: runs
+// of four k-mers), profiles/r04_exp_2048_bins_c4.txt.
 static int onepass_bits(const Index& ix)
 {
 	const int mbits = 2 * (int)ix.prm.m - 1;
-	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, kBinBitsMax) : kBinBitsOnepass;
+	const int most = ix.KW == 1 ? kBinBitsSlots : kBinBitsMax;
+	const int want_bits = ix.tune_bin_bits > 0 ? std::min(ix.tune_bin_bits, most) : kBinBitsOnepass;
 	return std::max(3, std::min(mbits, want_bits));
 }
 
@@ -1173,7 +1242,8 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
 	ensure_buf(ix.b_sorted, slots * 8 * (size_t)ix.KW, s);
 	// lpos (2 B per query) followed by the run table (3 x 4 B per (tile, bin))
-	const size_t lpos_bytes = (nq * 2 + 255) & ~(size_t)255, runs = (size_t)nblk << kBinBitsMax;
+	const int bpt = tbits > kBinBitsMax ? 2 : 1;  // bins per thread of the one-pass kernels
+	const size_t lpos_bytes = (nq * 2 + 255) & ~(size_t)255, runs = ((size_t)nblk << kBinBitsMax) * bpt;
 	ensure_buf(ix.b_inv, lpos_bytes + runs * 12, s);
 	uint16_t* d_lpos = ix.b_inv.as<uint16_t>();
 	RunTable rt;
@@ -1181,27 +1251,38 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	rt.obase = rt.gbase + runs;
 	rt.count = rt.obase + runs;
 	ensure_buf(ix.b_ids, slots * 8, s);
-	ensure_buf(ix.b_offs, ((size_t)nbins + 1) * 4, s);
+	ensure_buf(ix.b_offs, ((size_t)nbins + 2) * 4, s);
 	ensure_buf(ix.b_plan, sizeof(SlotPlan), s);
-	ensure_buf(ix.b_frac, sizeof(float) << kBinBitsMax, s);
+	ensure_buf(ix.b_frac, sizeof(float) << kBinBitsSlots, s);
 	if (handoff)
 		ensure_buf(ix.b_minis, slots * 4, s);
 	uint32_t* d_slot_minis = handoff ? ix.b_minis.as<uint32_t>() : nullptr;
 	uint32_t* d_cursors = ix.b_offs.as<uint32_t>();
 	const SlotPlan* d_plan = ix.b_plan.as<SlotPlan>();
 	const uint32_t ovf_blocks = 1024;
-	hipLaunchKernelGGL(k_plan_make, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac.as<float>() : nullptr, nq, nbins, pct, (uint32_t)max_main,
-	                   (uint32_t)nq, ovf_blocks, ix.b_plan.as<SlotPlan>(), d_cursors);
+	const uint32_t ovf_cap = ix.tune_test_ovf_cap > 0 ? std::min<uint32_t>((uint32_t)ix.tune_test_ovf_cap, (uint32_t)nq) : (uint32_t)nq;
+	if (bpt == 2)
+		hipLaunchKernelGGL(k_plan_make<2>, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac.as<float>() : nullptr, nq, nbins, pct, (uint32_t)max_main,
+		                   ovf_cap, ovf_blocks, ix.b_plan.as<SlotPlan>(), d_cursors);
+	else
+		hipLaunchKernelGGL(k_plan_make<1>, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac.as<float>() : nullptr, nq, nbins, pct, (uint32_t)max_main,
+		                   ovf_cap, ovf_blocks, ix.b_plan.as<SlotPlan>(), d_cursors);
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	ix.prof_mark(2, s);
 	ix.prof_mark(3, s);
 	const uint32_t pgrid = onepass_grid(nblk);
-	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
-		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt);
-	else
-		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors,
-		                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt);
+#define BLMX_OP(KWV, BPTV)                                                                                                                              \
+	hipLaunchKernelGGL((k_bin_onepass<KWV, BPTV>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors, \
+	                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt)
+	if (ix.KW == 1) {
+		if (bpt == 2)
+			BLMX_OP(1, 2);
+		else
+			BLMX_OP(1, 1);
+	} else {
+		BLMX_OP(2, 1);
+	}
+#undef BLMX_OP
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(4, s);
 	if (ix.KW == 1)
@@ -1210,22 +1291,33 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 		launch_query_slots_kw<2>(ix, d_plan, (uint32_t)(max_main >> 8), ovf_blocks, d_cursors, ix.b_sorted.p, d_slot_minis, ix.b_ids.p, narrow, s);
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(5, s);
+#define BLMX_GR(KWV, NARROWV, BPTV)                                                                                                                    \
+	hipLaunchKernelGGL((k_gather_runs<BinTile<KWV>::value, NARROWV, BPTV>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out)
 	if (ix.KW == 1) {
-		if (narrow)
-			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, true>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
-		else
-			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, false>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
+		if (bpt == 2) {
+			if (narrow)
+				BLMX_GR(1, true, 2);
+			else
+				BLMX_GR(1, false, 2);
+		} else {
+			if (narrow)
+				BLMX_GR(1, true, 1);
+			else
+				BLMX_GR(1, false, 1);
+		}
 	} else {
 		if (narrow)
-			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, true>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
+			BLMX_GR(2, true, 1);
 		else
-			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, false>), dim3(nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, ix.b_ids.p, nq, d_out);
+			BLMX_GR(2, false, 1);
 	}
+#undef BLMX_GR
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(6, s);
 	if (!ix.b_pstats.p)
 		BLMX_HIP(ix.b_pstats.alloc(64, true, s));
-	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>(), ix.b_pstats.as<unsigned long long>());
+	hipLaunchKernelGGL(k_plan_learn, dim3((nbins + 255) / 256), dim3(256), 0, s, d_cursors, nq, nbins, ix.b_frac.as<float>(), ix.b_pstats.as<unsigned long long>(),
+	                   ix.dropped_word());
 	ix.plan_bits = tbits;
 	update_filter_gate(ix, d_out, nq, s);
 	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 2) {  // bin occupancy of this batch (synchronises)
@@ -1330,7 +1422,7 @@ void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const u
 	ensure_buf(sp.ids, slots * 8, s);
 	ensure_buf(sp.lpos, sp.lpos_bytes + sp.runs * 12, s);
 	ensure_buf(sp.plan, sizeof(SlotPlan), s);
-	ensure_buf(sp.cursors, ((size_t)nbins + 1) * 4, s);
+	ensure_buf(sp.cursors, ((size_t)nbins + 2) * 4, s);
 	ensure_buf(sp.hdr, ((size_t)nbins + 2) * 8, s);
 	ensure_buf(sp.info, 128, s);
 	sp.h_info.ensure(128);
@@ -1338,15 +1430,15 @@ void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const u
 	rt.gbase = reinterpret_cast<uint32_t*>(sp.lpos.as<char>() + sp.lpos_bytes);
 	rt.obase = rt.gbase + sp.runs;
 	rt.count = rt.obase + sp.runs;
-	hipLaunchKernelGGL(k_plan_make, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac_sharded.as<float>() : nullptr, n, nbins, pct, (uint32_t)sp.max_main,
+	hipLaunchKernelGGL(k_plan_make<1>, dim3(1), dim3(1 << kBinBitsMax), 0, s, learnt ? ix.b_frac_sharded.as<float>() : nullptr, n, nbins, pct, (uint32_t)sp.max_main,
 	                   (uint32_t)n, 1024u, sp.plan.as<SlotPlan>(), sp.cursors.as<uint32_t>());
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	const uint32_t pgrid = onepass_grid(sp.nblk);
 	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_onepass<1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
+		hipLaunchKernelGGL((k_bin_onepass<1, 1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
 		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
 	else
-		hipLaunchKernelGGL((k_bin_onepass<2>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
+		hipLaunchKernelGGL((k_bin_onepass<2, 1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
 		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
 	FirstBins f;
 	f.world = world;
@@ -1480,21 +1572,21 @@ void slot_piece_gather(Index& ix, SlotPiece& sp, int64_t* d_out, hipStream_t s)
 	const uint16_t* d_lpos = sp.lpos.as<uint16_t>();
 	if (ix.KW == 1) {
 		if (sp.narrow)
-			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, true>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, true, 1>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
 		else
-			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, false>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+			hipLaunchKernelGGL((k_gather_runs<BinTile<1>::value, false, 1>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
 	} else {
 		if (sp.narrow)
-			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, true>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, true, 1>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
 		else
-			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, false>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
+			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, false, 1>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
 	}
 	BLMX_HIP(hipGetLastError());
 	ensure_buf(ix.b_frac_sharded, sizeof(float) << kBinBitsMax, s);
 	if (!ix.b_pstats.p)
 		BLMX_HIP(ix.b_pstats.alloc(64, true, s));
 	hipLaunchKernelGGL(k_plan_learn, dim3((sp.nbins + 255) / 256), dim3(256), 0, s, sp.cursors.as<uint32_t>(), sp.nq, sp.nbins, ix.b_frac_sharded.as<float>(),
-	                   ix.b_pstats.as<unsigned long long>());
+	                   ix.b_pstats.as<unsigned long long>(), ix.dropped_word());
 	ix.plan_nbins_sharded = sp.nbins;
 	update_filter_gate(ix, d_out, sp.nq, s);
 }
@@ -1523,7 +1615,10 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	// One pass into bin regions sized after the previous batch when there is one to learn from (automatic), always (1) or never (2)
 	// (slot numbers are 32-bit: bin regions + an overflow region that can hold the whole batch = about 2.1 slots per k-mer)
 	const bool onepass_ok = ix.prm.bits_saved <= 8 && nq < 1900000000ull && 2 * (int)ix.prm.m - 1 >= 3;
-	if (onepass_ok && (ix.tune_partition == 1 || (ix.tune_partition == 0 && ix.plan_bits == onepass_bits(ix)))) {
+	ix.check_dropped();
+	// (more bins than the exact partition holds: the first batch goes through the one-pass kernels too, with equal shares -- what does
+	// not fit a region goes through the overflow region -- and the next one knows its shares)
+	if (onepass_ok && (ix.tune_partition == 1 || (ix.tune_partition == 0 && (ix.plan_bits == onepass_bits(ix) || onepass_bits(ix) > kBinBitsMax)))) {
 		// behind the filter and with 1024 bins the slot kernel is issue-bound (90 % VALU, profiles/r02_pmc_c4.json): now the 4 B per
 		// k-mer of a handed-over minimizer are cheaper than computing it again (C4: 5.71 -> 5.62 ms per step)
 		const bool handoff1 = ix.tune_mini_handoff >= 0 ? ix.tune_mini_handoff != 0 : true;

@@ -604,8 +604,9 @@ namespace {
 
 constexpr char kImageMagic[8] = {'B', 'L', 'M', 'X', 'I', 'D', 'X', '1'};
 constexpr char kImageEnd[8] = {'B', 'L', 'M', 'X', 'E', 'N', 'D', '1'};
-constexpr uint32_t kImageVersion = 1;
-constexpr uint32_t kImageVersionFilter = 2;  // version 1 + the absent-key filter after the fallback ranks
+// (r04: 3 / 4 instead of 1 / 2 -- level-0 units in cross-paired 128-B blocks, blmx_stats_t grew; images of earlier rounds are refused)
+constexpr uint32_t kImageVersion = 3;
+constexpr uint32_t kImageVersionFilter = 4;  // + the absent-key filter after the fallback ranks
 
 struct FileHeader {
 	char magic[8];
@@ -680,8 +681,9 @@ void save_index(Index& ix, const char* path)
 	FileHeader h{};
 	memcpy(h.magic, kImageMagic, 8);
 	h.version = (ix.filter_bpk || ix.pos_hint) ? kImageVersionFilter : kImageVersion;
-	h.filter_bpk = ix.filter_bpk | (ix.pos_hint << 8) | ((uint32_t)ix.fat_lines << 16);  // low byte: filter bits per key; next byte: hint bits of the
-	                                                                                       // position fields; bit 16: the filter lives in fat level-0 lines
+	// low byte: filter bits per key; next byte: hint bits of the position fields; bit 16: the filter lives in 64-B level-0 units; bit 17: those
+	// are records (32 level bits + the position fields of their keys)
+	h.filter_bpk = ix.filter_bpk | (ix.pos_hint << 8) | ((uint32_t)ix.fat_lines << 16) | ((uint32_t)ix.rec_lines << 17);
 	h.abi = BLMX_ABI_VERSION;
 	h.stats_bytes = sizeof(blmx_stats_t);
 	h.group_desc_bytes = sizeof(GroupDesc);
@@ -752,10 +754,10 @@ void load_index(Index& ix, const char* path)
 	if (memcmp(h.magic, kImageMagic, 8) != 0)
 		throw StatusError{BLMX_EIO, "not a Blight MI355X index file"};
 	const uint32_t img_hint = (h.filter_bpk >> 8) & 0xffu;
-	const bool img_fat = (h.filter_bpk >> 16) & 1u;
+	const bool img_fat = (h.filter_bpk >> 16) & 1u, img_rec = (h.filter_bpk >> 17) & 1u;
 	h.filter_bpk &= 0xffu;
 	if ((h.version != kImageVersion && h.version != kImageVersionFilter) || (h.version == kImageVersion && (h.filter_bpk || img_hint)) || h.filter_bpk > 32 ||
-	    (img_fat && h.filter_bpk != 8) ||
+	    (img_fat && h.filter_bpk != 8) || (img_rec && !img_fat) ||
 	    img_hint > 3 || img_hint > h.bits_saved ||
 	    h.stats_bytes != sizeof(blmx_stats_t) || h.group_desc_bytes != sizeof(GroupDesc))
 		throw StatusError{BLMX_EIO, "index file written by an incompatible library version"};
@@ -782,6 +784,7 @@ void load_index(Index& ix, const char* path)
 	ix.filter_bpk = 0;
 	ix.filter_words = 0;
 	ix.fat_lines = img_fat;
+	ix.rec_lines = img_rec;
 	if (h.filter_bpk) {
 		if (h.st.local_number_kmer > (1ull << 40))
 			throw StatusError{BLMX_EIO, "index file is inconsistent (header)"};
@@ -810,6 +813,7 @@ void load_index(Index& ix, const char* path)
 				b->release();
 			ix.filter_bpk = 0;
 			ix.fat_lines = false;
+			ix.rec_lines = false;
 			ix.h_groups.clear();
 			ix.h_fb_group.clear();
 			throw StatusError{BLMX_EIO, std::string("index file is inconsistent (") + what + ")"};
@@ -831,8 +835,10 @@ void load_index(Index& ix, const char* path)
 			}
 			uint64_t glines = gd.nkeys ? (bits / 32 + kLineData32 - 1) / kLineData32 : 0;  // 16-B units of the group's lines
 			if (img_fat && gd.nkeys) {
-				const uint64_t w0 = gd.size[0] / 32, F = (w0 + kLineData32 - 1) / kLineData32;
-				glines = 4 * F + (bits / 32 - w0 + kLineData32 - 1) / kLineData32;
+				const uint64_t w0 = gd.size[0] / 32, F = img_rec ? w0 : (w0 + kLineData32 - 1) / kLineData32;
+				glines = 8 * ((F + 1) / 2) + (bits / 32 - w0 + kLineData32 - 1) / kLineData32;
+				if (gd.line_base % 8)  // (128-B blocks)
+					bad("group table");
 			}
 			if (gd.nbits <= img_hint || gd.nbits > 32 || gd.nkeys > (1ull << 40) || gd.line_base > h.total_lines || glines > h.total_lines - gd.line_base ||
 			    gd.posstart > h.positions_words * 64 || gd.nkeys * gd.nbits > h.positions_words * 64 - gd.posstart || gd.fb_start > h.nfb ||

@@ -6,6 +6,26 @@
 
 namespace blmx {
 
+// Experiment hook (tools: `python -m blight_amd.build --variant nt -DBLMX_EXP_NT=mask`): non-temporal hints on the loads and stores whose
+// lines nobody touches twice, so that they do not push the level-0 lines (3.8 touches per 128-B block and batch) out of the XCD's L2.
+// bit 0 the batch's slots and minimizers, 1 position fields, 2 sequence windows, 3 the IDs written per slot, 4 deeper MPHF levels.
+#ifndef BLMX_EXP_NT
+#define BLMX_EXP_NT 0
+#endif
+template <int BIT, typename T> __device__ __forceinline__ T exp_load(const T* p)
+{
+	if constexpr ((BLMX_EXP_NT >> BIT) & 1)
+		return __builtin_nontemporal_load(p);
+	else
+		return *p;
+}
+template <int BIT, typename T> __device__ __forceinline__ void exp_store(T* p, T v)
+{
+	if constexpr ((BLMX_EXP_NT >> BIT) & 1)
+		__builtin_nontemporal_store(v, p);
+	else
+		*p = v;
+}
 template <int KW> __device__ __forceinline__ Kmer<KW> load_kmer(const uint64_t* __restrict__ p, uint64_t i);
 template <> __device__ __forceinline__ Kmer<1> load_kmer<1>(const uint64_t* __restrict__ p, uint64_t i)
 {
@@ -37,6 +57,11 @@ __device__ __forceinline__ bool mphf_probe(const uint4* __restrict__ lines, uint
 {
 	const uint32_t w32 = (uint32_t)(bit >> 5);  // a group's level array is < 2^37 bits (checked at build time)
 	const uint32_t line = w32 / kLineData32;
+	if constexpr ((BLMX_EXP_NT >> 4) & 1) {
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&lines[line]));
+		return mphf_probe_line(make_uint4(q.x, q.y, q.z, q.w), w32 - line * kLineData32, (uint32_t)bit & 31u, rank);
+	}
 	return mphf_probe_line(lines[line], w32 - line * kLineData32, (uint32_t)bit & 31u, rank);
 }
 
@@ -166,14 +191,87 @@ __device__ __forceinline__ uint32_t fat_lines_of(uint64_t size0) { return ((uint
 constexpr int kFatUnits = 4;       // 16-B units per fat line
 constexpr int kFatFilterWords = 6;  // u64 filter words per fat line
 __device__ __forceinline__ uint32_t fat_filter_word(uint64_t fh) { return (uint32_t)(((fh & 0xffffffffull) * (uint64_t)kFatFilterWords) >> 32); }
+__device__ __forceinline__ uint32_t rec_filter_word(uint64_t fh) { return (uint32_t)(fh >> 31) & 1u; }  // (bit 31: the mask uses bits 32..61)
+
+// ---- level-0 records (r04) ------------------------------------------------------------------------------------------------------------
+// With DeviceIndexView::rec (implies fat) a level-0 unit of 64 bytes covers 32 level-0 bits instead of 96 and carries, besides the
+// filter, the POSITION FIELDS of the keys it ranks:
+//   u32[0] rank before the record | u32[1] 32 level-0 bits | u32[2..11] position fields, nbits each, field j = the record's j-th set
+//   bit (a copy of positions[rank + j]; the first rec_fields(nbits) of them) | u64[6..7] two words of the absent-key filter.
+// About 16 keys hash into the 32 bits (gamma = 2) and ~10 of them are ranked there; 320 bits hold 22 fields of 14 bits.  A level-0
+// key -- 61 % of all keys -- then costs ONE 64-byte sector for filter test, level-0 probe, rank AND position: one request to the
+// fabric and one dependent round trip fewer than with the field in the positions array (whose sector is somewhere else; the
+// `positions` array stays complete: deeper levels, fields beyond a record's capacity, export and the builders read it).  The slot
+// kernel runs at the chip's rate of random fabric requests (~5e10/s, profiles/r04_*): what it saves is requests.  Costs 64 B per
+// 16 keys (32 bits per key) instead of 64 B per 48: chosen at build time while the index stays a small share of the card's HBM.
+constexpr int kRecUnits = 4;       // 16-B units per record
+constexpr int kRecPosWord = 2;     // first u32 of the position area
+constexpr int kRecPosBits = 320;   // ten u32
+constexpr int kRecFilterWord = 6;  // first u64 of the two filter words
+__host__ __device__ __forceinline__ uint32_t rec_fields(uint32_t nbits)
+{
+	const uint32_t f = nbits ? (uint32_t)kRecPosBits / nbits : 0u;
+	return f > 32u ? 32u : f;
+}
+// 64-B level-0 units of a group: fat lines of 96 bits, or records of 32
+__host__ __device__ __forceinline__ uint64_t level0_units64(uint64_t size0, bool rec)
+{
+	const uint64_t w0 = size0 >> 5;
+	return rec ? w0 : (w0 + kLineData32 - 1) / kLineData32;
+}
+// ---- cross-paired level-0 blocks (r04) --------------------------------------------------------------------------------------------
+// What the slot kernel is bound by is the NUMBER of requests its L2 misses send to the fabric: 1.66e8 per 1e8 queries at 4.9e10/s --
+// the rate at which the chip serves random requests of any size up to a 128-byte line (tools/sector_probe: one 16-B load per random
+// line 49.4e9/s; one load that straddles the line's two 64-B sectors 49.5e9/s; two back-to-back loads to the two sectors 41-56e9/s
+// and ONE request at L1 and at L2; a second sector asked for after the first has arrived: a second request).  A batch touches
+// nearly every sector of the index, so asking for whole 128-B lines halves the requests.  The 64-B level-0 units (fat lines and
+// records alike) are therefore stored in 128-B blocks of two, CROSSED: the head of unit u (and a record's fields) in half u & 1 of
+// block u >> 1, its filter words in the OTHER half, where the partner's head is.  A query's two loads -- head and filter word, issued
+// back to back as before -- then always name both sectors of one line: one request brings the 128 bytes, and the partner unit's
+// queries find their halves in the L2.  Same bytes, same instructions; blocks are 128-B aligned (GroupDesc::line_base is a
+// multiple of 8 units).
+constexpr int kBlockUnits = 8;  // 16-B units per 128-B block
+__host__ __device__ __forceinline__ uint64_t level0_block_units(uint64_t size0, bool rec) { return ((level0_units64(size0, rec) + 1) / 2) * kBlockUnits; }
+__device__ __forceinline__ const uint4* level0_head(const uint4* __restrict__ group_lines, uint32_t u)
+{
+	return group_lines + (size_t)(u >> 1) * kBlockUnits + (u & 1u) * 4u;
+}
+// first filter word of unit u: behind the PARTNER's head (16 B of a fat line, 48 B of a record)
+__device__ __forceinline__ const uint64_t* level0_filter(const uint4* __restrict__ group_lines, uint32_t u, bool rec)
+{
+	return reinterpret_cast<const uint64_t*>(group_lines + (size_t)(u >> 1) * kBlockUnits + ((u & 1u) ^ 1u) * 4u) + (rec ? kRecFilterWord : 2);
+}
+
+// head (8 B: rank, bits) and one filter word (8 B) of a record in ONE round trip
+__device__ __forceinline__ void load_rec_head_and_filter(const uint4* __restrict__ recp, const uint64_t* __restrict__ fp, uint2& head, uint64_t& fw)
+{
+	uint2 f;
+	asm volatile(
+	    "global_load_dwordx2 %0, %2, off\n\t"
+	    "global_load_dwordx2 %1, %3, off\n\t"
+	    "s_waitcnt vmcnt(0)"
+	    : "=&v"(head), "=&v"(f)
+	    : "v"(recp), "v"(fp)
+	    : "memory");
+	fw = (uint64_t)f.x | ((uint64_t)f.y << 32);
+}
+// field j of a record (j < rec_fields(nbits)): the 8-B window starts at most 31 bits before the field and ends inside the record
+// (u32 11 is followed by the filter words)
+__device__ __forceinline__ uint32_t read_rec_field(const uint4* __restrict__ recp, uint32_t j, uint32_t nbits)
+{
+	typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+	const uint32_t o = j * nbits;
+	const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint32_t*>(recp) + kRecPosWord + (o >> 5));
+	const uint64_t v = ((uint64_t)w.x | ((uint64_t)w.y << 32)) >> (o & 31u);
+	return (uint32_t)(v & ((nbits >= 32) ? 0xffffffffull : ((1ull << nbits) - 1ull)));
+}
 
 // head (16 B) and one filter word (8 B) of a fat line in ONE round trip: the compiler would sink the second load behind the test of
 // the first
-__device__ __forceinline__ void load_fat_head_and_filter(const uint4* __restrict__ line, uint32_t word, uint4& head, uint64_t& fw)
+__device__ __forceinline__ void load_fat_head_and_filter(const uint4* __restrict__ line, const uint64_t* __restrict__ fp, uint4& head, uint64_t& fw)
 {
 	// (default cache policy: `nt` makes the slot kernel 40 % slower -- the bin's lines no longer stay in the Infinity Cache -- and `sc1`
 	// 11 %: the two loads of one line then cost two L2 requests; profiles/r03_exp_fat_line_cache_policy_c4.txt)
-	const uint64_t* fp = reinterpret_cast<const uint64_t*>(line) + 2 + word;
 	uint2 f;
 	asm volatile(
 	    "global_load_dwordx4 %0, %2, off\n\t"
@@ -189,24 +287,50 @@ __device__ __forceinline__ void load_fat_head_and_filter(const uint4* __restrict
 // Levels 0..2 use the sizes that came with the group head; deeper levels read their size on demand.
 // use_filter (fat layout only): the absent-key filter is consulted with the level-0 line; `rejected` = the filter says "not indexed"
 // (kNotFound is returned as well: nothing else is looked at).
+// field (records only): the position field of the returned rank when the record carries it, else kNoField.
+constexpr uint32_t kNoField = 0xffffffffu;  // (a field has at most 32 bits, but 2^32 - 1 is no position of a bucket: nt < 2^32)
 template <int KW>
 __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x,
-                                                        bool use_filter, bool& rejected)
+                                                        bool use_filter, bool& rejected, uint32_t& field)
 {
 	LevelHasher hs(x.lo);
 	const uint4* __restrict__ lines = reinterpret_cast<const uint4*>(v.lines) + gh.line_base;
 	uint64_t rank;
 	uint64_t off = 0;
 	rejected = false;
-	if (v.fat) {
+	field = kNoField;
+	if (v.rec) {
+		const uint64_t b0 = reduce_level(hs.next(0), gh.size0);
+		const uint32_t w32 = (uint32_t)(b0 >> 5), bi = (uint32_t)b0 & 31u;
+		const uint4* recp = level0_head(lines, w32);
+		uint2 H;
+		if (use_filter) {
+			const uint64_t fh = filter_hash<KW>(x), fm = filter_mask(fh);
+			uint64_t fw;
+			load_rec_head_and_filter(recp, level0_filter(lines, w32, true) + rec_filter_word(fh), H, fw);
+			if ((fw & fm) != fm) {
+				rejected = true;
+				return kNotFound;
+			}
+		} else {
+			H = *reinterpret_cast<const uint2*>(recp);
+		}
+		if ((H.y >> bi) & 1u) {
+			const uint32_t j = (uint32_t)__popc(H.y & ((1u << bi) - 1u));
+			if (j < rec_fields(gh.nbits))
+				field = read_rec_field(recp, j, gh.nbits);  // the sector is in flight or in the L1 / L2 it just came through
+			return (uint64_t)(H.x + j);
+		}
+		lines += (size_t)level0_block_units(gh.size0, true);  // the deeper levels: 16-B lines over the bits behind level 0
+	} else if (v.fat) {
 		const uint64_t b0 = reduce_level(hs.next(0), gh.size0);
 		const uint32_t w32 = (uint32_t)(b0 >> 5), fl = w32 / kLineData32;
-		const uint4* fat = lines + (size_t)fl * kFatUnits;
+		const uint4* fat = level0_head(lines, fl);
 		uint4 L;
 		if (use_filter) {
 			const uint64_t fh = filter_hash<KW>(x), fm = filter_mask(fh);
 			uint64_t fw;
-			load_fat_head_and_filter(fat, fat_filter_word(fh), L, fw);
+			load_fat_head_and_filter(fat, level0_filter(lines, fl, false) + fat_filter_word(fh), L, fw);
 			if ((fw & fm) != fm) {
 				rejected = true;
 				return kNotFound;
@@ -216,7 +340,7 @@ __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v,
 		}
 		if (mphf_probe_line(L, w32 - fl * kLineData32, (uint32_t)b0 & 31u, rank))
 			return rank;
-		lines += (size_t)fat_lines_of(gh.size0) * kFatUnits;  // the deeper levels: 16-B lines over the bits behind level 0
+		lines += (size_t)level0_block_units(gh.size0, false);  // the deeper levels: 16-B lines over the bits behind level 0
 	} else {
 		if (mphf_probe(lines, reduce_level(hs.next(0), gh.size0), rank))
 			return rank;
@@ -249,29 +373,38 @@ __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v,
 	return kNotFound;
 }
 template <int KW>
+__device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x,
+                                                        bool use_filter, bool& rejected)
+{
+	uint32_t field;
+	return mphf_lookup_levels<KW>(v, gd, gh, x, use_filter, rejected, field);
+}
+template <int KW>
 __device__ __forceinline__ uint64_t mphf_lookup_levels(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x)
 {
 	bool rejected;
 	return mphf_lookup_levels<KW>(v, gd, gh, x, false, rejected);
 }
 
-// the filter bits of k-mer x in the fat layout: the word of the fat line its level-0 hash selects (build: k_filter_keys / _junctions)
+// the filter bits of k-mer x in the fat / record layout: the word of the 64-B level-0 unit its level-0 hash selects (build:
+// k_filter_keys / _junctions)
 template <int KW>
 __device__ __forceinline__ unsigned long long* fat_filter_slot(const DeviceIndexView& v, uint64_t line_base, uint64_t size0, Kmer<KW> x, uint64_t fh)
 {
 	const uint64_t b0 = reduce_level(hash_bis(x.lo, kSeedH0), size0);
-	const uint32_t fl = (uint32_t)(b0 >> 5) / kLineData32;
-	uint64_t* line = const_cast<uint64_t*>(v.lines) + 2 * (line_base + (uint64_t)fl * kFatUnits);
-	return reinterpret_cast<unsigned long long*>(line + 2 + fat_filter_word(fh));
+	const uint4* group_lines = reinterpret_cast<const uint4*>(v.lines) + line_base;
+	const uint32_t u = v.rec ? (uint32_t)(b0 >> 5) : (uint32_t)(b0 >> 5) / kLineData32;
+	const uint64_t* w = level0_filter(group_lines, u, v.rec) + (v.rec ? rec_filter_word(fh) : fat_filter_word(fh));
+	return reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(w));
 }
 
 // mphf::lookup (bbhash.h:561-577): levels first, then the group's fallback table.
 template <int KW>
 __device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x,
-                                                 bool use_filter = false)
+                                                 bool use_filter, uint32_t& field)
 {
 	bool rejected;
-	const uint64_t r = mphf_lookup_levels<KW>(v, gd, gh, x, use_filter, rejected);
+	const uint64_t r = mphf_lookup_levels<KW>(v, gd, gh, x, use_filter, rejected, field);
 	if (r != kNotFound || rejected)
 		return r;
 	const uint32_t fb_count = gd->fb_count;  // from the descriptor: the compact query head does not carry the fallback fields
@@ -294,6 +427,13 @@ __device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const 
 		return v.fb_ranks[lo - 1];
 	return kNotFound;
 }
+template <int KW>
+__device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x,
+                                                 bool use_filter = false)
+{
+	uint32_t field;
+	return mphf_lookup<KW>(v, gd, gh, x, use_filter, field);
+}
 
 // bool_to_int, blight.cpp:473-482: nbits-wide little-endian field at bit posstart + h*nbits.
 // Physical layout: a field holds the key's position in its bucket >> (b - hint) -- `hint` more low bits than the reference keeps
@@ -305,7 +445,12 @@ __device__ __forceinline__ uint32_t read_position_field(const uint64_t* __restri
 	// (multi-dword loads need dword alignment only) instead of two aligned 8-B words
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 	const uint64_t o = posstart + h * (uint64_t)nbits;
-	const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint32_t*>(positions) + (o >> 5));
+	const u32x2* wp = reinterpret_cast<const u32x2*>(reinterpret_cast<const uint32_t*>(positions) + (o >> 5));
+	u32x2 w;
+	if constexpr ((BLMX_EXP_NT >> 1) & 1)
+		w = __builtin_nontemporal_load(wp);
+	else
+		w = *wp;
 	const uint32_t s = (uint32_t)o & 31u;
 	const uint64_t v = ((uint64_t)w.x | ((uint64_t)w.y << 32)) >> s;
 	return (uint32_t)(v & ((nbits >= 32) ? 0xffffffffull : ((1ull << nbits) - 1ull)));
@@ -319,6 +464,6 @@ __device__ __forceinline__ uint32_t read_position(const uint64_t* __restrict__ p
 // Extra low bits a field keeps for windows of 2^logp positions.  Only for the wide windows: at b = 8 the 256 steps of the scan are most
 // of the query kernel's instructions and the kernel is issue-bound (C5: 4.39 -> 3.82 ms); at b <= 6 the kernel waits for memory, the
 // shorter scan buys nothing (C4: 3.40 -> 3.41 ms) and the wider fields cost 3 bits per key.
-__host__ __device__ constexpr int position_hint_bits(int logp) { return logp >= 7 ? 3 : 0; }
+__host__ __device__ constexpr int position_hint_bits(int logp) { return logp >= 6 ? 3 : 0; }  // (b = 6: only when asked for, pos_hint = 2)
 
 }  // namespace blmx

@@ -157,7 +157,7 @@ __device__ __forceinline__ int scan_window(const uint64_t* __restrict__ seq, uin
 	uint64_t W[NW];
 #pragma unroll
 	for (int i = 0; i < NW; i++)
-		W[i] = seq[w0 + i];
+		W[i] = exp_load<2>(&seq[w0 + i]);
 	if (k >= 16) {
 	uint32_t X0, XR0;  // top 32 bits of the top-aligned queries
 	if constexpr (KW == 1) {
@@ -253,10 +253,12 @@ __device__ __forceinline__ void query_one_with(const DeviceIndexView& v, Kmer<KW
 			return;
 	}
 	// (fat level-0 lines: the filter word comes with the level-0 line, inside the lookup)
-	const uint64_t h = mphf_lookup<KW>(v, gd, gh, x, v.fat && v.filter != nullptr);
+	uint32_t field;  // level-0 records: the position field comes with the rank (index_device.h)
+	const uint64_t h = mphf_lookup<KW>(v, gd, gh, x, v.fat && v.filter != nullptr, field);
 	if (h == kNotFound)  // blight.cpp:725-726
 		return;
-	const uint32_t field = read_position_field(v.positions, gh.posstart, gh.nbits, h);
+	if (field == kNoField)
+		field = read_position_field(v.positions, gh.posstart, gh.nbits, h);
 	const uint64_t pos = (uint64_t)(field >> v.hint) << v.b;  // the reference's value: first position of the 2^b window
 	if (!(pos + (uint64_t)v.k - 1 < (uint64_t)bnt))  // blight.cpp:729
 		return;

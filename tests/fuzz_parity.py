@@ -36,8 +36,8 @@ def sweep(runs, seed, verbose=True):
             ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
             if rng.random() < 0.5:
                 ix.set_tuning("build_passes", int(rng.integers(1, 9)))  # passes over ranges of MPHF groups: the arrays must not depend on them
-            if rng.random() < 0.3:
-                ix.set_tuning("fat_lines", 0)                           # separate filter array instead of 64-B level-0 lines
+            if rng.random() < 0.5:
+                ix.set_tuning("fat_lines", int(rng.integers(0, 2)))     # separate filter array / fat level-0 lines instead of level-0 records
             ix.construct_index_from_sequences(seqs)
             if rng.random() < 0.8:
                 ix.set_tuning("absent_filter", 1)  # queries through the armed absent-key filter (else: maybe before its passes are done)

@@ -466,7 +466,70 @@ def test_absent_filter_keeps_every_answer_of_the_reference(B, O, k, kb, m, n, b,
     assert none.stats()["device_bytes"] < ix.stats()["device_bytes"]
 
 
-@pytest.mark.parametrize("k,kb,m,n,b,fat", [(31, 8, 7, 5, 6, 1), (31, 8, 9, 7, 4, 0), (63, 16, 9, 7, 8, 1)])
+@pytest.mark.parametrize("k,kb,m,n,b", [(31, 8, 9, 5, 6), (27, 8, 7, 3, 0), (63, 16, 9, 7, 8), (21, 8, 5, 0, 2)])
+def test_level0_layouts_answer_alike(B, O, k, kb, m, n, b):
+    """The MPHF's level 0 has three physical layouts (index_device.h): 16-B lines + a separate filter array (0), 64-B fat lines that carry
+    the filter (1), 64-B records of 32 level bits that carry the filter AND the position fields of the keys they rank (2, the default
+    while the index is small against the card).  None of them is observable: the exported arrays (the reference's logical arrays) are
+    equal among the three and to the oracle's, every k-mer and read gets the oracle's answer -- also positional queries, queries with
+    a caller's minimizer, the partitioned pipeline and a reloaded image.  b = 0 with a long low-complexity unitig makes position
+    fields of 18+ bits, so that a record holds fewer fields than it can rank keys and the rest is read from `positions`."""
+    rng = np.random.default_rng(4000 + k + b)
+    seqs = [_rand_seq(rng, k + int(rng.integers(0, 120))) for _ in range(1200)]
+    seqs += [_rand_seq(rng, 150000 if b == 0 else 3000, "AC"), seqs[3], "A" * (k + 20), seqs[10][1:]]
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    a = orc.arrays()
+    q = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs[:1200] + seqs[1201:]])
+    neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(3000)]
+    neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
+    allq = np.ascontiguousarray(np.concatenate([q, neg, q[::-1][:5000]]))
+    flat = allq.reshape(-1)
+    want = orc.query_kmers(flat if kb == 8 else allq)
+    sub = allq[::17]  # positional queries and queries with the caller's minimizer (python minimizers: a sample)
+    sub_minis = np.array([O.p_minimizer(x, k, m, kb) for x in O.array_to_kmers(sub, kb)], dtype=np.uint32)
+    want_pos = orc.query_kmers_mini(sub.reshape(-1) if kb == 8 else sub, sub_minis, want_pos=True)
+    want_mini = orc.query_kmers_mini(sub.reshape(-1) if kb == 8 else sub, sub_minis)
+    reads = [s[i:i + 2 * k + 7] for s in seqs[:200] for i in (0, 5)] + [_rand_seq(rng, 3 * k) for _ in range(50)]
+    want_reads = np.concatenate([orc.query_sequence(r) for r in reads])
+    exported = {}
+    sizes = {}
+    for layout in (0, 1, 2):
+        ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+        ix.set_tuning("fat_lines", layout)
+        if b > 6:
+            ix.set_tuning("filter_bits", 8)  # (the automatic 16 bits of the wide windows keep the filter a separate array)
+        ix.construct_index_from_sequences(seqs)
+        ix.set_tuning("absent_filter", 1)
+        sizes[layout] = ix.stats()["device_bytes"]
+        exported[layout] = {name: ix.export(name) for name in B.EXPORT}
+        for key in ("bucket_nt", "bucket_start", "seq", "positions", "g_nkeys", "g_prefix", "g_posstart", "g_nbits"):
+            assert np.array_equal(exported[layout][key], a[key]), (layout, key)
+        for pol in (-1, 1, 1):  # direct kernel; partitioned pipeline: exact pass, then one pass with the learnt regions
+            ix.set_query_binning(pol)
+            assert np.array_equal(ix.query_kmer_hash(flat), want), (layout, pol)
+        ix.set_query_binning(0)
+        ix.set_tuning("absent_filter", 0)
+        assert np.array_equal(ix.query_kmer_hash(flat), want), (layout, "unfiltered")
+        ix.set_tuning("absent_filter", 1)
+        assert np.array_equal(ix.query_get_pos_unitig(np.ascontiguousarray(sub).reshape(-1), sub_minis).astype(np.int64), want_pos), (layout, "pos")
+        assert np.array_equal(ix.query_get_hash(np.ascontiguousarray(sub).reshape(-1), sub_minis), want_mini), (layout, "caller's minimizer")
+        assert np.array_equal(ix.query_sequences_hash(reads), want_reads), (layout, "reads")
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            ix.dump_disk(td + "/i.blmx")
+            ld = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+            ld.load_disk(td + "/i.blmx")
+            assert np.array_equal(ld.query_kmer_hash(flat), want), (layout, "image")
+            assert ld.stats()["device_bytes"] == sizes[layout]
+            for name in B.EXPORT:
+                assert np.array_equal(ld.export(name), exported[layout][name]), (layout, "image", name)
+        ix.close()
+    for name in B.EXPORT:
+        assert np.array_equal(exported[0][name], exported[1][name]) and np.array_equal(exported[0][name], exported[2][name]), name
+    assert sizes[2] > sizes[1]  # what the records cost
+
+
+@pytest.mark.parametrize("k,kb,m,n,b,fat", [(31, 8, 7, 5, 6, 1), (31, 8, 9, 7, 4, 0), (63, 16, 9, 7, 8, 1), (31, 8, 9, 6, 6, 2), (63, 16, 9, 7, 5, 2)])
 def test_build_passes_do_not_change_the_index(B, O, k, kb, m, n, b, fat):
     """The construction works through the MPHF groups in passes (keys, survivor lists and position fields of one range of groups at a
     time: the reference builds one of 2^s super-buckets at a time, blight.cpp:335-356).  Every array, counter and answer is the same for
@@ -566,3 +629,30 @@ print("HOOKS-OK")
     e.update(env)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "HOOKS-OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_a_kmer_without_a_slot_fails_the_call(B):
+    """The one-pass partition places every k-mer in its bin's region or in the overflow region, which holds a whole batch: nothing can be
+    left over.  If something ever were (a bug), the k-mer would come back as "absent" -- so the kernel counts it and the call fails
+    instead (the next call, when the batch was answered asynchronously).  Test hook: an overflow region of 256 slots under a batch
+    that needs thousands (one bin's region is sized for a uniform batch, the batch is one k-mer repeated)."""
+    rng = np.random.default_rng(5)
+    seqs = [_rand_seq(rng, 200) for _ in range(3000)]
+    ix = _build(B, 31, 9, 6, 6, seqs)
+    ix.set_query_binning(1)
+    ix.set_tuning("partition", 1)
+    from oracle import oracle as O
+    orc = O.Oracle(31, 9, 6, 6, seqs)
+    q = np.concatenate([orc.canonical_kmers(s).reshape(-1) for s in seqs[:600]])
+    big = np.tile(q, 12)[:1 << 20]
+    ids = ix.query_kmer_hash(big)
+    assert (ids >= 0).all()
+    ix.set_tuning("test_ovf_cap", 256)
+    skew = np.full(1 << 20, q[0], dtype=np.uint64)
+    with pytest.raises(Exception) as e:
+        ix.query_kmer_hash(skew)
+        ix.query_kmer_hash(big)  # (at the latest)
+    assert "found no slot" in str(e.value)
+    ix.set_tuning("test_ovf_cap", 0)
+    assert np.array_equal(ix.query_kmer_hash(skew), np.full(1 << 20, ids[0]))
+    assert np.array_equal(ix.query_kmer_hash(big), ids)
