@@ -690,13 +690,14 @@ struct RunTable {
 
 template <int KW, int BPT>
 __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, const SlotPlan* __restrict__ sp, const uint64_t* __restrict__ kmers,
-                                                             const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
-                                                             uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint16_t* __restrict__ lpos,
-                                                             RunTable rt)
+                                                         const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
+                                                         uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint16_t* __restrict__ lpos,
+                                                         RunTable rt)
 {
 	constexpr int kTile = BinTile<KW>::value;
-	constexpr int kPer = kTile / kBinThreads;
-	constexpr int kNB = BPT << kBinBitsMax;  // BPT bins per thread
+	constexpr int THREADS = kBinThreads;
+	constexpr int kPer = kTile / THREADS;
+	constexpr int kNB = BPT * THREADS;  // BPT bins per thread
 	__shared__ uint64_t s_keys[kTile * KW];
 	__shared__ uint32_t s_mini[kTile];
 	__shared__ uint32_t s_cnt2[2][kNB];  // k-mers of this tile per bin, then the tile-local start of the bin; tiles alternate between the two
@@ -704,8 +705,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	__shared__ uint32_t s_obase[kNB];   // first overflow slot of the part of the run that does not fit the bin
 	__shared__ uint32_t s_rbase[kNB];   // the bin's region: first slot ...
 	__shared__ uint32_t s_rcap[kNB];    // ... and slots
-	__shared__ uint32_t s_wsum[kBinThreads / 64];
-	static_assert(kBinThreads == (1 << kBinBitsMax), "BPT bins per thread");
+	__shared__ uint32_t s_wsum[THREADS / 64];
+	static_assert(kTile <= 65536 && kTile % THREADS == 0, "16-bit tile-local positions");
 	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	{
 		const uint32_t nb = sp->nbins;
@@ -719,11 +720,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		}
 	}
 	const uint32_t ovf_at = sp->main_slots, all_slots = sp->main_slots + sp->ovf_cap, nbins_p = sp->nbins;
-	// A workgroup walks over tiles (grid = one workgroup per CU, or one per tile): the stores of one tile drain while the minimizers
-	// of the next are computed, the region table is loaded once, and there is no dispatch gap between tiles on a CU whose LDS holds
-	// only one of these workgroups.  r04: the counters are double-buffered, so that no barrier separates the copy-out of tile t from
-	// the minimizer phase of tile t + 1 (a wave that has issued its stores goes on hashing; 6 -> 4 barriers per tile): the barrier
-	// behind the minimizer phase of t + 1 is the one that says "tile t has been read".
+	// A workgroup walks over tiles (grid = a few workgroups per CU, or one per tile): the stores of one tile drain while the minimizers
+	// of the next are computed, the region table is loaded once, and there is no dispatch gap between tiles.  r04: the counters are
+	// double-buffered, so that no barrier separates the copy-out of tile t from the minimizer phase of tile t + 1 (a wave that has
+	// issued its stores goes on hashing; 6 -> 4 barriers per tile): the barrier behind the minimizer phase of t + 1 is the one that
+	// says "tile t has been read".
 	__syncthreads();
 	uint32_t par = 0;
 	for (uint64_t tile = blockIdx.x; tile * kTile < nq; tile += gridDim.x, par ^= 1u) {
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	uint32_t mini[kPer], rank[kPer];
 #pragma unroll
 	for (int e = 0; e < kPer; e++) {
-		const uint64_t i = base + (uint64_t)e * kBinThreads + t;
+		const uint64_t i = base + (uint64_t)e * THREADS + t;
 		mini[e] = 0;
 		rank[e] = 0;
 		if (i < nq) {
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	};
 #pragma unroll
 	for (int e = 0; e < kPer; e++) {
-		const uint64_t i = base + (uint64_t)e * kBinThreads + t;
+		const uint64_t i = base + (uint64_t)e * THREADS + t;
 		if (i < nq) {
 			const uint32_t b = bm.bin_of(mini[e]);
 			const uint32_t ls = s_cnt[b] + rank[e];
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	__syncthreads();
 	const uint32_t count = (uint32_t)min((uint64_t)kTile, nq - base);
 	uint32_t dropped = 0;
-	for (uint32_t sidx = t; sidx < count; sidx += kBinThreads) {
+	for (uint32_t sidx = t; sidx < count; sidx += THREADS) {
 		const uint32_t mi = s_mini[sidx];
 		const uint32_t b = bm.bin_of(mi);
 		const uint64_t dst = slot_of(b, sidx - s_cnt[b]);
