@@ -73,7 +73,11 @@ def parse_args():
     ap.add_argument("--rehearse-sharded", action="store_true",
                     help="run the N > 1 code path (native RCCL exchange, construction from slices, replicas leg) with a world of one rank")
     ap.add_argument("--present", type=float, default=0.5, help="fraction of the queries that are indexed k-mers (headline: 0.5)")
-    ap.add_argument("--skew", action="store_true", help="10 %% of the unitigs from a 2-symbol source (uneven buckets)")
+    ap.add_argument("--skew", nargs="?", const="dup", default=None, choices=["dup", "dedup"],
+                    help="every tenth unitig from a 2-symbol source (giant buckets).  dup (default): as generated -- repeated k-mers, hence "
+                         "fallback keys; dedup: repeated k-mers removed first, what BCALM2 unitigs look like (distinct k-mers, giant buckets)")
+    ap.add_argument("--light", action="store_true",
+                    help="the index at the reference's footprint: no absent-key filter (filter_bits = 0), 16-B MPHF lines")
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads of the sequence front-end leg (0 = skip)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-buffer / file / per-read-call measurements")
@@ -89,7 +93,7 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def synth_unitigs(torch, dev, n_kmers, k, seed, skew=False):
+def synth_unitigs(torch, dev, n_kmers, k, seed, skew=None):
     """Seeded random unitigs in HBM: lengths k-1+Geometric(mean 80), uniform ACGT; with `skew` every tenth unitig
     is drawn from the 2-symbol source {A, C}.  Returns (ascii u8, offsets i64, total)."""
     g = torch.Generator(device=dev)
@@ -123,6 +127,76 @@ def synth_unitigs(torch, dev, n_kmers, k, seed, skew=False):
         ascii_[s:e] = 65 + 2 * c + 2 * (c == 2).to(torch.uint8) + 13 * (c == 3).to(torch.uint8)
     ascii_[total:] = 0
     return ascii_, offs, total
+
+
+def synth_unitigs_dedup(torch, dev, blight_amd, n_kmers, k, seed):
+    """The realistic skew (--skew dedup): nine tenths of the k-mers in ordinary unitigs, one tenth in unitigs over {A, C} from which every
+    REPEATED k-mer has been removed -- a compacted de Bruijn graph (BCALM2, the reference's input, blight.cpp:212-229) never holds a
+    k-mer twice, but low-complexity sequence still piles millions of DISTINCT k-mers under a few minimizers: giant buckets and MPHF
+    groups without the duplicate keys (fallback entries) that the plain --skew makes.  The {A, C} unitigs are cut wherever a k-mer
+    that occurred before is dropped; runs of kept k-mers become the unitigs.  Returns (ascii u8, offsets i64, total)."""
+    n_ac = n_kmers // 10
+    a1, o1, t1 = synth_unitigs(torch, dev, n_kmers - n_ac, k, seed, None)
+    # {A, C} unitigs with ~8 % more k-mers than needed (a 31-mer over two symbols has 2^31 values: ~6 % of 2.5e8 draws repeat)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed * 31 + 5)
+    want = int(n_ac * 1.08) + 1000
+    nu = max(1, want // 80)
+    extra = torch.empty(nu, device=dev, dtype=torch.float32).geometric_(1.0 / 80.0, generator=g).to(torch.int64).clamp_(min=1)
+    lens = extra + (k - 1)
+    o2 = torch.zeros(nu + 1, device=dev, dtype=torch.int64)
+    torch.cumsum(lens, 0, out=o2[1:])
+    t2 = int(o2[-1].item())
+    c = torch.randint(0, 2, (t2,), device=dev, dtype=torch.uint8, generator=g)
+    a2 = (65 + 2 * c).contiguous()  # A / C
+    del c
+    # every k-mer start, its canonical k-mer, first occurrences
+    koff = torch.zeros(nu + 1, device=dev, dtype=torch.int64)
+    torch.cumsum(extra, 0, out=koff[1:])
+    K = int(koff[-1].item())
+    which = torch.repeat_interleave(torch.arange(nu, device=dev), extra)
+    ar = torch.arange(K, device=dev, dtype=torch.int64)
+    pos = (o2[:-1][which] + (ar - koff[:-1][which])).contiguous()
+    first_of_unitig = ar == koff[:-1][which]
+    del which
+    helper = blight_amd.kmer_Set_Light(k, 9 if k >= 11 else 3, 4, 2, 1, 6, device=dev.index or 0)
+    km = torch.empty(K, device=dev, dtype=torch.int64)
+    err = torch.zeros(1, device=dev, dtype=torch.int32)
+    helper.kmers_at_device(a2.data_ptr(), pos.data_ptr(), K, km.data_ptr(), err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    helper.close()
+    vals, idx = torch.sort(km, stable=True)
+    dup_sorted = torch.zeros(K, device=dev, dtype=torch.bool)
+    dup_sorted[1:] = vals[1:] == vals[:-1]
+    keep = torch.ones(K, device=dev, dtype=torch.bool)
+    keep[idx] = ~dup_sorted
+    del vals, idx, dup_sorted, km
+    # trim to exactly n_ac kept k-mers
+    ck = torch.cumsum(keep.to(torch.int64), 0)
+    keep &= ck <= n_ac
+    del ck
+    prev_kept = torch.zeros(K, device=dev, dtype=torch.bool)
+    prev_kept[1:] = keep[:-1]
+    start_run = keep & (first_of_unitig | ~prev_kept)
+    run_of = torch.cumsum(start_run.to(torch.int64), 0) - 1
+    nruns = int(start_run.sum().item())
+    run_len = torch.bincount(run_of[keep], minlength=nruns)
+    run_pos = pos[start_run]
+    del prev_kept, first_of_unitig, run_of, keep, start_run, pos, ar
+    new_lens = run_len + (k - 1)
+    o3 = torch.zeros(nruns + 1, device=dev, dtype=torch.int64)
+    torch.cumsum(new_lens, 0, out=o3[1:])
+    t3 = int(o3[-1].item())
+    r_of = torch.repeat_interleave(torch.arange(nruns, device=dev), new_lens)
+    src = run_pos[r_of] + (torch.arange(t3, device=dev, dtype=torch.int64) - o3[:-1][r_of])
+    a3 = a2[src]
+    del r_of, src, a2
+    ascii_ = torch.empty(t1 + t3 + 64, device=dev, dtype=torch.uint8)
+    ascii_[:t1] = a1[:t1]
+    ascii_[t1:t1 + t3] = a3
+    ascii_[t1 + t3:] = 0
+    offs = torch.cat([o1, o3[1:] + t1])
+    return ascii_, offs, t1 + t3
 
 
 def synth_queries(torch, ix, dev, ascii_, offs, total, k, nq, seed, kmer_words, present=0.5):
@@ -175,6 +249,21 @@ def synth_reads(torch, dev, ascii_, total, k, nreads, read_len, present, seed):
     chars = rows[perm].reshape(-1).contiguous()
     offs = torch.arange(nreads + 1, device=dev, dtype=torch.int64) * read_len
     return chars, offs, nreads, nreads * max(0, read_len - k + 1)
+
+
+def footprint(st):
+    """bits per indexed k-mer, array by array, next to the figures the reference's recap prints (blight.cpp:371-378: the packed graph,
+    the positions, and "+ 4" for the BBHash it does not measure there)"""
+    nk = max(1, st["local_number_kmer"])
+    seq = 2.0 * st["total_nt"] / nk
+    pos = st["positions_total_size"] / nk
+    mphf = 8.0 * st["mphf_bytes"] / nk
+    total = 8.0 * st["device_bytes"] / nk
+    return {"bits_per_kmer": {"packed_graph": round(seq, 3), "positions_reference_layout": round(pos, 3),
+                              "mphf_lines_incl_ranks_and_inline_filter": round(mphf, 3), "everything_in_hbm": round(total, 3)},
+            "reference_recap_bits_per_kmer": {"packed_graph": round(seq, 3), "positions": round(pos, 3), "with_bbhash_estimate": round(seq + pos + 4.0, 3)},
+            "what": "everything_in_hbm = all device arrays of the finished index (descriptors, fallback table, filter, padding); the reference's "
+                    "own figure is its recap's `TOTAL Bits per kmer (with bbhash)` = packed graph + positions + 4"}
 
 
 def host_cores():
@@ -350,8 +439,13 @@ def roofline_block(args, k, kw, b, nq, stages, step_ms, st):
            "pipeline": {"kernels": "k_plan_make + k_bin_onepass [stage k_bin_scatter] + k_query_slots [stage k_query] + k_gather_runs [stage k_gather_ids] + "
                                    "k_plan_learn (what `value` times; stages k_bin_hist / scan are empty once the bin shares are learnt)", "ms": step_ms,
                         "achieved": pipe_ach, "frac": pipe_ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": pipe_ach / HBM_COPY_GBS}}
+    out["which_fraction_is_which"] = ("frac = the REFERENCE's bytes per query (SURVEY 8d) x queries / kernel time / 8 TB/s: work done per second in the "
+                                      "reference's currency; traffic_frac (when a PMC summary of this source tree is under profiles/) = bytes the "
+                                      "counters saw the kernel move / kernel time / 8 TB/s: what the memory system really carried -- lower, because "
+                                      "the absent-key filter answers the absent half after one line; all_indexed.frac = frac on a batch where every "
+                                      "query does the reference's full work")
     pmc = load_pmc(args.workload)
-    if pmc and not args.skew and not args.kmers and not args.queries and args.present == 0.5:
+    if pmc and not args.skew and not args.kmers and not args.queries and args.present == 0.5 and not args.light:
         kern = pmc.get("kernels", {})
         out["pmc"] = {"file": pmc["file"], "source_digest_matches": pmc.get("source_digest") == source_digest()}
         cands = [(v.get("trace_avg_ns", 0.0) * v.get("trace_calls", 1), name) for name, v in kern.items() if name.startswith("k_query")]
@@ -627,6 +721,9 @@ def host_kmer_legs(torch, ix, q, ids, kw):
 
 def main():
     args = parse_args()
+    # the bench builds human-scale indexes in a row (query index, file legs, replicas): the library parks freed device blocks up to a
+    # cap per device (default 1/16 of the card); raised here, and said so in the line (config.scratch_cache_gb)
+    os.environ.setdefault("BLIGHT_SCRATCH_CACHE_GB", "48")
     # stdout carries exactly ONE line, the result: everything else that writes to file descriptor 1 (RCCL prints its version banner
     # there when a communicator is created) is sent to stderr.
     sys.stdout.flush()
@@ -673,7 +770,10 @@ def main():
 
     # ---- index: seeded synthetic unitigs generated in HBM, built by the HIP pipeline
     t0 = time.time()
-    ascii_, offs, total = synth_unitigs(torch, dev, n_kmers, k, args.seed, args.skew)
+    if args.skew == "dedup":
+        ascii_, offs, total = synth_unitigs_dedup(torch, dev, blight_amd, n_kmers, k, args.seed)
+    else:
+        ascii_, offs, total = synth_unitigs(torch, dev, n_kmers, k, args.seed, args.skew)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     ref_sample = None
@@ -683,6 +783,10 @@ def main():
         so = offs[: nu + 1].cpu().numpy()
         ref_sample = (ascii_[: int(so[-1])].cpu().numpy(), so)
     ix = blight_amd.kmer_Set_Light(k, m, n, min(n, 6), 1, b, device=local_rank)
+    if args.light:  # the reference's footprint: its arrays and nothing else (no absent-key filter, 16-B MPHF lines, its position fields)
+        ix.set_tuning("filter_bits", 0)
+        ix.set_tuning("fat_lines", 0)
+        ix.set_tuning("pos_hint", 0)
     if effective_mode == "sharded":
         ix.set_shard(rank, world)  # this rank keeps the MPHF groups it owns; IDs stay global
     t0 = time.time()
@@ -694,7 +798,7 @@ def main():
     st = ix.stats()
     if rank == 0:
         log("workload %s%s: %d k-mers, %d super-k-mers, %d unitigs, %.2f GB index, gen %.1f s, build %.2f s (%.1f M k-mers/s)" % (
-            args.workload, " (skewed)" if args.skew else "", st["number_kmer"], st["number_super_kmer"], offs.numel() - 1, st["device_bytes"] / 1e9,
+            args.workload, (" (skewed, %s)" % args.skew) if args.skew else "", st["number_kmer"], st["number_super_kmer"], offs.numel() - 1, st["device_bytes"] / 1e9,
             t_gen, t_build, st["number_kmer"] / t_build / 1e6))
 
     # ---- queries (per rank, resident in HBM)
@@ -848,6 +952,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ms_x.append(e0.elapsed_time(e1))
+            # per-kernel times of that workload's steady state (HIP events at the stage boundaries; two more batches of the same kind)
+            stages_x = {a: round(v, 4) for a, v in stage_profile(ix, lambda: ix.query_kmers_device(qx.data_ptr(), nq, scratch_ids.data_ptr(), stream), reps=2).items()}
             ms_h = []
             for j in range(2):
                 e0.record()
@@ -856,7 +962,7 @@ def main():
                 torch.cuda.synchronize()
                 ms_h.append(e0.elapsed_time(e1))
             excursion[name] = {"those_batches_ms": [round(x, 4) for x in ms_x], "steady_queries_per_s": nq / (ms_x[-1] * 1e-3),
-                               "next_headline_batches_ms": [round(x, 4) for x in ms_h]}
+                               "next_headline_batches_ms": [round(x, 4) for x in ms_h], "stages_ms": stages_x}
             del qx
         step(0)  # back to steady state (and ids_all[0] holds batch 0 again)
         torch.cuda.synchronize()
@@ -956,10 +1062,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if kw == 1 else "u128", "data": "synthetic",
             "config": {"workload": "%s%s: %d indexed %d-mers (seeded synthetic unitigs, k%d m%d n%d b%d), %d queries/step/GPU, "
-                                   "%g%% indexed / %g%% random" % (args.workload, " skewed (every tenth unitig from {A,C})" if args.skew else "",
+                                   "%g%% indexed / %g%% random" % (args.workload, (" skewed (a tenth of the k-mers in unitigs over {A,C}%s)" % (", repeated k-mers removed" if args.skew == "dedup" else "")) if args.skew else "",
                                                                     st["number_kmer"], k, k, m, n, b, nq, 100 * args.present, 100 * (1 - args.present)),
                        "parallelism": "1 GPU" if not multi else ("%s x%d" % (effective_mode, world)),
                        "index_bytes_per_gpu": st["device_bytes"], "kmers_per_gpu": st["local_number_kmer"],
+                       "footprint": footprint(st), "light": bool(args.light),
+                       "scratch_cache_gb": float(os.environ.get("BLIGHT_SCRATCH_CACHE_GB", "0")),
                        "build_scratch_peak_bytes": st["build_scratch_peak_bytes"],
                        "build_seconds": t_build, "build_seconds_filter_armed": t_build_armed,
                        "build_kmers_per_sec": st["number_kmer"] / t_build_armed,
@@ -983,6 +1091,20 @@ def main():
         }
         if excursion is not None:
             out["excursion"] = excursion
+            ai = excursion.get("after_a_batch_of_indexed_kmers_only")
+            if ai and "roofline" in out and "query_kernel" in out["roofline"] and ai.get("stages_ms"):
+                kq = ai["stages_ms"].get("k_query", 0.0)
+                if kq > 0:
+                    algo = ALGO_BYTES.get(k, 145)
+                    out["roofline"]["all_indexed"] = {
+                        "kernel_ms": kq, "step_ms": ai["those_batches_ms"][-1], "achieved": algo * nq / (kq * 1e-3) / 1e9,
+                        "frac": algo * nq / (kq * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "what": "the query kernel on a batch of indexed k-mers only (steady state of the excursion; the reference's own benchmark queries "
+                                "the indexed file): every query then does the reference's work, so this is the fraction to read as `bytes of the "
+                                "reference's algorithm per second`; `frac` above is the same quotient on the 50/50 batch, where the absent-key filter "
+                                "ends half the queries after one line, and `traffic_frac` is what the counters say the kernel really moved"}
+        if multi:
+            out["exchange"] = "native-rccl" if comm is not None else ("torch.distributed" if querier is not None else "replicas")
         if args.mode == "sharded" and multi and not sharded:
             out["sharded_fallback"] = effective_mode
         orc = None
@@ -1035,8 +1157,9 @@ def main():
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("bench sanity check failed")
-    if args.mode == "sharded" and multi and not sharded:
-        raise SystemExit("bench: --mode sharded was asked for, but the sharded exchange did not run (%s): the line above is NOT a sharded number" % effective_mode)
+    if args.mode == "sharded" and multi and comm is None:
+        raise SystemExit("bench: --mode sharded was asked for, but the native RCCL exchange did not run (%s; `exchange` in the line above says what "
+                         "did): the line above is NOT the number of the native sharded path" % effective_mode)
 
 
 if __name__ == "__main__":

@@ -826,6 +826,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_window_kb = value;
 	else if (k == "slot_piece_min")
 		ix.tune_slot_piece_min = value;
+	else if (k == "max_batch")  // test hook: device-resident batches are answered in pieces of this many k-mers (0 = 2^30)
+		ix.tune_max_batch = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
 	else if (k == "test_ovf_cap")  // test hook: slots of the one-pass partition's overflow region (0 = a whole batch)
 		ix.tune_test_ovf_cap = (int)value;
 	else if (k == "fat_lines")  // before building: 0 = 16-B lines + filter array, 1 = fat level-0 lines, 2 = level-0 records, -1 = automatic

@@ -638,6 +638,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 		const uint64_t n = cut[p + 1] - cut[p];
 		grow(c.sorted[p], n * 8 * kw + 16, s);
 		grow(c.inv[p], n * 4 + 16, s);
+		grow(c.ids_sorted[p], n * 8 + 16, s);  // (everything sized by this rank's own batch is allocated in front of the vote)
 		launch_partition(ix, (const uint64_t*)d_kmers + cut[p] * kw, n, c.sorted[p].p, c.inv[p].as<uint32_t>(), c.counts.as<uint64_t>() + (size_t)p * world, s);
 		BLMX_HIP(hipMemcpyAsync(c.h_dense.as<uint64_t>() + (size_t)p * world, c.counts.as<uint64_t>() + (size_t)p * world, 8 * (size_t)world, hipMemcpyDeviceToHost, s));
 		BLMX_HIP(hipEventRecord(c.ev_part[p], s));
@@ -666,14 +667,26 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 	} catch (const StatusError& err) {
 		local = err;
 	}
-	// ---- formats and per-owner counts of all pieces (+ one "cannot take part" flag) in one all-gather
-	const size_t per_piece = (size_t)world + 1, per_rank = (size_t)pieces * per_piece + 1;
+	// ---- formats and per-owner counts of all pieces, what every rank can receive without growing a buffer, the settings that size
+	// the flows (ID width, number of pieces: per-rank settings that must agree) and one "cannot take part" flag in one all-gather
+	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
+	const size_t idw = narrow ? 1 : 2;  // 32-bit words per slot of a returned slot range
+	const size_t per_piece = (size_t)world + 1 + 4, per_rank = (size_t)pieces * per_piece + 3;
 	std::vector<uint64_t> mine(per_rank, 0), all(per_rank * world, 0);
-	for (int p = 0; p < pieces && local.code == BLMX_OK; p++) {
-		mine[(size_t)p * per_piece] = slots_fmt[p] ? 1 : 0;
-		for (uint32_t r = 0; r < world; r++)
-			mine[(size_t)p * per_piece + 1 + r] = slots_fmt[p] ? (uint64_t)(c.sp[p].seg()[r + 1] - c.sp[p].seg()[r]) : c.h_dense.as<uint64_t>()[(size_t)p * world + r];
+	for (int p = 0; p < pieces; p++) {
+		uint64_t* mp = &mine[(size_t)p * per_piece];
+		if (local.code == BLMX_OK) {
+			mp[0] = slots_fmt[p] ? 1 : 0;
+			for (uint32_t r = 0; r < world; r++)
+				mp[1 + r] = slots_fmt[p] ? (uint64_t)(c.sp[p].seg()[r + 1] - c.sp[p].seg()[r]) : c.h_dense.as<uint64_t>()[(size_t)p * world + r];
+		}
+		mp[world + 1] = c.recv_k[p].bytes;  // capacities of this rank's receive buffers: every rank can tell whether somebody has to grow one
+		mp[world + 2] = c.recv_m[p].bytes;
+		mp[world + 3] = c.recv_h[p].bytes;
+		mp[world + 4] = c.ids_remote[p].bytes;
 	}
+	mine[per_rank - 3] = narrow ? 1 : 0;
+	mine[per_rank - 2] = (uint64_t)pieces;
 	mine[per_rank - 1] = local.code != BLMX_OK;
 	all_gather_host(c, mine.data(), per_rank, all.data(), s);
 	for (uint32_t r = 0; r < world; r++)
@@ -682,17 +695,18 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 				throw local;
 			throw StatusError{BLMX_ERCCL, "sharded query: another rank could not take part"};
 		}
+	for (uint32_t r = 0; r < world; r++)  // (every rank sees the same table: all of them give up together, before any flow is posted)
+		if (all[(size_t)r * per_rank + per_rank - 3] != (narrow ? 1u : 0u) || all[(size_t)r * per_rank + per_rank - 2] != (uint64_t)pieces)
+			throw StatusError{BLMX_EINVAL, "sharded query: the ranks disagree on the ID width (narrow_ids) or on the number of pieces (BLIGHT_DIST_CHUNKS / comm tuning)"};
 	auto fmt_of = [&](uint32_t r, int p) { return all[(size_t)r * per_rank + (size_t)p * per_piece] != 0; };
 	auto cnt_of = [&](uint32_t r, int p, uint32_t d) { return all[(size_t)r * per_rank + (size_t)p * per_piece + 1 + d]; };
-	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
-	const size_t idw = narrow ? 1 : 2;  // 32-bit words per slot of a returned slot range
+	auto cap_of = [&](uint32_t r, int p, int which) { return all[(size_t)r * per_rank + (size_t)p * per_piece + world + 1 + which]; };
 	struct Flows {
 		uint64_t ks[16], kr[16], ms[16], mr[16], hs[16], hr[16], is[16], ir[16];  // k-mers / minimizers / headers out and in, IDs back out and in (counts)
 		uint64_t recv_k_words, recv_m_words, recv_h_words, ids_words;
 	} F[kMaxPieces];
 	// header words a sender has for owner d: one per bin of d plus the end of its last region; the bin geometry follows from the shard
 	// boundaries and the index parameters, so it is the same on every rank (also on one that sends densely itself)
-	const uint32_t my_nb = slot_owner_bins(ix, me);
 	for (int p = 0; p < pieces; p++) {
 		for (uint32_t d = 0; d < world; d++) {
 			uint64_t to_d = 0;  // every rank sees the same matrix: all of them give up together
@@ -702,36 +716,69 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 				throw StatusError{BLMX_ELIMIT, "an owner receives fewer than 2^32 - 1 k-mers (or slots) per piece"};
 		}
 	}
-	for (int p = 0; p < pieces; p++) {
-		Flows& f = F[p];
+	// the flows of piece p as rank `who` sees them (every rank can work them out for every rank: the table is the same everywhere)
+	auto flows_of = [&](uint32_t who, int p, Flows& f) {
+		const uint32_t who_nb = slot_owner_bins(ix, who);
 		f.recv_k_words = f.recv_m_words = f.recv_h_words = f.ids_words = 0;
 		for (uint32_t r = 0; r < world; r++) {
-			const bool out_slots = slots_fmt[p], in_slots = fmt_of(r, p);
-			const uint64_t out_n = cnt_of(me, p, r), in_n = cnt_of(r, p, me);
-			const bool self = r == me;
-			// out: what I send to owner r
+			const bool out_slots = fmt_of(who, p), in_slots = fmt_of(r, p);
+			const uint64_t out_n = cnt_of(who, p, r), in_n = cnt_of(r, p, who);
+			const bool self = r == who;
+			// out: what `who` sends to owner r
 			f.ks[r] = (out_slots && self) ? 0 : out_n;                               // k-mers (slots or dense), KW words each
 			f.ms[r] = (out_slots && !self) ? out_n / 2 : 0;                          // minimizers, two per word
 			f.hs[r] = (out_slots && !self) ? (uint64_t)slot_owner_bins(ix, r) + 1 : 0;
 			f.ir[r] = out_slots ? (self ? 0 : out_n * idw / 2) : out_n;              // IDs that come back from owner r (words)
-			// in: what sender r holds for me
+			// in: what sender r holds for `who`
 			f.kr[r] = (in_slots && self) ? 0 : in_n;
 			f.mr[r] = (in_slots && !self) ? in_n / 2 : 0;
-			f.hr[r] = (in_slots && !self) ? (uint64_t)my_nb + 1 : 0;
+			f.hr[r] = (in_slots && !self) ? (uint64_t)who_nb + 1 : 0;
 			f.is[r] = in_slots ? (self ? 0 : in_n * idw / 2) : in_n;
 			f.recv_k_words += f.kr[r] * kw;
 			f.recv_m_words += f.mr[r];
 			f.recv_h_words += f.hr[r];
 			f.ids_words += f.is[r];
 		}
-		grow(c.recv_k[p], f.recv_k_words * 8 + 16, s);
-		grow(c.recv_m[p], f.recv_m_words * 8 + 16, s);
-		grow(c.recv_h[p], f.recv_h_words * 8 + 16, s);
-		grow(c.ids_remote[p], f.ids_words * 8 + 16, s);
-		if (!slots_fmt[p])
-			grow(c.ids_sorted[p], (cut[p + 1] - cut[p]) * 8 + 16, s);
+	};
+	// Somebody has to grow a receive buffer (first batches, a batch larger than its predecessors)?  Then an allocation can fail on one
+	// rank alone AFTER the vote above -- its peers would already be inside the grouped send / receive, and RCCL has no timeout -- so
+	// such a batch takes a second, one-word vote behind the allocations.  In the steady state nobody grows and nobody votes twice.
+	const uint32_t my_nb = slot_owner_bins(ix, me);
+	bool somebody_grows = false;
+	for (uint32_t r = 0; r < world && !somebody_grows; r++)
+		for (int p = 0; p < pieces; p++) {
+			Flows f;
+			flows_of(r, p, f);
+			if (f.recv_k_words * 8 + 16 > cap_of(r, p, 0) || f.recv_m_words * 8 + 16 > cap_of(r, p, 1) || f.recv_h_words * 8 + 16 > cap_of(r, p, 2) ||
+			    f.ids_words * 8 + 16 > cap_of(r, p, 3))
+				somebody_grows = true;
+		}
+	try {
+		for (int p = 0; p < pieces; p++) {
+			Flows& f = F[p];
+			flows_of(me, p, f);
+			grow(c.recv_k[p], f.recv_k_words * 8 + 16, s);
+			grow(c.recv_m[p], f.recv_m_words * 8 + 16, s);
+			grow(c.recv_h[p], f.recv_h_words * 8 + 16, s);
+			grow(c.ids_remote[p], f.ids_words * 8 + 16, s);
+		}
+		BLMX_HIP(hipStreamSynchronize(s));  // buffers that grew must exist before the other stream touches them
+	} catch (const StatusError& err) {
+		if (!somebody_grows)
+			throw;  // (not an allocation: the device is gone, and so is the communicator)
+		local = err;
 	}
-	BLMX_HIP(hipStreamSynchronize(s));  // buffers that grew must exist before the other stream touches them
+	if (somebody_grows) {
+		uint64_t my_vote = local.code != BLMX_OK;
+		std::vector<uint64_t> votes(world, 0);
+		all_gather_host(c, &my_vote, 1, votes.data(), s);
+		for (uint32_t r = 0; r < world; r++)
+			if (votes[r]) {
+				if (local.code != BLMX_OK)
+					throw local;
+				throw StatusError{BLMX_ERCCL, "sharded query: another rank could not allocate its receive buffers"};
+			}
+	}
 	// ---- the pipeline: collectives are issued in the same order on every rank (k-mers 0, k-mers 1, IDs 0, k-mers 2, IDs 1, ...)
 	auto send_kmers = [&](int p) {
 		const Flows& f = F[p];

@@ -83,10 +83,12 @@ struct DeviceIndexView {
 // again), and once a process has allocated as much as the card holds a call has to wait for VRAM the driver has not finished
 // reclaiming: 2.9-3.4 s, measured on every fourth or fifth C4-size build in a row (profiles/r03_exp_slow_hipmalloc.txt).
 //
-// ScratchCache (process-wide): device blocks of 1 MiB and more that a finished build, a destroyed index or a staging buffer gave up
-// are parked here -- up to `cap` bytes, default 1/6 of the device's memory, BLIGHT_SCRATCH_CACHE_GB -- and serve the next request
+// ScratchCache (process-wide, per device): device blocks of 1 MiB and more that a finished build, a destroyed index or a staging buffer
+// gave up are parked here -- up to a cap per device, default 1/16 of its memory, BLIGHT_SCRATCH_CACHE_GB -- and serve the next request
 // they fit: a build's temporaries with a loose fit, index arrays and staging buffers (DevBuf outside a pool) with a tight one, so
-// that an index reports and writes the sizes it asked for.  blmx_release_scratch, and any allocation that fails, empty it.
+// that an index reports and writes the sizes it asked for.  blmx_release_scratch, and any allocation that fails INSIDE this library,
+// empty it; an allocator that shares the card (torch's) does not know about it: such a process calls blmx_release_scratch when its
+// own allocation fails, or keeps the cap small.
 //
 // BuildPool (below): the cache of ONE build.  A human-scale build allocates ~60 temporaries whose lifetimes barely overlap; blocks
 // released by one are handed to the next request they fit (all work of a build is on one stream, so reuse is ordered), and what is
@@ -97,67 +99,97 @@ struct ScratchCache {
 		size_t bytes;
 		int device;
 	};
+	static constexpr int kMaxDevices = 64;
 	std::mutex mu;
-	std::vector<Block> blocks;
-	size_t held = 0;
-	long long cap = -1;  // -1 = not decided yet
+	std::vector<Block> blocks;   // free: nothing on the device touches them any more
+	std::vector<Block> pending;  // given up while work that uses them may still be queued: usable after the next device-wide synchronisation
+	size_t held[kMaxDevices] = {};     // bytes parked per device (free + pending)
+	long long cap[kMaxDevices];        // per device; -1 = not decided yet
+	ScratchCache()
+	{
+		for (long long& c : cap)
+			c = -1;
+	}
 	static ScratchCache& get()
 	{
 		static ScratchCache* c = new ScratchCache();  // never destroyed (the HIP runtime may be gone when static destructors run)
 		return *c;
 	}
-	void give(void* p, size_t bytes)
+	// cap of one device: BLIGHT_SCRATCH_CACHE_GB, else 1/16 of the device's memory (18 GB of an MI355X's 288: what a process that
+	// shares the card with another allocator -- torch's caching allocator, a host application -- can be expected to leave parked;
+	// a process that builds human-scale indexes in a row raises it, bench.py does and says so)
+	long long cap_of(int dev)
+	{
+		if (cap[dev] < 0) {
+			const char* e = getenv("BLIGHT_SCRATCH_CACHE_GB");
+			size_t fr = 0, tot = 0;
+			if (e)
+				cap[dev] = (long long)(atof(e) * 1e9);
+			else
+				cap[dev] = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 16) : 0;
+		}
+		return cap[dev];
+	}
+	void give(void* p, size_t bytes, bool in_use = false)
 	{
 		int dev = 0;
-		if (hipGetDevice(&dev) == hipSuccess) {
+		if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) {
 			std::lock_guard<std::mutex> lock(mu);
-			if (cap < 0) {
-				const char* e = getenv("BLIGHT_SCRATCH_CACHE_GB");
-				size_t fr = 0, tot = 0;
-				if (e)
-					cap = (long long)(atof(e) * 1e9);
-				else
-					cap = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 6) : 0;
-			}
-			if ((long long)(held + bytes) <= cap) {
-				blocks.push_back({p, bytes, dev});
-				held += bytes;
+			if ((long long)(held[dev] + bytes) <= cap_of(dev)) {
+				(in_use ? pending : blocks).push_back({p, bytes, dev});
+				held[dev] += bytes;
 				return;
 			}
 		}
 		(void)hipFree(p);
 	}
-	// tight: index arrays and staging buffers (what they hold is what the index reports) take a block at most 1/8 larger
+	// tight: index arrays and staging buffers (what they hold is what the index reports) take a block at most 1/8 larger; build
+	// temporaries one at most twice as large (or 1 MiB larger: a byte-sized temporary does not pin a 64-MiB block)
 	bool take(size_t n, void** p, size_t* bytes, bool tight = false)
 	{
 		int dev = 0;
-		if (hipGetDevice(&dev) != hipSuccess)
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
 			return false;
-		const size_t most = tight ? n + n / 8 + (1u << 20) : 2 * n + (64u << 20);
-		std::lock_guard<std::mutex> lock(mu);
-		size_t best = blocks.size();
-		for (size_t i = 0; i < blocks.size(); i++)
-			if (blocks[i].device == dev && blocks[i].bytes >= n && blocks[i].bytes <= most &&
-			    (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
-				best = i;
-		if (best == blocks.size())
-			return false;
+		const size_t most = tight ? n + n / 8 + (1u << 20) : std::max(2 * n, n + (size_t)(1u << 20));
+		std::unique_lock<std::mutex> lock(mu);
+		auto best_of = [&](const std::vector<Block>& v) {
+			size_t best = v.size();
+			for (size_t i = 0; i < v.size(); i++)
+				if (v[i].device == dev && v[i].bytes >= n && v[i].bytes <= most && (best == v.size() || v[i].bytes < v[best].bytes))
+					best = i;
+			return best;
+		};
+		size_t best = best_of(blocks);
+		if (best == blocks.size()) {
+			if (best_of(pending) == pending.size())
+				return false;
+			// a block that was given up with work possibly still queued on it: wait for the device ONCE, here, where a block is about to be
+			// reused (an allocation would have cost more) -- not at every release, which stalled every stream and thread of the process
+			lock.unlock();
+			(void)hipDeviceSynchronize();
+			lock.lock();
+			for (const Block& b : pending)
+				blocks.push_back(b);
+			pending.clear();
+			best = best_of(blocks);
+			if (best == blocks.size())
+				return false;  // (another thread took it meanwhile)
+		}
 		*p = blocks[best].p;
 		*bytes = blocks[best].bytes;
-		held -= blocks[best].bytes;
+		held[dev] -= std::min(held[dev], blocks[best].bytes);
 		blocks.erase(blocks.begin() + (long)best);
 		return true;
 	}
-	// a buffer that did not come from a build's pool (index array, staging, query scratch): kernels that use it may still be running
-	// -- hipFree would wait for them, so does this
+	// a buffer that did not come from a build's pool (index array, staging, query scratch): kernels that use it may still be queued.
+	// Small ones go back to the driver (hipFree waits for the device itself); large ones are parked as `pending`.
 	void give_synced(void* p, size_t bytes)
 	{
 		if (bytes < kMinBytes) {
 			(void)hipFree(p);
 			return;
 		}
-		(void)hipDeviceSynchronize();
-		give(p, bytes);
+		give(p, bytes, true);
 	}
 	static constexpr size_t kMinBytes = 1u << 20;
 	size_t release_all()  // everything back to the driver; returns the bytes released
@@ -166,13 +198,22 @@ struct ScratchCache {
 		{
 			std::lock_guard<std::mutex> lock(mu);
 			mine.swap(blocks);
-			held = 0;
+			mine.insert(mine.end(), pending.begin(), pending.end());
+			pending.clear();
+			for (size_t& h : held)
+				h = 0;
 		}
 		size_t n = 0;
+		int cur = 0;
+		const bool have_cur = hipGetDevice(&cur) == hipSuccess;
 		for (const Block& b : mine) {
-			(void)hipFree(b.p);
+			if (have_cur && b.device != cur)
+				(void)hipSetDevice(b.device);
+			(void)hipFree(b.p);  // (waits for the device: pending blocks are safe to free)
 			n += b.bytes;
 		}
+		if (have_cur)
+			(void)hipSetDevice(cur);
 		return n;
 	}
 };
@@ -455,6 +496,7 @@ struct Index {
 	// every later call on this index.  test_ovf_cap (test hook) shrinks the overflow region to provoke it.
 	unsigned long long* h_dropped = nullptr;
 	int tune_test_ovf_cap = 0;
+	int tune_max_batch = 0;  // test hook: k-mers per piece of a device-resident batch (0 = 2^30)
 	unsigned long long* dropped_word()
 	{
 		if (!h_dropped) {

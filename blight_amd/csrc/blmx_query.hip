@@ -1652,11 +1652,24 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	partition_end(ix, s);
 }
 
-void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s) { query_ids_pipeline(ix, d_kmers, nullptr, nq, d_out, s); }
+// Device-resident batches of any size: the pipeline numbers slots and k-mers with 32 bits, so a batch above 2^30 k-mers is answered
+// piece by piece, like the host-buffer calls do with their windows (max_batch: test hook that lowers the piece size).
+static void query_ids_chunked(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, hipStream_t s)
+{
+	const uint64_t piece = ix.tune_max_batch > 0 ? (uint64_t)ix.tune_max_batch : (1ull << 30);
+	for (uint64_t at = 0; at < nq || at == 0; at += piece) {
+		const uint64_t n = std::min(piece, nq - at);
+		query_ids_pipeline(ix, reinterpret_cast<const uint64_t*>(d_kmers) + at * (uint64_t)ix.KW, d_minis ? d_minis + at : nullptr, n, d_out + at, s);
+		if (nq == 0)
+			break;
+	}
+}
+
+void launch_query_ids_auto(Index& ix, const void* d_kmers, uint64_t nq, int64_t* d_out, hipStream_t s) { query_ids_chunked(ix, d_kmers, nullptr, nq, d_out, s); }
 
 void launch_query_ids_with_minis(Index& ix, const void* d_kmers, const uint32_t* d_minis, uint64_t nq, int64_t* d_out, hipStream_t s)
 {
-	query_ids_pipeline(ix, d_kmers, d_minis, nq, d_out, s);
+	query_ids_chunked(ix, d_kmers, d_minis, nq, d_out, s);
 }
 
 // ---- the three stages as separate entry points: the sharded exchange (blight_amd/dist.py) partitions on the rank that

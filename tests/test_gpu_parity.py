@@ -656,3 +656,30 @@ def test_a_kmer_without_a_slot_fails_the_call(B):
     ix.set_tuning("test_ovf_cap", 0)
     assert np.array_equal(ix.query_kmer_hash(skew), np.full(1 << 20, ids[0]))
     assert np.array_equal(ix.query_kmer_hash(big), ids)
+
+
+def test_device_batches_of_any_size_are_answered_in_pieces(B, O):
+    """A device-resident batch above 2^30 k-mers is answered piece by piece (the partition numbers slots with 32 bits); with the piece
+    size lowered to 2^20 (test hook) a batch of 3 * 2^20 + 17 k-mers goes through four pieces, the last one ragged, with and without
+    the partitioned pipeline, and equals the oracle."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(9)
+    seqs = [_rand_seq(rng, 300) for _ in range(4000)]
+    ix = _build(B, 31, 9, 6, 6, seqs)
+    orc = O.Oracle(31, 9, 6, 6, seqs)
+    q = np.concatenate([orc.canonical_kmers(s).reshape(-1) for s in seqs[:1500]])
+    neg = rng.integers(0, 1 << 62, size=len(q) // 2, dtype=np.uint64)
+    neg = np.array([min(int(x), O.p_rc(int(x), 31, 8)) for x in neg[:20000]], dtype=np.uint64)
+    allq = np.concatenate([q, neg])
+    n = 3 * (1 << 20) + 17
+    allq = np.tile(allq, n // len(allq) + 1)[:n]
+    want = orc.query_kmers(allq)
+    dq = torch.from_numpy(allq.view(np.int64)).cuda()
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    ix.set_tuning("max_batch", 1 << 20)
+    for pol in (1, 1, -1):
+        ix.set_query_binning(pol)
+        out.fill_(-7)
+        ix.query_kmers_device(dq.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want), pol
