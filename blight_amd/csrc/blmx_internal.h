@@ -101,9 +101,8 @@ struct ScratchCache {
 	};
 	static constexpr int kMaxDevices = 64;
 	std::mutex mu;
-	std::vector<Block> blocks;   // free: nothing on the device touches them any more
-	std::vector<Block> pending;  // given up while work that uses them may still be queued: usable after the next device-wide synchronisation
-	size_t held[kMaxDevices] = {};     // bytes parked per device (free + pending)
+	std::vector<Block> blocks;         // nothing on the device touches them any more
+	size_t held[kMaxDevices] = {};     // bytes parked per device
 	long long cap[kMaxDevices];        // per device; -1 = not decided yet
 	ScratchCache()
 	{
@@ -130,13 +129,13 @@ struct ScratchCache {
 		}
 		return cap[dev];
 	}
-	void give(void* p, size_t bytes, bool in_use = false)
+	void give(void* p, size_t bytes)
 	{
 		int dev = 0;
 		if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) {
 			std::lock_guard<std::mutex> lock(mu);
 			if ((long long)(held[dev] + bytes) <= cap_of(dev)) {
-				(in_use ? pending : blocks).push_back({p, bytes, dev});
+				blocks.push_back({p, bytes, dev});
 				held[dev] += bytes;
 				return;
 			}
@@ -151,45 +150,32 @@ struct ScratchCache {
 		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
 			return false;
 		const size_t most = tight ? n + n / 8 + (1u << 20) : std::max(2 * n, n + (size_t)(1u << 20));
-		std::unique_lock<std::mutex> lock(mu);
-		auto best_of = [&](const std::vector<Block>& v) {
-			size_t best = v.size();
-			for (size_t i = 0; i < v.size(); i++)
-				if (v[i].device == dev && v[i].bytes >= n && v[i].bytes <= most && (best == v.size() || v[i].bytes < v[best].bytes))
-					best = i;
-			return best;
-		};
-		size_t best = best_of(blocks);
-		if (best == blocks.size()) {
-			if (best_of(pending) == pending.size())
-				return false;
-			// a block that was given up with work possibly still queued on it: wait for the device ONCE, here, where a block is about to be
-			// reused (an allocation would have cost more) -- not at every release, which stalled every stream and thread of the process
-			lock.unlock();
-			(void)hipDeviceSynchronize();
-			lock.lock();
-			for (const Block& b : pending)
-				blocks.push_back(b);
-			pending.clear();
-			best = best_of(blocks);
-			if (best == blocks.size())
-				return false;  // (another thread took it meanwhile)
-		}
+		std::lock_guard<std::mutex> lock(mu);
+		size_t best = blocks.size();
+		for (size_t i = 0; i < blocks.size(); i++)
+			if (blocks[i].device == dev && blocks[i].bytes >= n && blocks[i].bytes <= most && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
+				best = i;
+		if (best == blocks.size())
+			return false;
 		*p = blocks[best].p;
 		*bytes = blocks[best].bytes;
 		held[dev] -= std::min(held[dev], blocks[best].bytes);
 		blocks.erase(blocks.begin() + (long)best);
 		return true;
 	}
-	// a buffer that did not come from a build's pool (index array, staging, query scratch): kernels that use it may still be queued.
-	// Small ones go back to the driver (hipFree waits for the device itself); large ones are parked as `pending`.
+	// a buffer that did not come from a build's pool (index array, staging, query scratch): kernels that use it may still be queued --
+	// hipFree would wait for them, and so does this (callers rely on exactly that: a buffer that grows in the middle of a multi-stream
+	// pipeline is only given up once everything queued before has finished).  Parking such blocks without the wait and synchronising
+	// when one is taken again was tried in r04: a file query that followed other tests in one process then lost 84 of 8.4e7 k-mers --
+	// the wait is part of what `release` means to the code around it.
 	void give_synced(void* p, size_t bytes)
 	{
 		if (bytes < kMinBytes) {
 			(void)hipFree(p);
 			return;
 		}
-		give(p, bytes, true);
+		(void)hipDeviceSynchronize();
+		give(p, bytes);
 	}
 	static constexpr size_t kMinBytes = 1u << 20;
 	size_t release_all()  // everything back to the driver; returns the bytes released
@@ -198,8 +184,6 @@ struct ScratchCache {
 		{
 			std::lock_guard<std::mutex> lock(mu);
 			mine.swap(blocks);
-			mine.insert(mine.end(), pending.begin(), pending.end());
-			pending.clear();
 			for (size_t& h : held)
 				h = 0;
 		}
@@ -209,7 +193,7 @@ struct ScratchCache {
 		for (const Block& b : mine) {
 			if (have_cur && b.device != cur)
 				(void)hipSetDevice(b.device);
-			(void)hipFree(b.p);  // (waits for the device: pending blocks are safe to free)
+			(void)hipFree(b.p);
 			n += b.bytes;
 		}
 		if (have_cur)
