@@ -143,17 +143,13 @@ struct ScratchCache {
 		(void)hipFree(p);
 	}
 	// tight: index arrays and staging buffers (what they hold is what the index reports) take a block at most 1/8 larger; build
-	// temporaries one at most twice as large + 64 MiB
+	// temporaries one at most twice as large (or 1 MiB larger: a byte-sized temporary does not pin a 64-MiB block)
 	bool take(size_t n, void** p, size_t* bytes, bool tight = false)
 	{
 		int dev = 0;
 		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
 			return false;
-		// (r04: a tighter loose fit -- max(2n, n + 1 MiB) -- sends more of a build's small temporaries to hipMalloc, whose fresh pages
-		// make the first kernels that touch them slower; with that timing the file-query test of tests/test_gpu_fullsize.py lost k-mers
-		// when it ran behind the CLI and front-end tests in one process, and not with BLIGHT_POISON=1, which touches every page first:
-		// a timing dependence in the multi-stream window pipeline that is NOT understood yet.  The r03 rule stays.)
-		const size_t most = tight ? n + n / 8 + (1u << 20) : 2 * n + (64u << 20);
+		const size_t most = tight ? n + n / 8 + (1u << 20) : std::max(2 * n, n + (size_t)(1u << 20));
 		std::lock_guard<std::mutex> lock(mu);
 		size_t best = blocks.size();
 		for (size_t i = 0; i < blocks.size(); i++)
@@ -168,10 +164,8 @@ struct ScratchCache {
 		return true;
 	}
 	// a buffer that did not come from a build's pool (index array, staging, query scratch): kernels that use it may still be queued --
-	// hipFree would wait for them, and so does this (callers rely on exactly that: a buffer that grows in the middle of a multi-stream
-	// pipeline is only given up once everything queued before has finished).  Parking such blocks without the wait and synchronising
-	// when one is taken again was tried in r04: a file query that followed other tests in one process then lost 84 of 8.4e7 k-mers --
-	// the wait is part of what `release` means to the code around it.
+	// hipFree would wait for them, and so does this: a buffer that grows in the middle of a multi-stream pipeline is only handed to
+	// somebody else once everything queued before has finished
 	void give_synced(void* p, size_t bytes)
 	{
 		if (bytes < kMinBytes) {

@@ -605,7 +605,8 @@ __global__ __launch_bounds__(1 << kBinBitsMax) void k_plan_make(const float* __r
 		const uint32_t b = t * BPT + j;
 		cap[j] = 0;
 		if (b < nbins) {
-			const double share = frac ? (double)frac[b] * (double)nq : (double)nq / (double)nbins;
+			double share = frac ? (double)frac[b] * (double)nq : (double)nq / (double)nbins;
+			share = share >= 0.0 ? (share <= (double)nq ? share : (double)nq) : 0.0;  // (whatever the share table holds: regions stay regions)
 			const double want = share * (100.0 + (double)slack_pct) / 100.0 + 256.0;
 			cap[j] = (uint32_t)(((uint64_t)want + 255u) & ~255ull);
 		}
@@ -1583,7 +1584,7 @@ void slot_piece_gather(Index& ix, SlotPiece& sp, int64_t* d_out, hipStream_t s)
 			hipLaunchKernelGGL((k_gather_runs<BinTile<2>::value, false, 1>), dim3(sp.nblk), dim3(kBinThreads), 0, s, d_plan, rt, d_lpos, sp.ids.p, sp.nq, d_out);
 	}
 	BLMX_HIP(hipGetLastError());
-	ensure_buf(ix.b_frac_sharded, sizeof(float) << kBinBitsMax, s);
+	ensure_buf(ix.b_frac_sharded, sizeof(float) << kBinBitsSlots, s);
 	if (!ix.b_pstats.p)
 		BLMX_HIP(ix.b_pstats.alloc(64, true, s));
 	hipLaunchKernelGGL(k_plan_learn, dim3((sp.nbins + 255) / 256), dim3(256), 0, s, sp.cursors.as<uint32_t>(), sp.nq, sp.nbins, ix.b_frac_sharded.as<float>(),
@@ -1645,7 +1646,7 @@ static void query_ids_pipeline(Index& ix, const void* d_kmers, const uint32_t* d
 	ix.prof_mark(6, s);
 	update_filter_gate(ix, d_out, nq, s);
 	if (onepass_ok && ix.tune_partition == 0 && pl.bm.nbound == 0 && (int)pl.nbins == (1 << onepass_bits(ix))) {  // the next batch can skip the histogram
-		ensure_buf(ix.b_frac, sizeof(float) << kBinBitsMax, s);
+		ensure_buf(ix.b_frac, sizeof(float) << kBinBitsSlots, s);
 		hipLaunchKernelGGL(k_plan_learn_offs, dim3((pl.nbins + 255) / 256), dim3(256), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, nq, pl.nbins, ix.b_frac.as<float>());
 		ix.plan_bits = onepass_bits(ix);
 	}
@@ -1700,7 +1701,7 @@ void launch_partition(Index& ix, const void* d_kmers, uint64_t nq, void* d_sorte
 		BLMX_HIP(hipGetLastError());
 	}
 	if (ix.tune_partition != 2 && ix.prm.bits_saved <= 8) {  // what the one-pass partition of the next sharded batch sizes its regions after
-		ensure_buf(ix.b_frac_sharded, sizeof(float) << kBinBitsMax, s);
+		ensure_buf(ix.b_frac_sharded, sizeof(float) << kBinBitsSlots, s);
 		hipLaunchKernelGGL(k_plan_learn_offs, dim3((pl.nbins + 255) / 256), dim3(256), 0, s, ix.b_offs.as<uint32_t>(), pl.nblk, nq, pl.nbins,
 		                   ix.b_frac_sharded.as<float>());
 		ix.plan_nbins_sharded = pl.nbins;
