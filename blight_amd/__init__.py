@@ -128,6 +128,7 @@ def load_library():
     lib.blmx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.blmx_stats.argtypes = [C.c_void_p, C.POINTER(blmx_stats_t)]
     lib.blmx_partition_stats.argtypes = [C.c_void_p, _u64p, C.c_int]
+    lib.blmx_serve_stats.argtypes = [C.c_void_p, _u64p]
     lib.blmx_release_scratch.argtypes = [_u64p, _u64p]
     lib.blmx_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     lib.blmx_export.restype = C.c_int64
@@ -257,6 +258,12 @@ class kmer_Set_Light:
         st = blmx_stats_t()
         self._check(self._lib.blmx_stats(self._h, C.byref(st)))
         return {f[0]: getattr(st, f[0]) for f in blmx_stats_t._fields_}
+
+    def serve_stats(self):
+        """the bounded serving burst of small calls: {kernels, calls, relaunches_after_deadline, alive}"""
+        a = np.zeros(4, dtype=np.uint64)
+        self._check(self._lib.blmx_serve_stats(self._h, a.ctypes.data_as(_u64p)))
+        return {"kernels": int(a[0]), "calls": int(a[1]), "relaunches_after_deadline": int(a[2]), "alive": bool(a[3])}
 
     def partition_stats(self, reset=False):
         """one-pass partition: {batches, kmers, overflow_kmers, max_overflow_of_a_batch} since the last reset"""

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libblight_mi355x.so")
-SOURCES = ["blmx_api.hip", "blmx_build.hip", "blmx_query.hip", "blmx_reads.hip", "blmx_front.hip", "blmx_stream.hip", "blmx_comm.hip"]
+SOURCES = ["blmx_api.hip", "blmx_build.hip", "blmx_query.hip", "blmx_reads.hip", "blmx_front.hip", "blmx_stream.hip", "blmx_comm.hip", "blmx_serve.hip"]
 HEADERS = ["blmx_internal.h", "device_prims.h", "index_device.h", "query_device.h", os.path.join(ROOT, "include", "blight_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-DNDEBUG",

@@ -207,6 +207,7 @@ int blmx_create(const blmx_params* p, blmx_index** out)
 	h->ix.tune_partition = env_int("BLIGHT_PARTITION", 0);
 	h->ix.tune_window_kb = env_int("BLIGHT_WINDOW_KB", 0);
 	h->ix.tune_fat_lines = env_int("BLIGHT_FAT_LINES", -1);
+	h->ix.tune_serve_burst = env_int("BLIGHT_SERVE_BURST", 1);
 	h->ix.tune_build_passes = env_int("BLIGHT_BUILD_PASSES", 0);
 	if (hipSetDevice(prm.device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
 		g_create_err = "hipStreamCreate failed";
@@ -223,6 +224,7 @@ void blmx_destroy(blmx_index* h)
 		return;
 	(void)hipSetDevice(h->ix.prm.device);
 	(void)hipDeviceSynchronize();  // device-pointer calls may still be running on the caller's streams
+	burst_destroy(h->ix);
 	destroy_host_front(h->ix.hf);
 	h->ix.hf = nullptr;
 	shard_build_abort(h->ix);
@@ -826,6 +828,12 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_window_kb = value;
 	else if (k == "slot_piece_min")
 		ix.tune_slot_piece_min = value;
+	else if (k == "serve_burst") {  // 0: small calls take one launch per round of the combiner (r03); 1: the bounded serving kernel
+		if (!value)
+			burst_stop(ix);
+		ix.tune_serve_burst = value != 0;
+	} else if (k == "fb_table")  // before building / loading: 0 = no hash tables over the fallback entries (lookups search the sorted arrays)
+		ix.tune_fb_table = value != 0;
 	else if (k == "max_batch")  // test hook: device-resident batches are answered in pieces of this many k-mers (0 = 2^30)
 		ix.tune_max_batch = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
 	else if (k == "test_ovf_cap")  // test hook: slots of the one-pass partition's overflow region (0 = a whole batch)
@@ -838,6 +846,14 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.bin_policy = value < 0 ? -1 : (value > 0 ? 1 : 0);
 	else
 		return fail(h, BLMX_EINVAL, "unknown tuning key");
+	return BLMX_OK;
+}
+
+int blmx_serve_stats(blmx_index* h, uint64_t* out4)
+{
+	if (!h || !out4)
+		return BLMX_EINVAL;
+	burst_stats(h->ix, out4);
 	return BLMX_OK;
 }
 

@@ -2405,6 +2405,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	// final group table (with the fallback ranges)
 	BLMX_HIP(hipMemcpyAsync(ix.groups.p, ix.h_groups.data(), (size_t)ngroups * sizeof(GroupDesc), hipMemcpyHostToDevice, s));
 	make_query_heads(ix);
+	make_fallback_table(ix, s);
 	v = ix.view();
 	v.filter = have_filter ? (fat ? ix.lines.as<uint64_t>() : ix.filter.as<uint64_t>()) : nullptr;
 	v.id_base = id_base;
@@ -2495,7 +2496,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	st.kmer_bytes = (uint32_t)(8 * KW);
 	st.max_levels_used = (uint32_t)levels_used;
 	st.device_bytes = ix.buckets.bytes + ix.groups.bytes + ix.qheads.bytes + ix.seq.bytes + ix.positions.bytes + ix.lines.bytes + ix.filter.bytes + ix.fb_keys.bytes +
-	                  ix.fb_ranks.bytes;
+	                  ix.fb_ranks.bytes + ix.fb_table.bytes + ix.fb_dir.bytes;
 	st.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -2865,6 +2866,71 @@ void init_filter_gate(Index& ix, hipStream_t s)
 	BLMX_HIP(ix.filter_gate.alloc(64, true, s));
 	BLMX_HIP(hipMemcpyAsync(ix.filter_gate.p, &one, 4, hipMemcpyHostToDevice, s));
 	BLMX_HIP(hipStreamSynchronize(s));
+}
+
+// One lane per fallback entry (sorted by group, key, input order): the LAST entry of a run of equal keys claims a slot of its group's
+// table by its rank word (all keys that are inserted differ, so a claimed slot is somebody else's: next slot) and writes its key.
+template <int KW>
+__global__ void k_fb_table_insert(const uint64_t* __restrict__ fk, const uint64_t* __restrict__ frank, const uint32_t* __restrict__ fgrp, uint64_t F,
+                                  const uint64_t* __restrict__ dir, unsigned long long* __restrict__ table)
+{
+	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= F)
+		return;
+	const uint32_t g = fgrp[e];
+	const Kmer<KW> x = load_kmer<KW>(fk, e);
+	if (e + 1 < F && fgrp[e + 1] == g && load_kmer<KW>(fk, e + 1) == x)
+		return;  // an earlier assignment of a duplicated key: overwritten in the reference's map (bbhash.h:724)
+	const uint64_t d = dir[g], first = d & 0x00ffffffffffffffull, mask = (1ull << (d >> 56)) - 1ull;
+	constexpr int W = FbSlot<KW>::words;
+	uint64_t at = fb_mix(x.lo, kmer_hi(x)) & mask;
+	for (;;) {
+		unsigned long long* sl = table + (first + at) * W;
+		if (atomicCAS(&sl[W == 2 ? 1 : 2], (unsigned long long)kNotFound, (unsigned long long)frank[e]) == (unsigned long long)kNotFound) {
+			sl[0] = x.lo;
+			if constexpr (KW == 2)
+				sl[1] = x.hi;
+			return;
+		}
+		at = (at + 1) & mask;
+	}
+}
+
+void make_fallback_table(Index& ix, hipStream_t s)
+{
+	ix.fb_table.release();
+	ix.fb_dir.release();
+	const uint64_t F = ix.h_fb_group.size();
+	if (F == 0 || ix.tune_fb_table == 0)
+		return;
+	std::vector<uint64_t> dir(ix.ngroups, 0);
+	uint64_t slots = 0;
+	for (uint32_t g = 0; g < ix.ngroups; g++) {
+		const uint64_t c = ix.h_groups[g].fb_count;
+		if (!c)
+			continue;
+		uint32_t lg = 1;
+		while ((1ull << lg) * 2 < c * 3)  // at least 1.5 slots per entry (duplicates included: an upper bound of what is inserted)
+			lg++;
+		dir[g] = slots | ((uint64_t)lg << 56);
+		slots += 1ull << lg;
+	}
+	const size_t W = ix.KW == 1 ? 2 : 4;
+	BLMX_HIP(ix.fb_table.alloc(slots * W * 8 + 64, false, s));
+	BLMX_HIP(hipMemsetAsync(ix.fb_table.p, 0xff, slots * W * 8 + 64, s));  // every rank word = kNotFound: empty
+	BLMX_HIP(ix.fb_dir.alloc((size_t)ix.ngroups * 8, false, s));
+	BLMX_HIP(hipMemcpyAsync(ix.fb_dir.p, dir.data(), (size_t)ix.ngroups * 8, hipMemcpyHostToDevice, s));
+	DevBuf d_grp;
+	BLMX_HIP(d_grp.alloc(F * 4, false, s));
+	BLMX_HIP(hipMemcpyAsync(d_grp.p, ix.h_fb_group.data(), F * 4, hipMemcpyHostToDevice, s));
+	if (ix.KW == 1)
+		hipLaunchKernelGGL((k_fb_table_insert<1>), dim3(grid_for(F)), dim3(kBlock), 0, s, ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_grp.as<uint32_t>(), F,
+		                   ix.fb_dir.as<uint64_t>(), ix.fb_table.as<unsigned long long>());
+	else
+		hipLaunchKernelGGL((k_fb_table_insert<2>), dim3(grid_for(F)), dim3(kBlock), 0, s, ix.fb_keys.as<uint64_t>(), ix.fb_ranks.as<uint64_t>(), d_grp.as<uint32_t>(), F,
+		                   ix.fb_dir.as<uint64_t>(), ix.fb_table.as<unsigned long long>());
+	BLMX_HIP(hipGetLastError());
+	BLMX_HIP(hipStreamSynchronize(s));  // (dir and d_grp go out of scope)
 }
 
 void make_query_heads(Index& ix)

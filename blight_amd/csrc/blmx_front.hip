@@ -695,6 +695,8 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 	BLMX_HIP(hipSetDevice(ix.prm.device));
 	HostFront& hf = host_front(ix);
 	// ---- one launch on a pinned slot
+	if (nseq == 1 && burst_query_sequence(ix, concat + a0, total - a0, nk_all, ids_out))  // one read: the serving burst (blmx_serve.hip)
+		return;
 	if (total - a0 <= kSmallChars && nseq <= kSmallSeqs && nk_all <= 48000 && read_query_fusable(ix)) {
 		SmallReq rq;  // answered by ONE launch together with whatever other callers are waiting (combine_small)
 		rq.kind = SmallReq::kSequences;
@@ -916,6 +918,8 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 	HostFront& hf = host_front(ix);
 	const size_t kb = (size_t)ix.KW * 8;
 	const size_t ob = mode == kQueryIds ? 8 : (mode == kQueryPos ? 4 : 1);
+	if (!minis && (mode == kQueryIds || mode == kQueryBool) && burst_query_kmers(ix, kmers, nq, out, mode == kQueryBool))  // blmx_serve.hip
+		return;
 	if (nq <= kSmallKmers && !minis && (mode == kQueryIds || mode == kQueryBool) && ix.prm.bits_saved <= 8) {
 		SmallReq rq;  // scalar calls of the facade land here: answered by ONE launch together with whatever other callers are waiting
 		rq.kind = SmallReq::kKmers;

@@ -66,6 +66,10 @@ struct DeviceIndexView {
 	const uint64_t* lines;      // MPHF lines: [rank | 7 data words]
 	const uint64_t* fb_keys;    // fallback keys (KW words each), sorted by (group, key)
 	const uint64_t* fb_ranks;
+	// the fallback entries once more as per-group open-addressing tables (index_device.h: fallback_find); fb_dir[g] = first slot of the
+	// group's table (low 56 bits) | log2 of its slots (high 8 bits), 0 = the group has no fallback keys
+	const uint64_t* fb_table;
+	const uint64_t* fb_dir;
 	uint64_t total_nt;
 	// absent-key filter (blocked Bloom filter over the keys of this index, one 64-bit block per probe; nullptr = off)
 	const uint64_t* filter;
@@ -374,6 +378,7 @@ struct FrontScratch {
 	DevBuf lpre;   // raw, construction: per line, sequences and characters of the window's sequence lines before it
 	DevBuf stage;  // raw, construction: the window's sequence characters, compacted, on their way into the 2-bit text
 };
+struct BurstState;  // blmx_serve.hip: the bounded serving burst of small calls (request ring in pinned memory)
 struct HostFront;  // blmx_stream.hip: pinned staging, window slots, small-call slots and worker threads of one index
 void destroy_host_front(HostFront*);
 
@@ -399,11 +404,13 @@ struct Index {
 	std::mutex mu;  // serialises the large host-buffer / file operations (they share the window slots)
 	std::atomic<uint64_t> number_query{0};  // blight.h:56; incremented atomically like the reference (blight.cpp:687-688, 717-718)
 	HostFront* hf = nullptr;                // created on first use (blmx_stream.hip)
+	BurstState* burst = nullptr;            // created on first use (blmx_serve.hip)
+	int tune_serve_burst = 1;               // small calls are answered by a bounded serving kernel (0: one launch per round of the combiner)
 	ShardExchange* xb = nullptr;            // state of a sharded build between its phases (blmx_build.hip)
 	std::mutex hf_mu;
 
 	// finished index (HBM)
-	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks, filter, filter_gate;
+	DevBuf buckets, groups, qheads, seq, positions, lines, fb_keys, fb_ranks, fb_table, fb_dir, filter, filter_gate;
 	uint64_t filter_words = 0;
 	uint32_t filter_bpk = 0;   // bits per key the filter was built with (0 = none)
 	bool fat_lines = false;    // level-0 lines carry the filter (64-B lines; no separate filter array)
@@ -534,12 +541,13 @@ struct Index {
 	int tune_fat_lines = -1;     // build: with 8 filter bits per key the filter lives inside 64-B level-0 units: 0 = separate filter array and 16-B
 	                             // lines, 1 = fat lines (96 level bits + filter), 2 = records (32 level bits + filter + position fields),
 	                             // -1 = automatic = fat lines (records measured slower on a 50/50 batch, profiles/r04_exp_level0_layouts_c4.txt)
+	int tune_fb_table = 1;       // the fallback entries also as per-group hash tables (0: lookups search the sorted entries, as in r03)
 	int tune_build_passes = 0;   // build: passes over ranges of MPHF groups (0 = automatic: at most 2^log2_superbuckets, <= 2^30 keys per pass)
 	int tune_slot_piece_min = 0; // sharded exchange: pieces of at least this many k-mers travel as bin regions (0 = default 2^19; tests lower it)
 
 	Index()
 	{
-		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks, &filter, &filter_gate})
+		for (DevBuf* b : {&buckets, &groups, &qheads, &seq, &positions, &lines, &fb_keys, &fb_ranks, &fb_table, &fb_dir, &filter, &filter_gate})
 			b->persistent = true;
 	}
 
@@ -577,6 +585,8 @@ struct Index {
 		v.lines = lines.as<uint64_t>();
 		v.fb_keys = fb_keys.as<uint64_t>();
 		v.fb_ranks = fb_ranks.as<uint64_t>();
+		v.fb_table = fb_table.as<uint64_t>();
+		v.fb_dir = fb_dir.p ? fb_dir.as<uint64_t>() : nullptr;
 		v.total_nt = st.total_nt;
 		v.fat = fat_lines;
 		v.rec = rec_lines;
@@ -600,6 +610,7 @@ struct DoneSignal {
 
 // build (blmx_build.hip)
 void make_query_heads(Index& ix);  // from ix.h_groups, after the group table is final (build and load)
+void make_fallback_table(Index& ix, hipStream_t s);  // from fb_keys / fb_ranks / h_fb_group / h_groups (build and load)
 void init_filter_gate(Index& ix, hipStream_t s);  // with the filter (build and load)
 void positions_to_reference_layout(const Index& ix, DevBuf& out, hipStream_t s);  // `positions` with the reference's field width (export)
 void build_from_device(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
@@ -687,6 +698,12 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_packed, Dev
 // the build from a text that is already 2-bit packed in HBM (first nucleotide of a word most significant, zero behind the end;
 // (total + 31) / 32 + 4 words); d_packed is taken over
 void build_from_device_packed(Index& ix, DevBuf& d_packed, const uint64_t* d_offs, uint64_t nseq, uint64_t total_len);
+// the bounded serving burst (blmx_serve.hip); the queries return false when they do not take the request
+bool burst_query_kmers(Index& ix, const void* kmers, uint64_t n, void* out, bool want_bool);
+bool burst_query_sequence(Index& ix, const char* chars, uint64_t nbytes, uint64_t nk, int64_t* out);
+void burst_stop(Index& ix);
+void burst_destroy(Index& ix);
+void burst_stats(Index& ix, uint64_t out[4]);
 // host-buffer entry points (blmx_stream.hip): pinned staging, windows in flight, small-call slots
 void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
 void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode);

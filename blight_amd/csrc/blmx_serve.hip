@@ -1,0 +1,471 @@
+// blmx_serve.hip -- a BOUNDED serving burst for the reference's own calling pattern (r04).
+//
+// The reference's applications call query_kmer_hash / query_sequence_hash once per k-mer or per read from OpenMP threads
+// (blight.cpp:537-550, 575-591; Colored_De_Bruijn_graph_snippet.cpp:122-157).  One kernel launch per call (or per round of the
+// combiner, blmx_front.hip) costs a launch plus a completion: 11-13 us per call, 3e5 scalar q/s from 8 threads -- below ONE core of
+// the reference.  Here the first caller launches a small serving kernel that STAYS while requests keep arriving:
+//
+//   * a ring of request slots in pinned host memory (64 slots of 16 KiB); a caller claims a slot, writes its k-mers or its read, then
+//     the slot's sequence number -- one 16-byte line that also carries the first k-mer, so a scalar call costs the kernel one read
+//     over PCIe --, and spins on the slot's `done` word;
+//   * 16 single-wave workgroups poll four slots each (system-scope loads), answer what they find with the query body of the batch
+//     kernels (query_device.h: same filter, same MPHF probes, same scan) -- one lane per k-mer; a read is 2-bit packed into the
+//     wave's LDS first and every lane takes the k-mers at its positions --, store the IDs into the slot, fence, store `done`;
+//   * every wave LEAVES after `idle` microseconds without a request (default 60) or after `max` milliseconds (default 20),
+//     whichever comes first, and the last one out says so in pinned memory.  Nothing waits for the kernel without a deadline: a
+//     caller whose request is not answered within 200 us looks whether the kernel has gone (it may have decided to leave just
+//     before the request arrived), launches the next one, and waits again; after 50 ms without an answer the call fails with
+//     BLMX_EHIP.  The kernel cannot outlive its bound, so the grid has always drained before the process ends; an index that is
+//     rebuilt, loaded or destroyed tells the waves to leave and waits for them (bounded by the same deadline).
+//
+// Requests that do not fit a slot (reads above 1536 characters, batches above 128 k-mers) and indexes with windows above 2^8 take the
+// launch-per-round path as before; serve_burst = 0 switches the burst off.
+#include <chrono>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <immintrin.h>
+
+#include "blmx_internal.h"
+#include "query_device.h"
+
+namespace blmx {
+
+constexpr uint32_t kBurstSlots = 64;
+constexpr uint32_t kBurstWaves = 16;                           // single-wave workgroups
+constexpr uint32_t kBurstPerWave = kBurstSlots / kBurstWaves;  // slots a wave polls
+constexpr size_t kBurstSlotBytes = 16384;
+constexpr size_t kBurstPayloadAt = 64, kBurstPayloadBytes = 2048, kBurstResultsAt = kBurstPayloadAt + kBurstPayloadBytes;
+constexpr uint32_t kBurstMaxChars = 1536, kBurstMaxKmers = 128;
+constexpr uint32_t kBurstMaxIds = (uint32_t)((kBurstSlotBytes - kBurstResultsAt) / 8);  // 1784
+static_assert(kBurstMaxChars <= kBurstPayloadBytes && kBurstMaxKmers * 16 <= kBurstPayloadBytes && kBurstMaxChars <= kBurstMaxIds, "slot layout");
+
+// the first 64 bytes of a slot.  Host writes [8, 24) and the payload, then `posted`; the device writes the results, err, then `done`.
+struct BurstHead {
+	uint32_t posted;    // sequence number of the request in the slot (host; 0 = never used)
+	uint32_t what;      // bit 31: a read (characters), else k-mers; bit 30: membership bytes wanted; low bits: characters / k-mers
+	uint64_t kmer0[2];  // the first k-mer (scalar calls need nothing else)
+	uint32_t done;      // = posted once the results are in place (device)
+	int32_t err;        // 1: a character outside ACGTacgt (device)
+	uint32_t pad[8];
+};
+static_assert(sizeof(BurstHead) == 64, "BurstHead");
+
+struct BurstCtrl {  // one line of pinned memory next to the ring
+	uint32_t stop;          // host: leave now
+	uint32_t exited_gen;    // device: generation of the last kernel whose waves have all left
+	uint32_t pad[14];
+};
+
+template <int KW, int LOGP>
+__device__ __forceinline__ int64_t serve_kmer(const DeviceIndexView& v, Kmer<KW> x)
+{
+	const Kmer<KW> xr = kmer_rc<KW>(x, v.k);
+	int64_t id = -1;
+	int32_t posj;
+	if (!(xr < x)) {  // (a non-canonical k-mer matches nothing: blight.cpp:733-735)
+		const uint32_t mini = kmer_minimizer<KW>(x, xr, v.k, v.m);
+		query_one<KW, LOGP, false>(v, x, xr, mini, id, posj);
+	}
+	return id;
+}
+
+// what the waves of one serving kernel share (device memory): they leave TOGETHER -- wave 0 decides, from the time ANY wave last served
+// a request -- so that "a kernel is there" means every slot is being watched (a wave that left alone would strand its four slots)
+struct BurstShared {
+	uint32_t left;              // waves that have left
+	uint32_t leaving;           // generation whose waves have been told to leave
+	unsigned long long last_work;  // s_memrealtime of the last served request
+};
+
+template <int KW, int LOGP>
+__global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t* __restrict__ ring, BurstCtrl* __restrict__ ctrl, BurstShared* __restrict__ sh,
+                                                    uint32_t gen, uint32_t idle_ticks, uint32_t max_ticks, uint32_t max_polls)
+{
+	__shared__ uint64_t s_seq[kBurstMaxChars / 32 + 8];  // a read, 2-bit packed, first nucleotide most significant (like the index's text)
+	__shared__ uint32_t s_bad;
+	const DeviceIndexView v = gated_view(v0);
+	const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+	// lane l < kBurstPerWave watches slot wave + l * kBurstWaves
+	const bool watcher = lane < kBurstPerWave;
+	uint8_t* my_slot = ring + (size_t)(wave + (watcher ? lane : 0) * kBurstWaves) * kBurstSlotBytes;
+	uint32_t served = 0;
+	if (watcher)  // what was answered before this kernel started stays answered
+		served = __hip_atomic_load(&reinterpret_cast<BurstHead*>(my_slot)->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+	if (wave == 0 && lane == 0)
+		atomicMax(&sh->last_work, (unsigned long long)t_start);
+	for (uint32_t poll = 0; poll < max_polls; poll++) {
+		// ---- poll: ONE 16-byte read per watched slot (one PCIe read: a consistent picture of the line) brings the sequence number, the
+		// kind and the first k-mer (low word)
+		uint32_t posted = served, what = 0;
+		uint64_t k0 = 0;
+		if (watcher) {
+			uint4 q;
+			asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(my_slot) : "memory");
+			posted = q.x;
+			what = q.y;
+			k0 = (uint64_t)q.z | ((uint64_t)q.w << 32);
+		}
+		const uint32_t stop = lane == 63 ? __hip_atomic_load(&ctrl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+		const bool pending = watcher && posted != served;
+		const uint64_t pend = __ballot(pending);
+		// Wave 0 looks at the clock for all of them (idle since ANY wave's last request, or the kernel's own time limit); everybody looks
+		// at its verdict and at the host's stop word, and leaves once it has nothing pending.
+		uint32_t go = stop;
+		if (lane == 0) {
+			if (wave == 0) {
+				const uint64_t now = __builtin_amdgcn_s_memrealtime();
+				const uint64_t lw = __hip_atomic_load(&sh->last_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((pend == 0 && now > lw && now - lw > idle_ticks) || now - t_start > max_ticks)
+					__hip_atomic_store(&sh->leaving, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			go |= __hip_atomic_load(&sh->leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen ? 1u : 0u;
+		}
+		const bool leave = __ballot(go != 0) != 0;
+		if (pend == 0) {
+			if (leave)
+				break;
+			__builtin_amdgcn_s_sleep(16);
+			continue;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (the payload was written before `posted`)
+		// ---- scalar calls of 64-bit k-mers: every watcher answers its own from the polled line
+		bool mine_done = false;
+		if constexpr (KW == 1) {
+			if (pending && (what & 0xbfffffffu) == 1u) {
+				Kmer<1> x;
+				x.lo = k0;
+				const int64_t id = serve_kmer<1, LOGP>(v, x);
+				if (what & 0x40000000u)
+					*reinterpret_cast<uint8_t*>(my_slot + kBurstResultsAt) = id >= 0 ? 1 : 0;
+				else
+					*reinterpret_cast<int64_t*>(my_slot + kBurstResultsAt) = id;
+				mine_done = true;
+			}
+		}
+		// ---- everything else, one request after the other, the whole wave on each
+		uint64_t rest = __ballot(pending && !mine_done);
+		while (rest) {
+			const int src = __ffsll((unsigned long long)rest) - 1;
+			rest &= rest - 1;
+			const uint32_t w = (uint32_t)__shfl((int)what, src);
+			uint8_t* slot = ring + (size_t)(wave + (uint32_t)src * kBurstWaves) * kBurstSlotBytes;
+			const uint32_t n = w & 0x3fffffffu;
+			if (w & 0x80000000u) {  // a read of n characters: 2-bit pack it into LDS, 16 characters per lane and round
+				if (lane == 0)
+					s_bad = 0;
+				for (uint32_t i = lane; i < sizeof(s_seq) / 8; i += 64)
+					s_seq[i] = 0;
+				__builtin_amdgcn_wave_barrier();
+				uint32_t* s32 = reinterpret_cast<uint32_t*>(s_seq);
+				const uint8_t* chars = slot + kBurstPayloadAt;
+				uint32_t bad = 0;
+				for (uint32_t c = lane; c * 16 < n; c += 64) {
+					typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+					const u32x4 q = *reinterpret_cast<const u32x4*>(chars + (size_t)c * 16);  // (payload bytes behind the read are the host's zeros)
+					uint32_t packed = 0;
+#pragma unroll
+					for (int j = 0; j < 16; j++) {
+						const uint32_t word = j < 4 ? q.x : (j < 8 ? q.y : (j < 12 ? q.z : q.w));
+						const uint8_t ch = (uint8_t)(word >> (8 * (j & 3)));
+						const uint32_t code = nuc_code(ch);
+						if (c * 16 + (uint32_t)j < n)
+							bad |= code > 3 ? 1u : 0u;
+						packed |= (code & 3u) << (30 - 2 * j);
+					}
+					s32[c ^ 1u] = packed;  // (little-endian u64 words: the first 16 nucleotides of a word are its high half)
+				}
+				if (bad)
+					s_bad = 1;
+				__builtin_amdgcn_wave_barrier();
+				const uint32_t nk = n >= (uint32_t)v.k ? n - (uint32_t)v.k + 1 : 0;
+				int64_t* ids = reinterpret_cast<int64_t*>(slot + kBurstResultsAt);
+				if (!s_bad)
+					for (uint32_t p = lane; p < nk; p += 64) {
+						const Kmer<KW> y = packed_kmer<KW>(s_seq, p, v.k);
+						const Kmer<KW> yr = kmer_rc<KW>(y, v.k);
+						ids[p] = serve_kmer<KW, LOGP>(v, yr < y ? yr : y);  // min_k, blight.cpp:86-91
+					}
+				if (lane == 0)
+					reinterpret_cast<BurstHead*>(slot)->err = (int32_t)s_bad;
+			} else {  // n canonical k-mers
+				const bool want_bool = (w & 0x40000000u) != 0;
+				for (uint32_t i = lane; i < n; i += 64) {
+					const Kmer<KW> x = load_kmer<KW>(reinterpret_cast<const uint64_t*>(slot + kBurstPayloadAt), i);
+					const int64_t id = serve_kmer<KW, LOGP>(v, x);
+					if (want_bool)
+						reinterpret_cast<uint8_t*>(slot + kBurstResultsAt)[i] = id >= 0 ? 1 : 0;
+					else
+						reinterpret_cast<int64_t*>(slot + kBurstResultsAt)[i] = id;
+				}
+				if (lane == 0)
+					reinterpret_cast<BurstHead*>(slot)->err = 0;
+			}
+		}
+		// ---- results before `done`
+		__threadfence_system();
+		if (pending) {
+			if (mine_done)
+				reinterpret_cast<BurstHead*>(my_slot)->err = 0;
+			__hip_atomic_store(&reinterpret_cast<BurstHead*>(my_slot)->done, posted, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			served = posted;
+		}
+		if (lane == 0)
+			atomicMax(&sh->last_work, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+		if (leave)  // (told to leave while requests were pending: they are answered, the next ones are the next kernel's)
+			break;
+	}
+	// ---- leave: the last wave out publishes the generation
+	if (lane == 0) {
+		__threadfence_system();
+		if (atomicAdd(&sh->left, 1u) + 1u == gridDim.x) {
+			sh->left = 0;
+			__threadfence();
+			__hip_atomic_store(&ctrl->exited_gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+struct BurstState {
+	Pinned ring;   // kBurstSlots slots + one BurstCtrl line
+	DevBuf left;   // BurstShared of the current kernel
+	hipStream_t s = nullptr;
+	std::mutex launch_mu;
+	std::atomic<uint32_t> launched_gen{0};
+	std::atomic<uint32_t> busy[kBurstSlots];
+	std::atomic<uint32_t> next_hint{0};
+	uint32_t seq[kBurstSlots] = {};
+	std::atomic<uint64_t> launches{0}, calls{0}, relaunch_after_timeout{0};
+	uint32_t idle_us = 60, max_ms = 20;
+	BurstState()
+	{
+		for (auto& b : busy)
+			b.store(0);
+	}
+	uint8_t* slot(uint32_t i) { return ring.as<uint8_t>() + (size_t)i * kBurstSlotBytes; }
+	BurstCtrl* ctrl() { return reinterpret_cast<BurstCtrl*>(ring.as<uint8_t>() + (size_t)kBurstSlots * kBurstSlotBytes); }
+	bool alive()
+	{
+		const uint32_t ex = __atomic_load_n(&ctrl()->exited_gen, __ATOMIC_ACQUIRE);
+		return launched_gen.load(std::memory_order_acquire) != ex;
+	}
+};
+
+namespace {
+
+BurstState* burst_state(Index& ix)
+{
+	std::lock_guard<std::mutex> l(ix.hf_mu);
+	if (!ix.burst) {
+		std::unique_ptr<BurstState> b(new BurstState());
+		b->ring.ensure((size_t)kBurstSlots * kBurstSlotBytes + 4096);
+		memset(b->ring.p, 0, (size_t)kBurstSlots * kBurstSlotBytes + 4096);
+		BLMX_HIP(hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking));
+		BLMX_HIP(b->left.alloc(64, true, b->s));
+		BLMX_HIP(hipStreamSynchronize(b->s));
+		if (const char* e = getenv("BLIGHT_SERVE_IDLE_US"))
+			b->idle_us = (uint32_t)std::max(1, atoi(e));
+		if (const char* e = getenv("BLIGHT_SERVE_MAX_MS"))
+			b->max_ms = (uint32_t)std::max(1, atoi(e));
+		ix.burst = b.release();
+	}
+	return ix.burst;
+}
+
+template <int KW> void launch_burst_kw(const Index& ix, BurstState& b, uint32_t gen)
+{
+	const DeviceIndexView v = ix.view();
+	// s_memrealtime counts at 100 MHz; the poll cap bounds the kernel even if that clock were to stand still (a poll takes >= 1 us)
+	const uint32_t idle_ticks = b.idle_us * 100u, max_ticks = b.max_ms * 100000u, max_polls = b.max_ms * 4000u + 1000u;
+#define BLMX_SV(LP)                                                                                                                                    \
+	case LP:                                                                                                                                           \
+		hipLaunchKernelGGL((k_serve_burst<KW, LP>), dim3(kBurstWaves), dim3(64), 0, b.s, v, b.ring.as<uint8_t>(), b.ctrl(), b.left.as<BurstShared>(), gen, \
+		                   idle_ticks, max_ticks, max_polls);                                                                                          \
+		break;
+	switch (v.b) {
+		BLMX_SV(0)
+		BLMX_SV(1)
+		BLMX_SV(2)
+		BLMX_SV(3)
+		BLMX_SV(4)
+		BLMX_SV(5)
+		BLMX_SV(6)
+		BLMX_SV(7)
+		BLMX_SV(8)
+	default:
+		throw StatusError{BLMX_EINVAL, "internal: the serving burst needs bits_to_save <= 8"};
+	}
+#undef BLMX_SV
+	BLMX_HIP(hipGetLastError());
+}
+
+// make sure a serving kernel is (still) there; returns after the launch has been enqueued
+void ensure_burst(Index& ix, BurstState& b)
+{
+	if (b.alive())
+		return;
+	std::lock_guard<std::mutex> l(b.launch_mu);
+	if (b.alive())
+		return;
+	BLMX_HIP(hipSetDevice(ix.prm.device));
+	__atomic_store_n(&b.ctrl()->stop, 0u, __ATOMIC_RELEASE);
+	uint32_t gen = b.launched_gen.load(std::memory_order_relaxed) + 1;
+	if (gen == 0)
+		gen = 1;
+	if (ix.KW == 1)
+		launch_burst_kw<1>(ix, b, gen);
+	else
+		launch_burst_kw<2>(ix, b, gen);
+	b.launched_gen.store(gen, std::memory_order_release);
+	b.launches.fetch_add(1, std::memory_order_relaxed);
+}
+
+int claim_slot(BurstState& b)
+{
+	const uint32_t h = b.next_hint.fetch_add(1, std::memory_order_relaxed);
+	for (uint32_t i = 0; i < kBurstSlots; i++) {
+		const uint32_t sidx = (h + i) % kBurstSlots;
+		uint32_t z = 0;
+		if (b.busy[sidx].compare_exchange_strong(z, 1u, std::memory_order_acquire))
+			return (int)sidx;
+	}
+	return -1;
+}
+
+// post the request that sits in slot `si` (payload and head fields written) and wait for its answer
+void post_and_wait(Index& ix, BurstState& b, int si, uint32_t what, const uint64_t kmer0[2])
+{
+	BurstHead* h = reinterpret_cast<BurstHead*>(b.slot((uint32_t)si));
+	uint32_t seq = ++b.seq[si];
+	if (seq == 0)
+		seq = ++b.seq[si];
+	h->what = what;
+	h->kmer0[0] = kmer0[0];
+	h->kmer0[1] = kmer0[1];
+	__atomic_store_n(&h->posted, seq, __ATOMIC_RELEASE);
+	ensure_burst(ix, b);
+	const auto t0 = std::chrono::steady_clock::now();
+	auto deadline = t0 + std::chrono::microseconds(200);
+	for (uint32_t spin = 0;; spin++) {
+		if (__atomic_load_n(&h->done, __ATOMIC_ACQUIRE) == seq)
+			return;
+		_mm_pause();
+		if ((spin & 255u) == 255u) {
+			const auto now = std::chrono::steady_clock::now();
+			if (now > deadline) {
+				if (now - t0 > std::chrono::milliseconds(50))
+					throw StatusError{BLMX_EHIP, "the serving kernel did not answer a call within 50 ms"};
+				if (!b.alive()) {  // the kernel had decided to leave when the request arrived: the next one takes it
+					b.relaunch_after_timeout.fetch_add(1, std::memory_order_relaxed);
+					ensure_burst(ix, b);
+				}
+				deadline = now + std::chrono::microseconds(200);
+			}
+		}
+	}
+}
+
+struct SlotLease {
+	BurstState& b;
+	int si;
+	~SlotLease() { b.busy[si].store(0, std::memory_order_release); }
+};
+
+}  // namespace
+
+bool burst_usable(const Index& ix) { return ix.tune_serve_burst != 0 && ix.built && ix.prm.bits_saved <= 8; }
+
+// n canonical k-mers (KW words each) -> IDs (int64) or membership bytes; false: not taken (the caller uses the launch-per-round path)
+bool burst_query_kmers(Index& ix, const void* kmers, uint64_t n, void* out, bool want_bool)
+{
+	if (!burst_usable(ix) || n == 0 || n > kBurstMaxKmers)
+		return false;
+	BurstState& b = *burst_state(ix);
+	const int si = claim_slot(b);
+	if (si < 0)
+		return false;
+	SlotLease lease{b, si};
+	const size_t kb = (size_t)ix.KW * 8;
+	uint8_t* slot = b.slot((uint32_t)si);
+	uint64_t k0[2] = {0, 0};
+	memcpy(k0, kmers, kb);
+	if (!(n == 1 && ix.KW == 1))
+		memcpy(slot + kBurstPayloadAt, kmers, n * kb);
+	post_and_wait(ix, b, si, (uint32_t)n | (want_bool ? 0x40000000u : 0u), k0);
+	memcpy(out, slot + kBurstResultsAt, want_bool ? n : n * 8);
+	ix.number_query.fetch_add(n, std::memory_order_relaxed);
+	b.calls.fetch_add(1, std::memory_order_relaxed);
+	return true;
+}
+
+// one sequence of nbytes characters (nk = nbytes - k + 1 > 0 k-mers) -> IDs; throws BLMX_EDNA like the other paths
+bool burst_query_sequence(Index& ix, const char* chars, uint64_t nbytes, uint64_t nk, int64_t* out)
+{
+	if (!burst_usable(ix) || nbytes > kBurstMaxChars || nk == 0 || nk > kBurstMaxIds)
+		return false;
+	BurstState& b = *burst_state(ix);
+	const int si = claim_slot(b);
+	if (si < 0)
+		return false;
+	SlotLease lease{b, si};
+	uint8_t* slot = b.slot((uint32_t)si);
+	memcpy(slot + kBurstPayloadAt, chars, nbytes);
+	memset(slot + kBurstPayloadAt + nbytes, 0, ((nbytes + 15) & ~(uint64_t)15) - nbytes);
+	const uint64_t k0[2] = {0, 0};
+	post_and_wait(ix, b, si, (uint32_t)nbytes | 0x80000000u, k0);
+	if (reinterpret_cast<BurstHead*>(slot)->err)
+		throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
+	memcpy(out, slot + kBurstResultsAt, nk * 8);
+	ix.number_query.fetch_add(nk, std::memory_order_relaxed);
+	b.calls.fetch_add(1, std::memory_order_relaxed);
+	return true;
+}
+
+// tell the waves to leave and wait until they have (bounded: the kernel leaves by itself after max_ms)
+void burst_stop(Index& ix)
+{
+	BurstState* b = ix.burst;
+	if (!b)
+		return;
+	std::lock_guard<std::mutex> l(b->launch_mu);
+	if (!b->alive())
+		return;
+	__atomic_store_n(&b->ctrl()->stop, 1u, __ATOMIC_RELEASE);
+	const auto t0 = std::chrono::steady_clock::now();
+	while (b->alive() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
+		_mm_pause();
+	(void)hipStreamSynchronize(b->s);  // (returns at once when the waves have left; bounded by the kernel's own limit otherwise)
+}
+
+void burst_destroy(Index& ix)
+{
+	if (!ix.burst)
+		return;
+	burst_stop(ix);
+	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) != 0 && ix.burst->calls.load())
+		fprintf(stderr, "[blmx serve] %llu calls answered by %llu serving kernels (%llu launched after a caller's 200-us deadline)\n",
+		        (unsigned long long)ix.burst->calls.load(), (unsigned long long)ix.burst->launches.load(),
+		        (unsigned long long)ix.burst->relaunch_after_timeout.load());
+	if (ix.burst->s) {
+		(void)hipStreamSynchronize(ix.burst->s);
+		(void)hipStreamDestroy(ix.burst->s);
+	}
+	delete ix.burst;
+	ix.burst = nullptr;
+}
+
+// what the tests look at: {kernels launched, calls answered, relaunches after a deadline, 1 if a kernel is there now}
+void burst_stats(Index& ix, uint64_t out[4])
+{
+	out[0] = out[1] = out[2] = out[3] = 0;
+	if (!ix.burst)
+		return;
+	out[0] = ix.burst->launches.load();
+	out[1] = ix.burst->calls.load();
+	out[2] = ix.burst->relaunch_after_timeout.load();
+	out[3] = ix.burst->alive() ? 1 : 0;
+}
+
+}  // namespace blmx

@@ -809,7 +809,7 @@ void load_index(Index& ix, const char* path)
 	// in BLMX_EIO here instead of a GPU memory fault later.
 	{
 		auto bad = [&](const char* what) {
-			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks, &ix.filter, &ix.filter_gate})
+			for (DevBuf* b : {&ix.buckets, &ix.groups, &ix.qheads, &ix.seq, &ix.positions, &ix.lines, &ix.fb_keys, &ix.fb_ranks, &ix.fb_table, &ix.fb_dir, &ix.filter, &ix.filter_gate})
 				b->release();
 			ix.filter_bpk = 0;
 			ix.fat_lines = false;
@@ -856,6 +856,7 @@ void load_index(Index& ix, const char* path)
 			bad("key counts");
 	}
 	make_query_heads(ix);
+	make_fallback_table(ix, s);  // (derived from the sorted entries: not part of the image)
 	ix.pos_hint = img_hint;
 	ix.shard_rank = h.shard_rank;
 	ix.shard_world = h.shard_world;

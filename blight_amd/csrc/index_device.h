@@ -398,6 +398,50 @@ __device__ __forceinline__ unsigned long long* fat_filter_slot(const DeviceIndex
 	return reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(w));
 }
 
+// ---- the fallback table as a hash table (r04) -----------------------------------------------------------------------------------------
+// _final_hash of the reference is an unordered_map per MPHF (bbhash.h:781).  The sorted (group, key, input order) arrays keep every
+// entry -- the export and the image are made of them -- but a lookup in them is a binary search: ~20 dependent loads where low
+// complexity puts millions of keys behind a few minimizers.  Each group's entries therefore sit once more in an open-addressing table
+// of its own: power-of-two slots, at least 1.5 per entry, linear probing from mix(key); a slot = [key (KW words) | rank], 16 bytes
+// for 64-bit k-mers, 32 (one word unused) for 128-bit ones; rank = kNotFound marks an empty slot.  Only the entry that the map's
+// "last assignment wins" (bbhash.h:724) leaves behind -- the LAST of a run of equal keys -- is in the table.  One or two loads.
+template <int KW> struct FbSlot { static constexpr int words = KW == 1 ? 2 : 4; };
+__device__ __forceinline__ uint64_t fb_mix(uint64_t lo, uint64_t hi)
+{
+	uint64_t h = lo ^ (hi * 0x9e3779b97f4a7c15ull);
+	h ^= h >> 31;
+	h *= 0x7fb5d329728ea185ull;
+	h ^= h >> 27;
+	h *= 0x81dadef4bc2dd44dull;
+	return h ^ (h >> 33);
+}
+template <int KW>
+__device__ __forceinline__ uint64_t fallback_find(const DeviceIndexView& v, uint32_t group, Kmer<KW> x)
+{
+	const uint64_t dir = v.fb_dir[group];
+	if (dir == 0)
+		return kNotFound;
+	const uint64_t first = dir & 0x00ffffffffffffffull, mask = (1ull << (dir >> 56)) - 1ull;
+	uint64_t at = fb_mix(x.lo, kmer_hi(x)) & mask;
+	for (;;) {  // (ends: the table is never full)
+		const uint64_t* sl = v.fb_table + (first + at) * FbSlot<KW>::words;
+		if constexpr (KW == 1) {
+			const ulonglong2 e = *reinterpret_cast<const ulonglong2*>(sl);
+			if (e.y == kNotFound)
+				return kNotFound;
+			if (e.x == x.lo)
+				return e.y;
+		} else {
+			const ulonglong2 e = reinterpret_cast<const ulonglong2*>(sl)[0], f = reinterpret_cast<const ulonglong2*>(sl)[1];
+			if (f.x == kNotFound)
+				return kNotFound;
+			if (e.x == x.lo && e.y == x.hi)
+				return f.x;
+		}
+		at = (at + 1) & mask;
+	}
+}
+
 // mphf::lookup (bbhash.h:561-577): levels first, then the group's fallback table.
 template <int KW>
 __device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const GroupDesc* __restrict__ gd, const GroupHead& gh, Kmer<KW> x,
@@ -410,9 +454,12 @@ __device__ __forceinline__ uint64_t mphf_lookup(const DeviceIndexView& v, const 
 	const uint32_t fb_count = gd->fb_count;  // from the descriptor: the compact query head does not carry the fallback fields
 	if (fb_count == 0)
 		return r;
-	const uint64_t fb_start = gd->fb_start;
-	// _final_hash.find(elem), bbhash.h:567-575.  The table is sorted by (group, key, input order) and keeps every
+	// _final_hash.find(elem), bbhash.h:567-575.
+	if (v.fb_dir)
+		return fallback_find<KW>(v, (uint32_t)(gd - v.groups), x);
+	// (no table: the sorted entries themselves.)  The table is sorted by (group, key, input order) and keeps every
 	// occurrence of a duplicated key; the map's "last assignment wins" (bbhash.h:724) = the LAST entry of an equal run.
+	const uint64_t fb_start = gd->fb_start;
 	uint64_t lo = fb_start, hi = lo + fb_count;
 	const uint64_t begin = lo;
 	while (lo < hi) {  // upper bound

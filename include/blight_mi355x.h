@@ -332,6 +332,12 @@ int blmx_stats(const blmx_index* ix, blmx_stats_t* out);
  * k-mers that did not fit their bin's region and went through the overflow region (they are answered all the same, only without
  * locality), the largest such count of one batch]; reset != 0 clears the counters.  Synchronises the device. */
 int blmx_partition_stats(blmx_index* ix, uint64_t* out4, int reset);
+/* The bounded serving burst that answers small calls (one k-mer, one read: the reference's calling pattern, blight.cpp:537-550,
+ * 575-591): out4 = [serving kernels launched so far, calls they answered, kernels launched because a caller's 200-us deadline found
+ * the previous one gone, 1 if a serving kernel is alive right now].  A kernel leaves by itself after BLIGHT_SERVE_IDLE_US (60)
+ * microseconds without a request or BLIGHT_SERVE_MAX_MS (20) milliseconds, whichever comes first; blmx_set_tuning("serve_burst", 0)
+ * stops it and sends small calls through one launch per round instead. */
+int blmx_serve_stats(blmx_index* ix, uint64_t* out4);
 /* Memory the library keeps between calls, per process: device blocks of 1 MiB and more that a finished build or a destroyed index
  * gave up (scratch, index arrays, staging; up to 1/6 of the device's memory, or BLIGHT_SCRATCH_CACHE_GB; they serve the next build
  * or index of the process -- on this driver hipMalloc of VRAM the process has used before costs 25-100 ms per GB, and ~3 s when the

@@ -401,3 +401,69 @@ def test_partition_paths_and_skewed_batches(B, O, k, kb, b):
         assert np.array_equal(ix.query_kmer_hash(batches[name].reshape(-1)), wants[name]), name
     half = uniform[: len(uniform) // 3]  # another batch size: the shares scale
     assert np.array_equal(ix.query_kmer_hash(half.reshape(-1)), wants["uniform"][: len(half)])
+
+
+def test_serving_burst_answers_small_calls_and_leaves(B, O):
+    """Small calls -- one k-mer, a few k-mers, one read: the reference's calling pattern (blight.cpp:537-550, 575-591) -- are answered by
+    a BOUNDED serving kernel that polls a request ring in pinned memory (blmx_serve.hip).  Every answer equals the oracle's (64- and
+    128-bit k-mers, membership, reads with and without invalid characters, from eight threads at once); the kernel is gone within
+    its idle bound once the calls stop, the next call simply starts the next one; with serve_burst = 0 the same calls take one launch
+    per round and give the same answers."""
+    import time
+    for (k, kb, m, n, b) in ((31, 8, 9, 6, 6), (63, 16, 9, 5, 8), (21, 8, 7, 3, 2)):
+        ix, orc, seqs, rng = _index(B, O, k, m, n, b, kb, 23 + k, nseq=600)
+        ix.set_tuning("absent_filter", 1)
+        pos = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs[:40]])
+        neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in (int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(300))], kb).reshape(-1, kb // 8)
+        q = np.ascontiguousarray(np.concatenate([pos[:300], neg]))
+        want = orc.query_kmers(q.reshape(-1) if kb == 8 else q)
+        before = ix.serve_stats()
+        got = np.array([ix.query_kmer_hash(np.ascontiguousarray(q[i]).reshape(-1))[0] for i in range(len(q))])
+        assert np.array_equal(got, want)
+        st = ix.serve_stats()
+        assert st["calls"] - before["calls"] == len(q) and st["kernels"] >= 1
+        # a few k-mers per call, membership
+        for a in range(0, len(q), 37):
+            part = np.ascontiguousarray(q[a:a + 37]).reshape(-1)
+            assert np.array_equal(ix.query_kmer_hash(part), want[a:a + 37])
+            assert np.array_equal(ix.query_kmer_bool(part), want[a:a + 37] >= 0)
+        # reads: one call each
+        reads = _reads(rng, seqs, k, 120)
+        for r in reads:
+            assert np.array_equal(ix.query_sequence_hash(r), _want(orc, [r], k))
+        with pytest.raises(Exception):
+            ix.query_sequence_hash(reads[0][:k + 3] + "N" + reads[0][k + 4:])
+        assert np.array_equal(ix.query_sequence_hash(reads[1]), _want(orc, [reads[1]], k))  # the ring is fine after a failed call
+        # eight threads at once
+        errors = []
+
+        def worker(t):
+            try:
+                for i in range(t, len(q), 8):
+                    if ix.query_kmer_hash(np.ascontiguousarray(q[i]).reshape(-1))[0] != want[i]:
+                        errors.append(("kmer", i))
+                for i in range(t, len(reads), 8):
+                    if not np.array_equal(ix.query_sequence_hash(reads[i]), _want(orc, [reads[i]], k)):
+                        errors.append(("read", i))
+            except Exception as e:  # pragma: no cover
+                errors.append(repr(e))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errors, errors[:5]
+        # no traffic: the kernel leaves within its bound (60 us idle by default; the check allows for a loaded box)
+        t0 = time.time()
+        while ix.serve_stats()["alive"] and time.time() - t0 < 1.0:
+            time.sleep(0.001)
+        assert not ix.serve_stats()["alive"], "the serving kernel is still there %.3f s after the last call" % (time.time() - t0)
+        kernels = ix.serve_stats()["kernels"]
+        assert ix.query_kmer_hash(np.ascontiguousarray(q[0]).reshape(-1))[0] == want[0]  # the next call starts the next kernel
+        assert ix.serve_stats()["kernels"] == kernels + 1
+        # the same calls without the burst
+        ix.set_tuning("serve_burst", 0)
+        assert not ix.serve_stats()["alive"]
+        calls = ix.serve_stats()["calls"]
+        assert np.array_equal(np.array([ix.query_kmer_hash(np.ascontiguousarray(q[i]).reshape(-1))[0] for i in range(0, len(q), 5)]), want[::5])
+        assert np.array_equal(ix.query_sequence_hash(reads[2]), _want(orc, [reads[2]], k))
+        assert ix.serve_stats()["calls"] == calls
+        ix.close()

@@ -683,3 +683,45 @@ def test_device_batches_of_any_size_are_answered_in_pieces(B, O):
         ix.query_kmers_device(dq.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), want), pol
+
+
+@pytest.mark.parametrize("k,kb,m,n,b", [(31, 8, 7, 3, 4), (63, 16, 9, 5, 8), (15, 8, 5, 0, 2)])
+def test_fallback_hash_table_on_and_off(B, O, k, kb, m, n, b):
+    """Keys that survive all 16 MPHF levels (duplicated k-mers do, always) live in the reference's unordered_map (bbhash.h:567-575,
+    711-728).  Here: the sorted entries (exported, part of the image) and, derived from them, one open-addressing table per MPHF group
+    that lookups probe (fb_table = 1, default) instead of searching the sorted entries (0).  Same answers either way, for every key
+    incl. the duplicated ones ("last assignment wins"), for absent k-mers that reach the fallback stage, and after an image round trip."""
+    rng = np.random.default_rng(31 + k)
+    seqs = [_rand_seq(rng, k + int(rng.integers(0, 80))) for _ in range(400)]
+    seqs += [_rand_seq(rng, 4000, "AC"), _rand_seq(rng, 3000, "AC"), "A" * (k + 50), "AC" * (k + 9)] + seqs[:120] + [seqs[7][2:]]
+    orc = O.Oracle(k, m, n, b, seqs, kmer_bytes=kb)
+    q = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs])
+    neg = [int.from_bytes(rng.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(4000)]
+    neg += [int("".join(rng.choice(["00", "01"], size=k)), 2) for _ in range(4000)]  # {A, C} k-mers: the groups that hold the fallback keys
+    neg = O.kmers_to_array([min(x, O.p_rc(x, k, kb)) for x in neg], kb).reshape(-1, kb // 8)
+    allq = np.ascontiguousarray(np.concatenate([q, neg]))
+    want = orc.query_kmers(allq.reshape(-1) if kb == 8 else allq)
+    sizes = {}
+    for table in (1, 0):
+        ix = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+        ix.set_tuning("fb_table", table)
+        ix.construct_index_from_sequences(seqs)
+        ix.set_tuning("absent_filter", 1)
+        st = ix.stats()
+        assert st["fallback_keys"] > 100
+        sizes[table] = st["device_bytes"]
+        for pol in (-1, 1, 1):
+            ix.set_query_binning(pol)
+            assert np.array_equal(ix.query_kmer_hash(allq.reshape(-1)), want), (table, pol)
+        ix.set_tuning("absent_filter", 0)  # every absent k-mer now walks the levels, many of them into the fallback stage
+        assert np.array_equal(ix.query_kmer_hash(allq.reshape(-1)), want), (table, "unfiltered")
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            ix.dump_disk(td + "/i.blmx")
+            ld = B.kmer_Set_Light(k, m, n, min(n, 3), 1, b, kmer_bytes=kb)
+            ld.set_tuning("fb_table", table)
+            ld.load_disk(td + "/i.blmx")
+            ld.set_tuning("absent_filter", 0)
+            assert np.array_equal(ld.query_kmer_hash(allq.reshape(-1)), want), (table, "image")
+        ix.close()
+    assert sizes[1] > sizes[0]
