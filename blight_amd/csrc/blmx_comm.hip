@@ -621,6 +621,17 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 	if (local.code == BLMX_OK && nq >= 0xffffffffull)
 		local = StatusError{BLMX_ELIMIT, "a partitioned batch holds fewer than 2^32 - 1 k-mers"};
 	const uint32_t world = c.world, me = c.rank;
+	// BLIGHT_TRACE=3: host wall-clock of the phases of one exchange step, per rank (what the rehearsals under profiles/ print)
+	static const bool trace = getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) == 3;
+	auto t_last = std::chrono::steady_clock::now();
+	double ph[6] = {0, 0, 0, 0, 0, 0};
+	auto phase = [&](int i) {
+		if (!trace)
+			return;
+		const auto now = std::chrono::steady_clock::now();
+		ph[i] += std::chrono::duration<double, std::milli>(now - t_last).count();
+		t_last = now;
+	};
 	const char* e = getenv("BLIGHT_DIST_CHUNKS");
 	// pieces overlap the exchange of one with the queries of another; with one rank there is nothing to overlap, and a piece of
 	// half the batch loses locality in its bins.  Must be the same on every rank.
@@ -667,6 +678,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 	} catch (const StatusError& err) {
 		local = err;
 	}
+	phase(0);  // partition of all pieces + the wait for their per-owner counts
 	// ---- formats and per-owner counts of all pieces, what every rank can receive without growing a buffer, the settings that size
 	// the flows (ID width, number of pieces: per-rank settings that must agree) and one "cannot take part" flag in one all-gather
 	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
@@ -689,6 +701,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 	mine[per_rank - 2] = (uint64_t)pieces;
 	mine[per_rank - 1] = local.code != BLMX_OK;
 	all_gather_host(c, mine.data(), per_rank, all.data(), s);
+	phase(1);  // the all-gather of counts (includes waiting for the slowest rank's partition)
 	for (uint32_t r = 0; r < world; r++)
 		if (all[(size_t)r * per_rank + per_rank - 1]) {
 			if (local.code != BLMX_OK)
@@ -779,6 +792,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 				throw StatusError{BLMX_ERCCL, "sharded query: another rank could not allocate its receive buffers"};
 			}
 	}
+	phase(2);  // receive buffers (+ the second vote when somebody grew)
 	// ---- the pipeline: collectives are issued in the same order on every rank (k-mers 0, k-mers 1, IDs 0, k-mers 2, IDs 1, ...)
 	auto send_kmers = [&](int p) {
 		const Flows& f = F[p];
@@ -863,6 +877,13 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 			launch_gather_ids(ix, c.ids_sorted[p].as<int64_t>(), c.inv[p].as<uint32_t>(), cut[p + 1] - cut[p], d_ids + cut[p], s);
 	}
 	ix.number_query.fetch_add(nq, std::memory_order_relaxed);
+	phase(3);  // flows, owner kernels and gathers ENQUEUED (the device works on them from here on)
+	if (trace) {
+		BLMX_HIP(hipStreamSynchronize(s));
+		phase(4);
+		fprintf(stderr, "[blmx exchange] rank %u of %u, %llu k-mers in %d pieces: partition+counts %.3f ms, all-gather %.3f, buffers %.3f, enqueue %.3f, device drain %.3f\n", me,
+		        world, (unsigned long long)nq, pieces, ph[0], ph[1], ph[2], ph[3], ph[4]);
+	}
 }
 
 // Sharded construction from slices: every rank passes ITS OWN consecutive piece of the input (rank order = input order).  Collective.

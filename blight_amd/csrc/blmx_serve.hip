@@ -93,6 +93,7 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 	if (watcher)  // what was answered before this kernel started stays answered
 		served = __hip_atomic_load(&reinterpret_cast<BurstHead*>(my_slot)->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+	uint64_t t_mine = t_start;
 	if (wave == 0 && lane == 0)
 		atomicMax(&sh->last_work, (unsigned long long)t_start);
 	for (uint32_t poll = 0; poll < max_polls; poll++) {
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 		if (pend == 0) {
 			if (leave)
 				break;
-			__builtin_amdgcn_s_sleep(16);
+			if (__builtin_amdgcn_s_memrealtime() - t_mine > 2000u)  // (20 us after its own last request a wave polls back to back: a blocking
+				__builtin_amdgcn_s_sleep(16);                        // caller's next call comes within microseconds; then it eases off the link)
 			continue;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (the payload was written before `posted`)
@@ -211,8 +213,9 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 			__hip_atomic_store(&reinterpret_cast<BurstHead*>(my_slot)->done, posted, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 			served = posted;
 		}
+		t_mine = __builtin_amdgcn_s_memrealtime();
 		if (lane == 0)
-			atomicMax(&sh->last_work, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+			atomicMax(&sh->last_work, (unsigned long long)t_mine);
 		if (leave)  // (told to leave while requests were pending: they are answered, the next ones are the next kernel's)
 			break;
 	}
