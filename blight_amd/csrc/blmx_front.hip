@@ -1323,7 +1323,7 @@ void load_fasta_raw_to_device(Index& ix, const char* path, DevBuf& d_text, DevBu
 		seen += nbytes;
 		if (nbytes + 64 > w.d_in.bytes && used[slot])
 			BLMX_HIP(hipEventSynchronize(parsed[slot]));  // (the slot's device buffer is about to be replaced)
-		grow(w.d_in, nbytes + 64, s);
+		grow(w.d_in, nbytes + 64, s_copy);  // (on the COPY's stream: a fill of the fresh block -- BLIGHT_POISON -- must not land on top of the copy)
 		if (used[slot])
 			BLMX_HIP(hipStreamWaitEvent(s_copy, parsed[slot], 0));  // the kernels of the slot's previous window have read its device buffer
 		BLMX_HIP(hipMemcpyAsync(w.d_in.p, w.h_in.p, nbytes, hipMemcpyHostToDevice, s_copy));
