@@ -773,11 +773,37 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_group_lds(BuildGroups bg, 
 // walk), walks the list again to write them, and stores the finished slice.  Keys are hashed once per walk and slice, which
 // is cheap next to atomics; one launch per level, workgroups of finished groups exit at once.
 // lvcnt[level * ngroups + g] = keys of group g alive at `level` (level 0: all keys, implicit list).
+// r04: the level-`level` bit index of every key a sliced group still holds, ONCE per level (blockIdx.y = the group's number in glist,
+// blockIdx.x = a chunk of its current key list).  The slice workgroups below then walk 4-byte bit indices: before, each of the up to
+// 45 slices of a 13-M-key group hashed every key of the group itself, twice (mark and survive walks) -- 6e8 hash_bis per group
+// and level 0 -- and the deep levels of groups full of duplicated keys re-hashed every survivor from level 0 in every walk.
+template <int KW>
+__global__ __launch_bounds__(kBlock) void k_sliced_level_bits(BuildGroups bg, const uint64_t* __restrict__ keys, int level, const uint32_t* __restrict__ glist,
+                                                              const uint32_t* __restrict__ listA, const uint32_t* __restrict__ listB,
+                                                              const uint32_t* __restrict__ lvcnt, uint32_t* __restrict__ lbits)
+{
+	const uint32_t g = glist[blockIdx.y];
+	const GroupDesc* gd = &bg.groups[g];
+	const uint64_t kb = bg.g_prefix[g];
+	const uint32_t count = level == 0 ? (uint32_t)gd->nkeys : lvcnt[(uint64_t)level * bg.ngroups + g];
+	const uint64_t size = gd->size[level];
+	const uint32_t* cur = ((level & 1) ? listB : listA) + kb;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (uint64_t)gridDim.x * kBlock) {
+		const uint32_t j = level == 0 ? (uint32_t)i : cur[i];
+		const uint64_t key = KW == 1 ? keys[kb + j] : keys[2 * (kb + j)];
+		LevelHasher hs(key);
+		uint64_t h = 0;
+		for (int l = 0; l <= level; l++)
+			h = hs.next(l);
+		lbits[kb + i] = (uint32_t)reduce_level(h, size);
+	}
+}
+
 template <int KW>
 __global__ __launch_bounds__(kGroupBlock) void k_mphf_level_sliced(BuildGroups bg, const uint64_t* __restrict__ keys, int level,
                                                                    const uint2* __restrict__ items, uint32_t* __restrict__ listA,
                                                                    uint32_t* __restrict__ listB, uint32_t* __restrict__ lvcnt,
-                                                                   uint32_t* __restrict__ gbits32)
+                                                                   uint32_t* __restrict__ gbits32, const uint32_t* __restrict__ lbits)
 {
 	__shared__ uint32_t s_bits[kLdsLevelWords];
 	__shared__ uint32_t s_coll[kLdsLevelWords];
@@ -805,33 +831,24 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_level_sliced(BuildGroups b
 	// mark (processLevel_, bbhash.h:677-709) + count the keys that fall into this slice; four keys in flight per thread (the walk
 	// is a stream of dependent-free loads: one per iteration left the CU at a few GB/s)
 	constexpr uint32_t kIlp = 4;
-	auto load_key = [&](uint32_t i) -> uint64_t {
-		const uint32_t j = level == 0 ? i : cur[i];
-		return KW == 1 ? keys[kb + j] : keys[2 * (kb + j)];
-	};
-	auto bit_of_key = [&](uint64_t key) -> uint32_t {
-		LevelHasher hs(key);
-		uint64_t h = 0;
-		for (int l = 0; l <= level; l++)
-			h = hs.next(l);
-		return (uint32_t)reduce_level(h, size);
-	};
+	const uint32_t* __restrict__ mybits = lbits + kb;  // bit index of the i-th key of the group's current list (k_sliced_level_bits)
+	(void)keys;
 	const uint32_t rounds = (count + kGroupBlock * kIlp - 1) / (kGroupBlock * kIlp);
 	uint32_t mine = 0;
 	for (uint32_t r = 0; r < rounds; r++) {
-		uint64_t key[kIlp];
+		uint32_t bitv[kIlp];
 		bool in[kIlp];
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
 			const uint32_t i = (r * kIlp + u) * kGroupBlock + threadIdx.x;
 			in[u] = i < count;
-			key[u] = in[u] ? load_key(i) : 0;
+			bitv[u] = in[u] ? mybits[i] : 0;
 		}
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
 			if (!in[u])
 				continue;
-			const uint32_t b = bit_of_key(key[u]);
+			const uint32_t b = bitv[u];
 			const uint32_t lw = (b >> 5) - w0;
 			if (lw < wn) {
 				const uint32_t m = 1u << (b & 31);
@@ -866,21 +883,21 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_level_sliced(BuildGroups b
 		s_base = atomicAdd(&lvcnt[(uint64_t)(level + 1) * bg.ngroups + g], nsurv);
 	__syncthreads();
 	for (uint32_t r = 0; r < rounds; r++) {
-		uint64_t key[kIlp];
-		uint32_t jj[kIlp];
+		uint32_t bitv[kIlp];
+		uint32_t ii[kIlp];
 		bool in[kIlp];
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
 			const uint32_t i = (r * kIlp + u) * kGroupBlock + threadIdx.x;
 			in[u] = i < count;
-			jj[u] = in[u] ? (level == 0 ? i : cur[i]) : 0;
-			key[u] = in[u] ? (KW == 1 ? keys[kb + jj[u]] : keys[2 * (kb + jj[u])]) : 0;
+			ii[u] = i;
+			bitv[u] = in[u] ? mybits[i] : 0;
 		}
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
 			bool surv = false;
 			if (in[u]) {
-				const uint32_t b = bit_of_key(key[u]);
+				const uint32_t b = bitv[u];
 				const uint32_t lw = (b >> 5) - w0;
 				surv = lw < wn && ((s_coll[lw] >> (b & 31)) & 1u);
 			}
@@ -892,8 +909,8 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_level_sliced(BuildGroups b
 				if ((int)lane == leader)
 					base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
 				base = __shfl(base, leader);
-				if (surv)
-					nxt[s_base + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = jj[u];
+				if (surv)  // (the key's index: only survivors read the list)
+					nxt[s_base + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = level == 0 ? ii[u] : cur[ii[u]];
 			}
 		}
 	}
@@ -2047,7 +2064,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	v.fb_keys = nullptr;  // (not built yet; k_fill_positions does not look there)
 
 	// buffers of ONE pass: keys, two survivor lists, position fields, line popcounts
-	DevBuf d_keys, d_lA, d_lB, d_field, d_linepc, d_linepre;
+	DevBuf d_keys, d_lA, d_lB, d_field, d_linepc, d_linepre, d_lbits;
 	if (npass > 1 && BuildPool::current() && !(getenv("BLIGHT_POOL_TRIM") && atoi(getenv("BLIGHT_POOL_TRIM")) == 0))
 		BuildPool::current()->drain(true);  // bounded memory was asked for: the blocks K1-K5 have parked go back before the pass buffers are taken
 	BLMX_HIP(d_keys.alloc((max_keys + 1) * 8 * KW, false, s));
@@ -2056,6 +2073,8 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		BLMX_HIP(d_lB.alloc((max_keys + 1) * 4, false, s));
 	}
 	BLMX_HIP(d_field.alloc((max_keys + 1) * 4, false, s));
+	if (n_sliced)
+		BLMX_HIP(d_lbits.alloc((max_keys + 1) * 4, false, s));  // per-level bit indices of the sliced groups' keys (k_sliced_level_bits)
 	BLMX_HIP(d_linepc.alloc((max_lines + 2) * 8, false, s));
 	BLMX_HIP(d_linepre.alloc((max_lines + 2) * 8, false, s));
 	// the fallback table grows pass by pass (groups in increasing order = table order)
@@ -2155,11 +2174,20 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 				BLMX_HIP(d_glist.alloc(h_sliced.size() * 4, false, s));
 				BLMX_HIP(hipMemcpyAsync(d_items.p, h_items.data(), h_items.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
 				BLMX_HIP(hipMemcpyAsync(d_glist.p, h_sliced.data(), h_sliced.size() * 4, hipMemcpyHostToDevice, s));
+				uint32_t* lbits_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(d_lbits.p) - (uintptr_t)kb0 * 4);
+				uint64_t largest = 1;
+				for (uint32_t g : h_sliced)
+					largest = std::max<uint64_t>(largest, ix.h_groups[g].nkeys);
 				for (int l = 0; l < kLevels; l++) {
 					const size_t ni = level_off[l + 1] - level_off[l];
-					if (ni)
+					if (ni) {
+						// (the grid covers the largest group's level-0 list; deeper lists are shorter: workgroups beyond a list leave at once)
+						const unsigned gx = (unsigned)std::min<uint64_t>((largest + kBlock - 1) / kBlock, 1u << 16);
+						hipLaunchKernelGGL((k_sliced_level_bits<KW>), dim3(l == 0 ? gx : std::max(1u, gx >> std::min(l, 6)), (unsigned)h_sliced.size()), dim3(kBlock), 0, s, bg, keys_p, l,
+						                   d_glist.as<uint32_t>(), lA_p, lB_p, d_lvcnt.as<uint32_t>(), lbits_p);
 						hipLaunchKernelGGL((k_mphf_level_sliced<KW>), dim3((unsigned)ni), dim3(kGroupBlock), 0, s, bg, keys_p, l, d_items.as<uint2>() + level_off[l], lA_p,
-						                   lB_p, d_lvcnt.as<uint32_t>(), d_bits.as<uint32_t>());
+						                   lB_p, d_lvcnt.as<uint32_t>(), d_bits.as<uint32_t>(), lbits_p);
+					}
 					if (trace) {
 						char what[64];
 						snprintf(what, sizeof what, "  K7 sliced level %d (%zu wg)", l, ni);
