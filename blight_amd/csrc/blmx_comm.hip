@@ -191,11 +191,33 @@ struct LoopHub {
 	};
 	std::map<uint64_t, Coll> colls;
 	double timeout_s = 120.0;
+	bool poisoned = false;  // a wait has timed out: flows and collective slots of the ranks that did arrive are stale from then on
 
+	// (caller holds mu)  A rank that has waited in vain leaves posted flows and a collective sequence number behind that its peers will
+	// never match: the hub is dead from here on -- every later call on any of its communicators fails at once with BLMX_ERCCL instead
+	// of pulling a stale flow (a pointer its owner may have freed) or waiting out another deadline.
+	void poison()
+	{
+		poisoned = true;
+		for (auto& row : q)
+			for (auto& d : row)
+				d.clear();
+		colls.clear();
+		cv.notify_all();
+	}
+	void check(const char* what) const
+	{
+		if (poisoned)
+			throw StatusError{BLMX_ERCCL, std::string("loopback transport: an earlier collective timed out, this communicator group is dead (") + what + ")"};
+	}
 	template <typename Pred> void wait(std::unique_lock<std::mutex>& l, Pred pred, const char* what)
 	{
-		if (!cv.wait_for(l, std::chrono::duration<double>(timeout_s), pred))
-			throw StatusError{BLMX_ERCCL, std::string("loopback transport: a peer did not arrive (") + what + ")"};
+		check(what);
+		if (!cv.wait_for(l, std::chrono::duration<double>(timeout_s), [&] { return poisoned || pred(); }) || poisoned) {
+			const bool first = !poisoned;
+			poison();
+			throw StatusError{BLMX_ERCCL, std::string("loopback transport: ") + (first ? "a peer did not arrive (" : "a peer gave up waiting (") + what + ")"};
+		}
 	}
 };
 
@@ -299,6 +321,7 @@ struct LoopbackTransport final : Transport {
 			BLMX_HIP(hipEventRecord(f->ready, o.s));
 			{
 				std::lock_guard<std::mutex> l(hub->mu);
+				hub->check("post of a flow");
 				hub->q[me][o.peer].push_back(f);
 			}
 			hub->cv.notify_all();
@@ -314,8 +337,11 @@ struct LoopbackTransport final : Transport {
 				f = hub->q[o.peer][me].front();
 				hub->q[o.peer][me].pop_front();
 			}
-			if (f->n != o.n)
+			if (f->n != o.n) {
+				std::lock_guard<std::mutex> l(hub->mu);
+				hub->poison();
 				throw StatusError{BLMX_ERCCL, "loopback transport: send and receive disagree on the length of a flow"};
+			}
 			BLMX_HIP(hipStreamWaitEvent(o.s, f->ready, 0));
 			if (o.n)
 				BLMX_HIP(hipMemcpyAsync(o.p, f->p, o.n * 8, hipMemcpyDeviceToDevice, o.s));

@@ -430,11 +430,18 @@ namespace {
 void wait_small(SmallSlot& sl, volatile unsigned int* flag, unsigned int ticket)
 {
 	for (int spin = 0; spin < 400000; spin++) {
-		if (*flag == ticket)
+		if (__atomic_load_n(const_cast<const unsigned int*>(flag), __ATOMIC_ACQUIRE) == ticket)  // (the answers are read behind this)
 			return;
 		_mm_pause();
 	}
+	// The flag never came (a launch of this round failed after the slot's target had been raised, or the device is slow beyond reason):
+	// the stream says when the round is over, and the slot's count starts afresh -- otherwise every later round on this slot would
+	// spin out its 400,000 polls before falling back to the stream.
 	BLMX_HIP(hipStreamSynchronize(sl.s));
+	BLMX_HIP(hipMemsetAsync(sl.counter.p, 0, 64, sl.s));
+	BLMX_HIP(hipStreamSynchronize(sl.s));
+	sl.target = 0;
+	std::atomic_thread_fence(std::memory_order_acquire);
 }
 
 // answer everything in `batch` with (at most) one fused read launch and one k-mer launch on one pinned slot
@@ -495,11 +502,20 @@ void serve_small(Index& ix, HostFront& hf, std::vector<SmallReq*>& batch, AfterL
 	// a round of ONE wave / workgroup (a k-mer, a read) signals by itself: no device-side count
 	const DoneSignal done{units > 1 ? sl.counter.as<unsigned int>() : nullptr, flag, sl.target, sl.ticket};
 	const uint64_t t_packed = tr ? now_ns() : 0;
-	if (nk_seq)
-		launch_read_query(ix, nullptr, reinterpret_cast<const uint8_t*>(base + o_chars), nbytes, nbytes, h_offs, h_koffs, nseq,
-		                  reinterpret_cast<int64_t*>(base + o_ids), nullptr, h_err, sl.s, done);
-	if (nkm)
-		launch_query(ix, base + o_kmers, nullptr, nkm, base + o_kids, kQueryIds, sl.s, done);
+	try {
+		if (nk_seq)
+			launch_read_query(ix, nullptr, reinterpret_cast<const uint8_t*>(base + o_chars), nbytes, nbytes, h_offs, h_koffs, nseq,
+			                  reinterpret_cast<int64_t*>(base + o_ids), nullptr, h_err, sl.s, done);
+		if (nkm)
+			launch_query(ix, base + o_kmers, nullptr, nkm, base + o_kids, kQueryIds, sl.s, done);
+	} catch (...) {
+		// one of the launches was not enqueued: the slot's device counter will never reach the target that was raised for this round
+		(void)hipStreamSynchronize(sl.s);
+		(void)hipMemsetAsync(sl.counter.p, 0, 64, sl.s);
+		(void)hipStreamSynchronize(sl.s);
+		sl.target = 0;
+		throw;
+	}
 	after_launch();  // (the next leader may gather, pack and launch on another slot while this launch is in flight)
 	const uint64_t t_launched = tr ? now_ns() : 0;
 	if (units)

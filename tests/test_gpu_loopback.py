@@ -233,3 +233,43 @@ def test_loopback_ranks_must_agree_on_the_world():
     with pytest.raises(ValueError):
         B.Comm(uid, 1, 3)
     a.close()
+
+
+def test_a_rank_that_never_arrives_kills_the_group_not_the_process(monkeypatch):
+    """Every wait of the loopback transport has a deadline.  A rank that waits in vain (its peer threw before the collective, or never
+    called it) gets BLMX_ERCCL -- and the group is dead from then on: what the ranks that did arrive had posted is stale, so every later
+    collective on any communicator of the id fails AT ONCE instead of pulling a stale flow or waiting out another deadline."""
+    import time
+    import torch
+    import blight_amd as B
+    monkeypatch.setenv("BLIGHT_LOOPBACK_TIMEOUT", "1.5")
+    rng = np.random.default_rng(3)
+    k, m, n, b = 31, 9, 6, 6
+    seqs = [_rand_seq(rng, 200) for _ in range(800)]
+    shards = []
+    for r in range(2):
+        a = B.kmer_Set_Light(k, m, n, 3, 1, b)
+        a.set_shard(r, 2)
+        a.construct_index_from_sequences(seqs)
+        shards.append(a)
+    uid = B.comm_loopback_id()
+    comms = [None, None]
+
+    def mk(r):
+        comms[r] = B.Comm(uid, r, 2, device=0)
+    run_ranks(2, mk)
+    dev = torch.device("cuda", 0)
+    q = torch.randint(0, 1 << 60, (5000,), dtype=torch.int64, device=dev)
+    out = torch.empty(5000, dtype=torch.int64, device=dev)
+    t0 = time.time()
+    with pytest.raises(Exception, match="did not arrive|gave up"):  # rank 1 never calls
+        comms[0].query_kmers_sharded_device(shards[0], q.data_ptr(), 5000, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert 1.0 < time.time() - t0 < 20.0
+    for r in (1, 0):
+        t0 = time.time()
+        with pytest.raises(Exception, match="dead|did not arrive|gave up"):
+            comms[r].query_kmers_sharded_device(shards[r], q.data_ptr(), 5000, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert time.time() - t0 < 1.0  # at once: no second deadline
+    torch.cuda.synchronize()
+    for c in comms:
+        c.close()
