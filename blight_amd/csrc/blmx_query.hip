@@ -689,7 +689,28 @@ struct RunTable {
 	uint32_t* count;
 };
 
-template <int KW, int BPT>
+#ifndef BLMX_EXP_STAMP
+#define BLMX_EXP_STAMP 0
+#endif
+#if BLMX_EXP_STAMP
+// variant build only (python -m blight_amd.build --variant stamp -DBLMX_EXP_STAMP=1): shader-clock time of wave 0 of every workgroup between
+// the phase boundaries of k_bin_onepass, summed over tiles; printed by the launching function every 16th batch
+__device__ unsigned long long g_bin_stamps[16];
+#define BLMX_STAMP(I)                                                                \
+	do {                                                                             \
+		if (t == 0) {                                                                \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+			atomicAdd(&g_bin_stamps[I], now_ - stamp_);                              \
+			stamp_ = now_;                                                           \
+		}                                                                            \
+	} while (0)
+#else
+#define BLMX_STAMP(I) \
+	do {              \
+	} while (0)
+#endif
+constexpr int kWaitVmcnt0 = 0x0F70;  // s_waitcnt vmcnt(0) alone on gfx9: expcnt = 7, lgkmcnt = 15 left open
+template <int KW, int BPT, bool MINIS>  // MINIS: the caller hands the minimizers over (read front end), they are loaded with the k-mers
 __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, const SlotPlan* __restrict__ sp, const uint64_t* __restrict__ kmers,
                                                          const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
                                                          uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint16_t* __restrict__ lpos,
@@ -727,6 +748,29 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	// issued its stores goes on hashing; 6 -> 4 barriers per tile): the barrier behind the minimizer phase of t + 1 is the one that
 	// says "tile t has been read".
 	__syncthreads();
+	// The k-mers of a tile are loaded one tile AHEAD, all of a thread's loads at once, right behind the barrier that ends the minimizer
+	// phase, and they are waited for BEFORE the copy-out issues its stores: vmcnt counts loads and stores in one queue on this ISA, so a
+	// load issued behind the copy-out's stores can only be waited for together with them -- which put the whole drain of a tile's
+	// 114 KB (and one load latency per k-mer) in front of the minimizer phase of the next tile (r04: the kernel took VALU time PLUS
+	// memory time, 0.75 + 0.65 ms at C4).  Now the minimizer phase starts from registers and runs while the stores drain.
+	Kmer<KW> xn[kPer];
+	uint32_t mn[MINIS ? kPer : 1];
+	auto load_tile = [&](uint64_t tile_) {
+#pragma unroll
+		for (int e = 0; e < kPer; e++) {
+			const uint64_t i = tile_ * kTile + (uint64_t)e * THREADS + t;
+			if (i < nq) {
+				xn[e] = load_kmer<KW>(kmers, i);
+				if constexpr (MINIS)
+					mn[e] = minis_in[i];
+			}
+		}
+	};
+	load_tile(blockIdx.x);
+	__builtin_amdgcn_s_waitcnt(kWaitVmcnt0);
+#if BLMX_EXP_STAMP
+	unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
 	uint32_t par = 0;
 	for (uint64_t tile = blockIdx.x; tile * kTile < nq; tile += gridDim.x, par ^= 1u) {
 	uint32_t* const s_cnt = s_cnt2[par];
@@ -738,13 +782,19 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		const uint64_t i = base + (uint64_t)e * THREADS + t;
 		mini[e] = 0;
 		rank[e] = 0;
+		x[e] = xn[e];
 		if (i < nq) {
-			x[e] = load_kmer<KW>(kmers, i);
-			mini[e] = minis_in ? minis_in[i] : kmer_minimizer<KW>(x[e], kmer_rc<KW>(x[e], k), k, m);
+			if constexpr (MINIS)
+				mini[e] = mn[e];
+			else
+				mini[e] = kmer_minimizer<KW>(x[e], kmer_rc<KW>(x[e], k), k, m);
 			rank[e] = atomicAdd(&s_cnt[bm.bin_of(mini[e])], 1u);
 		}
 	}
+	BLMX_STAMP(0);  // minimizer phase
 	__syncthreads();
+	BLMX_STAMP(1);  // its barrier
+	load_tile(tile + gridDim.x);
 	// BPT bins per thread: tile-local exclusive scan of the counts, slot reservation in the bin and in the overflow region
 	{
 		uint32_t c[BPT], mine = 0;
@@ -780,7 +830,9 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 			rt.obase[ri] = ob;
 			rt.count[ri] = c[j];
 		}
+		BLMX_STAMP(2);  // scan + slot reservation (global atomics)
 		__syncthreads();
+		BLMX_STAMP(3);
 		uint32_t wbase = 0;
 		for (uint32_t w = 0; w < wave; w++)
 			wbase += s_wsum[w];
@@ -792,6 +844,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		}
 	}
 	__syncthreads();
+	BLMX_STAMP(4);  // bin starts + barrier
 	auto slot_of = [&](uint32_t b, uint32_t r) -> uint64_t {  // r-th k-mer of this tile's run of bin b
 		const uint32_t g = s_gbase[b], gs = g + r, capb = s_rcap[b];
 		return gs < capb ? (uint64_t)s_rbase[b] + gs : (uint64_t)ovf_at + s_obase[b] + (gs - max(g, capb));
@@ -812,7 +865,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 			lpos[i] = (uint16_t)ls;
 		}
 	}
+	BLMX_STAMP(5);  // scatter into LDS
 	__syncthreads();
+	BLMX_STAMP(6);
+	__builtin_amdgcn_s_waitcnt(kWaitVmcnt0);  // the next tile's k-mers are in their registers before the first store below is issued
 	const uint32_t count = (uint32_t)min((uint64_t)kTile, nq - base);
 	uint32_t dropped = 0;
 	for (uint32_t sidx = t; sidx < count; sidx += THREADS) {
@@ -834,6 +890,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	}
 	if (dropped)
 		atomicAdd(&cursors[nbins_p + 1], dropped);
+	BLMX_STAMP(7);  // wait for the next tile's k-mers + copy-out issued
 	}
 }
 
@@ -1273,9 +1330,16 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	ix.prof_mark(2, s);
 	ix.prof_mark(3, s);
 	const uint32_t pgrid = onepass_grid(nblk);
-#define BLMX_OP(KWV, BPTV)                                                                                                                              \
-	hipLaunchKernelGGL((k_bin_onepass<KWV, BPTV>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors, \
+#define BLMX_OP1(KWV, BPTV, MV)                                                                                                                              \
+	hipLaunchKernelGGL((k_bin_onepass<KWV, BPTV, MV>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors, \
 	                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt)
+#define BLMX_OP(KWV, BPTV)      \
+	do {                        \
+		if (d_minis)            \
+			BLMX_OP1(KWV, BPTV, true);  \
+		else                    \
+			BLMX_OP1(KWV, BPTV, false); \
+	} while (0)
 	if (ix.KW == 1) {
 		if (bpt == 2)
 			BLMX_OP(1, 2);
@@ -1285,6 +1349,23 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 		BLMX_OP(2, 1);
 	}
 #undef BLMX_OP
+#undef BLMX_OP1
+#if BLMX_EXP_STAMP
+	{
+		static int calls = 0;
+		if (++calls % 16 == 0) {
+			unsigned long long h[16];
+			(void)hipStreamSynchronize(s);
+			(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bin_stamps), sizeof h);
+			fprintf(stderr, "[bin stamps, 16 batches, cycles of wave 0 summed over workgroups and tiles, 100 MHz ticks]");
+			for (int i = 0; i < 8; i++)
+				fprintf(stderr, " %d:%llu", i, h[i]);
+			fprintf(stderr, "\n");
+			memset(h, 0, sizeof h);
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(g_bin_stamps), h, sizeof h);
+		}
+	}
+#endif
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(4, s);
 	if (ix.KW == 1)
@@ -1436,12 +1517,21 @@ void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const u
 	                   (uint32_t)n, 1024u, sp.plan.as<SlotPlan>(), sp.cursors.as<uint32_t>());
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	const uint32_t pgrid = onepass_grid(sp.nblk);
-	if (ix.KW == 1)
-		hipLaunchKernelGGL((k_bin_onepass<1, 1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
-		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
-	else
-		hipLaunchKernelGGL((k_bin_onepass<2, 1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n,
-		                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt);
+#define BLMX_OPP(KWV, MV)                                                                                                                                        \
+	hipLaunchKernelGGL((k_bin_onepass<KWV, 1, MV>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n, \
+	                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt)
+	if (ix.KW == 1) {
+		if (d_minis)
+			BLMX_OPP(1, true);
+		else
+			BLMX_OPP(1, false);
+	} else {
+		if (d_minis)
+			BLMX_OPP(2, true);
+		else
+			BLMX_OPP(2, false);
+	}
+#undef BLMX_OPP
 	FirstBins f;
 	f.world = world;
 	for (uint32_t r = 0; r <= world; r++)
