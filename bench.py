@@ -83,6 +83,7 @@ def parse_args():
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-buffer / file / per-read-call measurements")
     ap.add_argument("--batches", type=int, default=4, help="independently seeded query batches rotated through the timed loop")
     ap.add_argument("--no-fasta-leg", action="store_true", help="skip construct_index(file) on files written to tmpfs")
+    ap.add_argument("--tune", action="append", default=[], help=argparse.SUPPRESS)  # experiments: name=value passed to blmx_set_tuning before the timed steps
     ap.add_argument("--exp-sort", type=int, default=-1, help=argparse.SUPPRESS)  # experiment: order every batch by (MPHF group, top N bits of the level-0 hash)
     ap.add_argument("--no-excursion", action="store_true", help="skip the all-absent / all-indexed batches after the timed steps (profiling runs: "
                                                                 "every launch of the query kernels is then a headline step)")
@@ -792,6 +793,8 @@ def main():
     t0 = time.time()
     ix.construct_index_from_device(ascii_.data_ptr(), offs.data_ptr(), offs.numel() - 1, total)
     t_build = time.time() - t0
+    for tv in args.tune:
+        ix.set_tuning(tv.split("=")[0], int(tv.split("=")[1]))
     ix.set_tuning("absent_filter", 1)  # the filter's passes run in the background after the build: the timed steps start with it armed
     t_build_armed = time.time() - t0   # build + the filter's background passes: the state the timed queries run on
     t_filter_bg = t_build_armed - t_build

@@ -834,6 +834,8 @@ int blmx_set_tuning(blmx_index* h, const char* key, int value)
 		ix.tune_serve_burst = value != 0;
 	} else if (k == "fb_table")  // before building / loading: 0 = no hash tables over the fallback entries (lookups search the sorted arrays)
 		ix.tune_fb_table = value != 0;
+	else if (k == "bin_rounds")  // the one-pass partition kernel stages a tile in this many pieces: 2 (two workgroups per CU) or 1
+		ix.tune_bin_rounds = value == 1 ? 1 : 2;
 	else if (k == "max_batch")  // test hook: device-resident batches are answered in pieces of this many k-mers (0 = 2^30)
 		ix.tune_max_batch = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
 	else if (k == "test_ovf_cap")  // test hook: slots of the one-pass partition's overflow region (0 = a whole batch)

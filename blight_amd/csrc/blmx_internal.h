@@ -485,6 +485,7 @@ struct Index {
 	// every later call on this index.  test_ovf_cap (test hook) shrinks the overflow region to provoke it.
 	unsigned long long* h_dropped = nullptr;
 	int tune_test_ovf_cap = 0;
+	int tune_bin_rounds = 2;  // k_bin_onepass: 2 = two workgroups per CU staging half a tile at a time (default), 1 = one per CU staging all of it
 	int tune_max_batch = 0;  // test hook: k-mers per piece of a device-resident batch (0 = 2^30)
 	unsigned long long* dropped_word()
 	{

@@ -710,25 +710,32 @@ __device__ unsigned long long g_bin_stamps[16];
 	} while (0)
 #endif
 constexpr int kWaitVmcnt0 = 0x0F70;  // s_waitcnt vmcnt(0) alone on gfx9: expcnt = 7, lgkmcnt = 15 left open
-template <int KW, int BPT, bool MINIS>  // MINIS: the caller hands the minimizers over (read front end), they are loaded with the k-mers
-__global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMap bm, const SlotPlan* __restrict__ sp, const uint64_t* __restrict__ kmers,
-                                                         const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
-                                                         uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint16_t* __restrict__ lpos,
-                                                         RunTable rt)
+// MINIS: the caller hands the minimizers over (read front end), they are loaded with the k-mers.
+// THREADS = 1024: one workgroup per CU (123 KB of LDS), the whole tile staged in bin order and copied out at once, the next tile's k-mers
+// loaded one tile ahead.  THREADS = 512 (r04, the default for up to 1024 bins): TWO workgroups per CU, each staging its tile in two
+// pieces of half a tile (72 KB of LDS each), 16 k-mers and two bins per thread: while one workgroup reserves slots (a global atomic
+// round trip), scatters into LDS and issues its stores -- a third of a tile's time with nothing for the vector ALUs to do, see the
+// phase stamps in profiles/r04_exp_partition_kernel_c4.txt -- the other one computes minimizers.
+template <int KW, int BPT, bool MINIS, int THREADS, int ROUNDS>
+__global__ __launch_bounds__(THREADS, ROUNDS * THREADS / 256) void k_bin_onepass(int k, int m, BinMap bm, const SlotPlan* __restrict__ sp, const uint64_t* __restrict__ kmers,
+                                                     const uint32_t* __restrict__ minis_in, uint64_t nq, uint32_t* __restrict__ cursors,
+                                                     uint64_t* __restrict__ slots, uint32_t* __restrict__ slot_minis, uint16_t* __restrict__ lpos,
+                                                     RunTable rt)
 {
 	constexpr int kTile = BinTile<KW>::value;
-	constexpr int THREADS = kBinThreads;
 	constexpr int kPer = kTile / THREADS;
 	constexpr int kNB = BPT * THREADS;  // BPT bins per thread
-	__shared__ uint64_t s_keys[kTile * KW];
-	__shared__ uint32_t s_mini[kTile];
+	constexpr int kStage = kTile / ROUNDS;  // the tile is staged and copied out in ROUNDS pieces of kStage k-mers (in bin order)
+	constexpr bool AHEAD = ROUNDS == 1;
+	__shared__ uint64_t s_keys[kStage * KW];
+	__shared__ uint32_t s_mini[kStage];
 	__shared__ uint32_t s_cnt2[2][kNB];  // k-mers of this tile per bin, then the tile-local start of the bin; tiles alternate between the two
 	__shared__ uint32_t s_gbase[kNB];   // first slot (inside the bin) of this tile's run
 	__shared__ uint32_t s_obase[kNB];   // first overflow slot of the part of the run that does not fit the bin
 	__shared__ uint32_t s_rbase[kNB];   // the bin's region: first slot ...
 	__shared__ uint32_t s_rcap[kNB];    // ... and slots
 	__shared__ uint32_t s_wsum[THREADS / 64];
-	static_assert(kTile <= 65536 && kTile % THREADS == 0, "16-bit tile-local positions");
+	static_assert(kTile <= 65536 && kTile % THREADS == 0 && kTile % ROUNDS == 0, "16-bit tile-local positions");
 	const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	{
 		const uint32_t nb = sp->nbins;
@@ -745,14 +752,13 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	// A workgroup walks over tiles (grid = a few workgroups per CU, or one per tile): the stores of one tile drain while the minimizers
 	// of the next are computed, the region table is loaded once, and there is no dispatch gap between tiles.  r04: the counters are
 	// double-buffered, so that no barrier separates the copy-out of tile t from the minimizer phase of tile t + 1 (a wave that has
-	// issued its stores goes on hashing; 6 -> 4 barriers per tile): the barrier behind the minimizer phase of t + 1 is the one that
-	// says "tile t has been read".
+	// issued its stores goes on hashing): the barrier behind the minimizer phase of t + 1 is the one that says "tile t has been read".
 	__syncthreads();
-	// The k-mers of a tile are loaded one tile AHEAD, all of a thread's loads at once, right behind the barrier that ends the minimizer
-	// phase, and they are waited for BEFORE the copy-out issues its stores: vmcnt counts loads and stores in one queue on this ISA, so a
-	// load issued behind the copy-out's stores can only be waited for together with them -- which put the whole drain of a tile's
-	// 114 KB (and one load latency per k-mer) in front of the minimizer phase of the next tile (r04: the kernel took VALU time PLUS
-	// memory time, 0.75 + 0.65 ms at C4).  Now the minimizer phase starts from registers and runs while the stores drain.
+	// One workgroup per CU: the k-mers of a tile are loaded one tile AHEAD, all of a thread's loads at once, right behind the barrier that
+	// ends the minimizer phase, and they are waited for BEFORE the copy-out issues its stores: vmcnt counts loads and stores in one queue
+	// on this ISA, so a load issued behind the copy-out's stores can only be waited for together with them -- which put the whole drain
+	// of a tile's 114 KB (and one load latency per k-mer) in front of the minimizer phase of the next tile.  Two workgroups per CU: all
+	// of a thread's loads at once at the head of the tile (the other workgroup computes meanwhile; no registers for a second tile).
 	Kmer<KW> xn[kPer];
 	uint32_t mn[MINIS ? kPer : 1];
 	auto load_tile = [&](uint64_t tile_) {
@@ -766,8 +772,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 			}
 		}
 	};
-	load_tile(blockIdx.x);
-	__builtin_amdgcn_s_waitcnt(kWaitVmcnt0);
+	if constexpr (AHEAD) {
+		load_tile(blockIdx.x);
+		__builtin_amdgcn_s_waitcnt(kWaitVmcnt0);
+	}
 #if BLMX_EXP_STAMP
 	unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -777,6 +785,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	const uint64_t base = tile * kTile;
 	Kmer<KW> x[kPer];
 	uint32_t mini[kPer], rank[kPer];
+	if constexpr (!AHEAD)
+		load_tile(tile);
 #pragma unroll
 	for (int e = 0; e < kPer; e++) {
 		const uint64_t i = base + (uint64_t)e * THREADS + t;
@@ -794,7 +804,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 	BLMX_STAMP(0);  // minimizer phase
 	__syncthreads();
 	BLMX_STAMP(1);  // its barrier
-	load_tile(tile + gridDim.x);
+	if constexpr (AHEAD)
+		load_tile(tile + gridDim.x);
 	// BPT bins per thread: tile-local exclusive scan of the counts, slot reservation in the bin and in the overflow region
 	{
 		uint32_t c[BPT], mine = 0;
@@ -849,48 +860,63 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_onepass(int k, int m, BinMa
 		const uint32_t g = s_gbase[b], gs = g + r, capb = s_rcap[b];
 		return gs < capb ? (uint64_t)s_rbase[b] + gs : (uint64_t)ovf_at + s_obase[b] + (gs - max(g, capb));
 	};
+	// rank[] becomes the tile-local position in bin order
 #pragma unroll
 	for (int e = 0; e < kPer; e++) {
 		const uint64_t i = base + (uint64_t)e * THREADS + t;
 		if (i < nq) {
-			const uint32_t b = bm.bin_of(mini[e]);
-			const uint32_t ls = s_cnt[b] + rank[e];
-			if constexpr (KW == 1) {
-				s_keys[ls] = x[e].lo;
-			} else {
-				s_keys[2 * ls] = x[e].lo;
-				s_keys[2 * ls + 1] = x[e].hi;
-			}
-			s_mini[ls] = mini[e];
-			lpos[i] = (uint16_t)ls;
+			rank[e] += s_cnt[bm.bin_of(mini[e])];
+			lpos[i] = (uint16_t)rank[e];
 		}
 	}
-	BLMX_STAMP(5);  // scatter into LDS
-	__syncthreads();
-	BLMX_STAMP(6);
-	__builtin_amdgcn_s_waitcnt(kWaitVmcnt0);  // the next tile's k-mers are in their registers before the first store below is issued
 	const uint32_t count = (uint32_t)min((uint64_t)kTile, nq - base);
 	uint32_t dropped = 0;
-	for (uint32_t sidx = t; sidx < count; sidx += THREADS) {
-		const uint32_t mi = s_mini[sidx];
-		const uint32_t b = bm.bin_of(mi);
-		const uint64_t dst = slot_of(b, sidx - s_cnt[b]);
-		if (dst >= all_slots) {  // cannot happen (the overflow region holds a whole batch) -- but if it ever does it must not pass for an
-			dropped++;           // absent k-mer: counted, and the call fails (k_plan_learn -> Index::check_dropped)
-			continue;
+#pragma unroll
+	for (int r = 0; r < ROUNDS; r++) {
+		const uint32_t r0 = (uint32_t)r * kStage;
+		if (r)
+			__syncthreads();  // the copy-out of the piece before has read the staging area
+#pragma unroll
+		for (int e = 0; e < kPer; e++) {
+			const uint64_t i = base + (uint64_t)e * THREADS + t;
+			const uint32_t ls = rank[e] - r0;  // wraps for a k-mer of an earlier piece
+			if (i < nq && ls < (uint32_t)kStage) {
+				if constexpr (KW == 1) {
+					s_keys[ls] = x[e].lo;
+				} else {
+					s_keys[2 * ls] = x[e].lo;
+					s_keys[2 * ls + 1] = x[e].hi;
+				}
+				s_mini[ls] = mini[e];
+			}
 		}
-		if (slot_minis)
-			slot_minis[dst] = mi;
-		if constexpr (KW == 1) {
-			slots[dst] = s_keys[sidx];
-		} else {
-			slots[2 * dst] = s_keys[2 * sidx];
-			slots[2 * dst + 1] = s_keys[2 * sidx + 1];
+		BLMX_STAMP(5);  // scatter into LDS
+		__syncthreads();
+		BLMX_STAMP(6);
+		if constexpr (AHEAD)
+			__builtin_amdgcn_s_waitcnt(kWaitVmcnt0);  // the next tile's k-mers are in their registers before the first store below is issued
+		const uint32_t r1 = min(count, r0 + (uint32_t)kStage);
+		for (uint32_t sidx = r0 + t; sidx < r1; sidx += THREADS) {
+			const uint32_t mi = s_mini[sidx - r0];
+			const uint32_t b = bm.bin_of(mi);
+			const uint64_t dst = slot_of(b, sidx - s_cnt[b]);
+			if (dst >= all_slots) {  // cannot happen (the overflow region holds a whole batch) -- but if it ever does it must not pass for an
+				dropped++;           // absent k-mer: counted, and the call fails (k_plan_learn -> Index::check_dropped)
+				continue;
+			}
+			if (slot_minis)
+				slot_minis[dst] = mi;
+			if constexpr (KW == 1) {
+				slots[dst] = s_keys[sidx - r0];
+			} else {
+				slots[2 * dst] = s_keys[2 * (sidx - r0)];
+				slots[2 * dst + 1] = s_keys[2 * (sidx - r0) + 1];
+			}
 		}
+		BLMX_STAMP(7);  // (wait for the next tile's k-mers +) copy-out issued
 	}
 	if (dropped)
 		atomicAdd(&cursors[nbins_p + 1], dropped);
-	BLMX_STAMP(7);  // wait for the next tile's k-mers + copy-out issued
 	}
 }
 
@@ -1248,18 +1274,20 @@ static void launch_query_slots_kw(const Index& ix, const SlotPlan* d_plan, uint3
 
 // workgroups of k_bin_onepass: three per compute unit that walk over the tiles (one per tile: 1.55 ms per 1e8 at C4; 512 .. 2048
 // walking workgroups: 1.45 - 1.48 ms, profiles/r03_exp_onepass_grid_c4.txt); BLIGHT_ONEPASS_GRID=n overrides (0 = one per tile)
-static uint32_t onepass_grid(uint32_t nblk)
+static uint32_t onepass_grid(uint32_t nblk, int resident = 1)
 {
-	static const int n = [] {
-		const char* e = getenv("BLIGHT_ONEPASS_GRID");
-		if (e)
-			return atoi(e);
-		int dev = 0, cus = 256;
+	static const int cus = [] {
+		int dev = 0;
 		hipDeviceProp_t prop;
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-			cus = prop.multiProcessorCount;
-		return 3 * cus;
+			return (int)prop.multiProcessorCount;
+		return 256;
 	}();
+	static const int env = [] {
+		const char* e = getenv("BLIGHT_ONEPASS_GRID");
+		return e ? atoi(e) : -1;
+	}();
+	const int n = env >= 0 ? env : 3 * cus * resident;  // `resident` workgroups fit a CU
 	return n > 0 ? std::min<uint32_t>(nblk, (uint32_t)n) : nblk;
 }
 
@@ -1329,24 +1357,28 @@ static void query_ids_onepass(Index& ix, const void* d_kmers, const uint32_t* d_
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	ix.prof_mark(2, s);
 	ix.prof_mark(3, s);
-	const uint32_t pgrid = onepass_grid(nblk);
-#define BLMX_OP1(KWV, BPTV, MV)                                                                                                                              \
-	hipLaunchKernelGGL((k_bin_onepass<KWV, BPTV, MV>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, d_cursors, \
-	                   ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt)
-#define BLMX_OP(KWV, BPTV)      \
-	do {                        \
-		if (d_minis)            \
-			BLMX_OP1(KWV, BPTV, true);  \
-		else                    \
-			BLMX_OP1(KWV, BPTV, false); \
+#define BLMX_OP1(KWV, BPTV, MV, TV, RV)                                                                                                                        \
+	hipLaunchKernelGGL((k_bin_onepass<KWV, BPTV, MV, TV, RV>), dim3(onepass_grid(nblk, RV)), dim3(TV), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, d_plan, km, d_minis, nq, \
+	                   d_cursors, ix.b_sorted.as<uint64_t>(), d_slot_minis, d_lpos, rt)
+#define BLMX_OP(KWV, BPTV, TV, RV)              \
+	do {                                        \
+		if (d_minis)                            \
+			BLMX_OP1(KWV, BPTV, true, TV, RV);  \
+		else                                    \
+			BLMX_OP1(KWV, BPTV, false, TV, RV); \
 	} while (0)
+	const bool two_wg = ix.tune_bin_rounds != 1;  // two workgroups per CU staging half a tile at a time (default) or one staging all of it
 	if (ix.KW == 1) {
 		if (bpt == 2)
-			BLMX_OP(1, 2);
+			BLMX_OP(1, 2, 1024, 1);
+		else if (two_wg)
+			BLMX_OP(1, 1, 1024, 2);
 		else
-			BLMX_OP(1, 1);
+			BLMX_OP(1, 1, 1024, 1);
+	} else if (two_wg) {
+		BLMX_OP(2, 1, 1024, 2);
 	} else {
-		BLMX_OP(2, 1);
+		BLMX_OP(2, 1, 1024, 1);
 	}
 #undef BLMX_OP
 #undef BLMX_OP1
@@ -1517,9 +1549,17 @@ void slot_piece_partition(Index& ix, SlotPiece& sp, const void* d_kmers, const u
 	                   (uint32_t)n, 1024u, sp.plan.as<SlotPlan>(), sp.cursors.as<uint32_t>());
 	const uint64_t* km = reinterpret_cast<const uint64_t*>(d_kmers);
 	const uint32_t pgrid = onepass_grid(sp.nblk);
-#define BLMX_OPP(KWV, MV)                                                                                                                                        \
-	hipLaunchKernelGGL((k_bin_onepass<KWV, 1, MV>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm, sp.plan.as<SlotPlan>(), km, d_minis, n, \
-	                   sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(), sp.lpos.as<uint16_t>(), rt)
+#define BLMX_OPP(KWV, MV)                                                                                                                                  \
+	do {                                                                                                                                                   \
+		if (ix.tune_bin_rounds != 1)                                                                                                                       \
+			hipLaunchKernelGGL((k_bin_onepass<KWV, 1, MV, 1024, 2>), dim3(onepass_grid(sp.nblk, 2)), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m,   \
+			                   bm, sp.plan.as<SlotPlan>(), km, d_minis, n, sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(),       \
+			                   sp.lpos.as<uint16_t>(), rt);                                                                                                \
+		else                                                                                                                                               \
+			hipLaunchKernelGGL((k_bin_onepass<KWV, 1, MV, 1024, 1>), dim3(pgrid), dim3(kBinThreads), 0, s, (int)ix.prm.k, (int)ix.prm.m, bm,                  \
+			                   sp.plan.as<SlotPlan>(), km, d_minis, n, sp.cursors.as<uint32_t>(), sp.slots.as<uint64_t>(), sp.minis.as<uint32_t>(),           \
+			                   sp.lpos.as<uint16_t>(), rt);                                                                                                \
+	} while (0)
 	if (ix.KW == 1) {
 		if (d_minis)
 			BLMX_OPP(1, true);
