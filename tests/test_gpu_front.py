@@ -392,6 +392,12 @@ def test_partition_paths_and_skewed_batches(B, O, k, kb, b):
                 ix.set_tuning("partition", part)
                 ix.set_tuning("bin_bits", bits)
                 assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), (name, part, bits)
+        # the one-pass kernel as one workgroup per CU that stages a whole tile (default: two, half a tile at a time)
+        ix.set_tuning("partition", 1)
+        ix.set_tuning("bin_bits", 0)
+        ix.set_tuning("bin_rounds", 1)
+        assert np.array_equal(ix.query_kmer_hash(q.reshape(-1)), want), (name, "bin_rounds=1")
+        ix.set_tuning("bin_rounds", 2)
     ix.set_tuning("partition", 0)
     ix.set_tuning("bin_bits", 0)
     # automatic mode over a sequence of batches: regions learnt from a batch of the same distribution, then from a very different one
