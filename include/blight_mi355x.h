@@ -309,6 +309,8 @@ int blmx_set_query_binning(blmx_index* ix, int policy);
  *                    the first batch, afterwards one pass into bin regions sized after the previous batch (default); 1 = always
  *                    one pass; 2 = always the exact sort.  "slot_slack_pct": slack of the regions (0 = default).
  *   "bin_bits"       partition bins = 2^value (0 = default: 10 with the one-pass partition, 9 with the exact one)
+ *   "bin_rounds"     the one-pass partition kernel stages a tile of k-mers in LDS in 2 pieces, two workgroups per compute unit (default), or
+ *                    in 1, one workgroup per compute unit that loads the next tile's k-mers ahead
  *   "mini_handoff"   1/0/-1: the partition pass hands the minimizers to the query kernel / it recomputes them / automatic
  *   "query_heads"    0: query kernels read the full group descriptor instead of the compact head
  *   "reads_mode"     sequence / file queries: 0 automatic, 1 front end fused with the query body, 2 front end -> partitioned pipeline
