@@ -690,6 +690,20 @@ def fasta_leg(torch, B, dev, ascii_, offs, k, m, n, b, kw, args):
                          "same_unitigs_from_hbm_seconds": t_dev, "equal_to_build_from_hbm": bool(same)}
             f.close()
             if gz:
+                # the denominator of that figure: zlib's inflate alone on one host thread over the same file (the library reads it with
+                # gzread; one DEFLATE stream cannot be inflated by two threads), nothing parsed, nothing copied to the card
+                import zlib
+                t0 = time.perf_counter()
+                dobj, nout = zlib.decompressobj(31), 0
+                with open(fpath, "rb") as fh:
+                    while True:
+                        chunk = fh.read(1 << 20)
+                        if not chunk:
+                            break
+                        nout += len(dobj.decompress(chunk))
+                t_z = time.perf_counter() - t0
+                out[name]["zlib_inflate_alone"] = {"seconds": t_z, "text_GB_per_s": nout / t_z / 1e9, "threads": 1,
+                                                   "share_of_the_build": t_z / secs}
                 os.unlink(fpath)
     finally:
         for fn in os.listdir(tmpdir):
