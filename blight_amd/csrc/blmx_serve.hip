@@ -24,6 +24,7 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <immintrin.h>
 
 #include "blmx_internal.h"
@@ -45,10 +46,14 @@ struct BurstHead {
 	uint32_t posted;    // sequence number of the request in the slot (host; 0 = never used)
 	uint32_t what;      // bit 31: a read (characters), else k-mers; bit 30: membership bytes wanted; low bits: characters / k-mers
 	uint64_t kmer0[2];  // the first k-mer (scalar calls need nothing else)
+	uint32_t pad0[2];
+	// the answer line: ONE aligned 16-byte store of the device = one write over PCIe, no fence in front of it for a scalar call
+	int64_t id0;        // the ID (or 0 / 1 for a membership call) of a scalar call of a 64-bit k-mer; other calls: results area
 	uint32_t done;      // = posted once the results are in place (device)
 	int32_t err;        // 1: a character outside ACGTacgt (device)
-	uint32_t pad[8];
+	uint32_t pad[4];
 };
+static_assert(offsetof(BurstHead, id0) == 32, "the answer is one aligned 16-byte store");
 static_assert(sizeof(BurstHead) == 64, "BurstHead");
 
 struct BurstCtrl {  // one line of pinned memory next to the ring
@@ -134,15 +139,14 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (the payload was written before `posted`)
 		// ---- scalar calls of 64-bit k-mers: every watcher answers its own from the polled line
 		bool mine_done = false;
+		int64_t my_id = 0;
+		int32_t my_err = 0;
 		if constexpr (KW == 1) {
 			if (pending && (what & 0xbfffffffu) == 1u) {
 				Kmer<1> x;
 				x.lo = k0;
 				const int64_t id = serve_kmer<1, LOGP>(v, x);
-				if (what & 0x40000000u)
-					*reinterpret_cast<uint8_t*>(my_slot + kBurstResultsAt) = id >= 0 ? 1 : 0;
-				else
-					*reinterpret_cast<int64_t*>(my_slot + kBurstResultsAt) = id;
+				my_id = (what & 0x40000000u) ? (int64_t)(id >= 0 ? 1 : 0) : id;
 				mine_done = true;
 			}
 		}
@@ -189,8 +193,8 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 						const Kmer<KW> yr = kmer_rc<KW>(y, v.k);
 						ids[p] = serve_kmer<KW, LOGP>(v, yr < y ? yr : y);  // min_k, blight.cpp:86-91
 					}
-				if (lane == 0)
-					reinterpret_cast<BurstHead*>(slot)->err = (int32_t)s_bad;
+				if ((int)lane == src)
+					my_err = (int32_t)s_bad;
 			} else {  // n canonical k-mers
 				const bool want_bool = (w & 0x40000000u) != 0;
 				for (uint32_t i = lane; i < n; i += 64) {
@@ -201,16 +205,16 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 					else
 						reinterpret_cast<int64_t*>(slot + kBurstResultsAt)[i] = id;
 				}
-				if (lane == 0)
-					reinterpret_cast<BurstHead*>(slot)->err = 0;
 			}
 		}
-		// ---- results before `done`
-		__threadfence_system();
+		// ---- results before `done`: the results area of a read / k-mer list is fenced ONCE, then the answer line {ID, done, err} goes out
+		// as one 16-byte store per slot; a wave that had only scalar calls has nothing to fence
+		if (__ballot(pending && !mine_done))
+			__threadfence_system();
 		if (pending) {
-			if (mine_done)
-				reinterpret_cast<BurstHead*>(my_slot)->err = 0;
-			__hip_atomic_store(&reinterpret_cast<BurstHead*>(my_slot)->done, posted, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+			const u32x4 ans = {(uint32_t)my_id, (uint32_t)((uint64_t)my_id >> 32), posted, (uint32_t)my_err};
+			asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(my_slot + offsetof(BurstHead, id0)), "v"(ans) : "memory");
 			served = posted;
 		}
 		t_mine = __builtin_amdgcn_s_memrealtime();
@@ -404,7 +408,15 @@ bool burst_query_kmers(Index& ix, const void* kmers, uint64_t n, void* out, bool
 	if (!(n == 1 && ix.KW == 1))
 		memcpy(slot + kBurstPayloadAt, kmers, n * kb);
 	post_and_wait(ix, b, si, (uint32_t)n | (want_bool ? 0x40000000u : 0u), k0);
-	memcpy(out, slot + kBurstResultsAt, want_bool ? n : n * 8);
+	if (n == 1 && ix.KW == 1) {  // the answer came with `done`
+		const int64_t id = reinterpret_cast<BurstHead*>(slot)->id0;
+		if (want_bool)
+			*reinterpret_cast<uint8_t*>(out) = (uint8_t)id;
+		else
+			*reinterpret_cast<int64_t*>(out) = id;
+	} else {
+		memcpy(out, slot + kBurstResultsAt, want_bool ? n : n * 8);
+	}
 	ix.number_query.fetch_add(n, std::memory_order_relaxed);
 	b.calls.fetch_add(1, std::memory_order_relaxed);
 	return true;
