@@ -8,9 +8,10 @@
 //   * a ring of request slots in pinned host memory (64 slots of 16 KiB); a caller claims a slot, writes its k-mers or its read, then
 //     the slot's sequence number -- one 16-byte line that also carries the first k-mer, so a scalar call costs the kernel one read
 //     over PCIe --, and spins on the slot's `done` word;
-//   * 16 single-wave workgroups poll four slots each (system-scope loads), answer what they find with the query body of the batch
-//     kernels (query_device.h: same filter, same MPHF probes, same scan) -- one lane per k-mer; a read is 2-bit packed into the
-//     wave's LDS first and every lane takes the k-mers at its positions --, store the IDs into the slot, fence, store `done`;
+//   * 16 workgroups of two waves: wave 0 polls four slots (system-scope loads) and answers scalar calls by itself; for a read or a
+//     k-mer list both waves work -- the query body of the batch kernels (query_device.h: same filter, same MPHF probes, same scan),
+//     one thread per k-mer; a read is 2-bit packed into LDS first and every thread takes the k-mers at its positions --, store the
+//     IDs into the slot, fence, and wave 0 sends the slot's answer line {ID, done, err} as one 16-byte store;
 //   * every wave LEAVES after `idle` microseconds without a request (default 60) or after `max` milliseconds (default 20),
 //     whichever comes first, and the last one out says so in pinned memory.  Nothing waits for the kernel without a deadline: a
 //     caller whose request is not answered within 200 us looks whether the kernel has gone (it may have decided to leave just
@@ -83,57 +84,81 @@ struct BurstShared {
 	unsigned long long last_work;  // s_memrealtime of the last served request
 };
 
+constexpr uint32_t kBurstThreads = 128;  // the polling wave + one helper wave that takes every other 64 k-mers of a read or a list
+
 template <int KW, int LOGP>
-__global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t* __restrict__ ring, BurstCtrl* __restrict__ ctrl, BurstShared* __restrict__ sh,
-                                                    uint32_t gen, uint32_t idle_ticks, uint32_t max_ticks, uint32_t max_polls)
+__global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v0, uint8_t* __restrict__ ring, BurstCtrl* __restrict__ ctrl,
+                                                              BurstShared* __restrict__ sh, uint32_t gen, uint32_t idle_ticks, uint32_t max_ticks,
+                                                              uint32_t max_polls)
 {
 	__shared__ uint64_t s_seq[kBurstMaxChars / 32 + 8];  // a read, 2-bit packed, first nucleotide most significant (like the index's text)
 	__shared__ uint32_t s_bad;
+	// what wave 0 (the poller) tells the helper wave each round: bit 0 leave, bit 1 something is pending; the slots (lanes of wave 0) whose
+	// requests need the whole workgroup, and their `what` words.  Every branch both waves take between two barriers depends on these only.
+	__shared__ uint32_t s_ctl;
+	__shared__ uint64_t s_rest;
+	__shared__ uint32_t s_what[kBurstPerWave];
 	const DeviceIndexView v = gated_view(v0);
-	const uint32_t lane = threadIdx.x, wave = blockIdx.x;
-	// lane l < kBurstPerWave watches slot wave + l * kBurstWaves
-	const bool watcher = lane < kBurstPerWave;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, wave = blockIdx.x;
+	// lane l < kBurstPerWave of wave 0 watches slot wave + l * kBurstWaves
+	const bool watcher = wv == 0 && lane < kBurstPerWave;
 	uint8_t* my_slot = ring + (size_t)(wave + (watcher ? lane : 0) * kBurstWaves) * kBurstSlotBytes;
 	uint32_t served = 0;
 	if (watcher)  // what was answered before this kernel started stays answered
 		served = __hip_atomic_load(&reinterpret_cast<BurstHead*>(my_slot)->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
 	uint64_t t_mine = t_start;
-	if (wave == 0 && lane == 0)
+	if (wave == 0 && tid == 0)
 		atomicMax(&sh->last_work, (unsigned long long)t_start);
 	for (uint32_t poll = 0; poll < max_polls; poll++) {
-		// ---- poll: ONE 16-byte read per watched slot (one PCIe read: a consistent picture of the line) brings the sequence number, the
-		// kind and the first k-mer (low word)
 		uint32_t posted = served, what = 0;
 		uint64_t k0 = 0;
-		if (watcher) {
-			uint4 q;
-			asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(my_slot) : "memory");
-			posted = q.x;
-			what = q.y;
-			k0 = (uint64_t)q.z | ((uint64_t)q.w << 32);
-		}
-		const uint32_t stop = lane == 63 ? __hip_atomic_load(&ctrl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-		const bool pending = watcher && posted != served;
-		const uint64_t pend = __ballot(pending);
-		// Wave 0 looks at the clock for all of them (idle since ANY wave's last request, or the kernel's own time limit); everybody looks
-		// at its verdict and at the host's stop word, and leaves once it has nothing pending.
-		uint32_t go = stop;
-		if (lane == 0) {
-			if (wave == 0) {
-				const uint64_t now = __builtin_amdgcn_s_memrealtime();
-				const uint64_t lw = __hip_atomic_load(&sh->last_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((pend == 0 && now > lw && now - lw > idle_ticks) || now - t_start > max_ticks)
-					__hip_atomic_store(&sh->leaving, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		bool pending = false;
+		if (wv == 0) {
+			// ---- poll: ONE 16-byte read per watched slot (one PCIe read: a consistent picture of the line) brings the sequence number,
+			// the kind and the first k-mer (low word)
+			if (watcher) {
+				uint4 q;
+				asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(my_slot) : "memory");
+				posted = q.x;
+				what = q.y;
+				k0 = (uint64_t)q.z | ((uint64_t)q.w << 32);
 			}
-			go |= __hip_atomic_load(&sh->leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen ? 1u : 0u;
+			const uint32_t stop = lane == 63 ? __hip_atomic_load(&ctrl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+			pending = watcher && posted != served;
+			const uint64_t pend = __ballot(pending);
+			// Wave 0 of workgroup 0 looks at the clock for all of them (idle since ANY workgroup's last request, or the kernel's own time
+			// limit); everybody looks at its verdict and at the host's stop word, and leaves once it has nothing pending.
+			uint32_t go = stop;
+			if (lane == 0) {
+				if (wave == 0) {
+					const uint64_t now = __builtin_amdgcn_s_memrealtime();
+					const uint64_t lw = __hip_atomic_load(&sh->last_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((pend == 0 && now > lw && now - lw > idle_ticks) || now - t_start > max_ticks)
+						__hip_atomic_store(&sh->leaving, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				go |= __hip_atomic_load(&sh->leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen ? 1u : 0u;
+			}
+			const bool leave0 = __ballot(go != 0) != 0;
+			const bool whole = pending && !(KW == 1 && (what & 0xbfffffffu) == 1u);  // needs the workgroup (not a scalar call of a 64-bit k-mer)
+			if (whole)
+				s_what[lane] = what;
+			const uint64_t rest0 = __ballot(whole);
+			if (lane == 0) {
+				s_ctl = (leave0 ? 1u : 0u) | (pend ? 2u : 0u);
+				s_rest = rest0;
+			}
 		}
-		const bool leave = __ballot(go != 0) != 0;
-		if (pend == 0) {
+		__syncthreads();
+		const uint32_t ctl = s_ctl;
+		uint64_t rest = s_rest;
+		__syncthreads();  // (the next round's s_ctl is not written before everybody has read this one)
+		const bool leave = (ctl & 1u) != 0;
+		if (!(ctl & 2u)) {
 			if (leave)
 				break;
-			if (__builtin_amdgcn_s_memrealtime() - t_mine > 2000u)  // (20 us after its own last request a wave polls back to back: a blocking
-				__builtin_amdgcn_s_sleep(16);                        // caller's next call comes within microseconds; then it eases off the link)
+			if (wv == 0 && __builtin_amdgcn_s_memrealtime() - t_mine > 2000u)  // (20 us after its own last request a wave polls back to back: a
+				__builtin_amdgcn_s_sleep(16);                                    // blocking caller's next call comes within microseconds)
 			continue;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (the payload was written before `posted`)
@@ -150,24 +175,24 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 				mine_done = true;
 			}
 		}
-		// ---- everything else, one request after the other, the whole wave on each
-		uint64_t rest = __ballot(pending && !mine_done);
+		// ---- everything else, one request after the other, both waves on each: thread t takes k-mers t, t + 128, ...
+		const bool any_whole = rest != 0;
 		while (rest) {
 			const int src = __ffsll((unsigned long long)rest) - 1;
 			rest &= rest - 1;
-			const uint32_t w = (uint32_t)__shfl((int)what, src);
+			const uint32_t w = s_what[src];
 			uint8_t* slot = ring + (size_t)(wave + (uint32_t)src * kBurstWaves) * kBurstSlotBytes;
 			const uint32_t n = w & 0x3fffffffu;
-			if (w & 0x80000000u) {  // a read of n characters: 2-bit pack it into LDS, 16 characters per lane and round
-				if (lane == 0)
+			if (w & 0x80000000u) {  // a read of n characters: 2-bit pack it into LDS, 16 characters per thread
+				if (tid == 0)
 					s_bad = 0;
-				for (uint32_t i = lane; i < sizeof(s_seq) / 8; i += 64)
+				for (uint32_t i = tid; i < sizeof(s_seq) / 8; i += kBurstThreads)
 					s_seq[i] = 0;
-				__builtin_amdgcn_wave_barrier();
+				__syncthreads();
 				uint32_t* s32 = reinterpret_cast<uint32_t*>(s_seq);
 				const uint8_t* chars = slot + kBurstPayloadAt;
 				uint32_t bad = 0;
-				for (uint32_t c = lane; c * 16 < n; c += 64) {
+				for (uint32_t c = tid; c * 16 < n; c += kBurstThreads) {
 					typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 					const u32x4 q = *reinterpret_cast<const u32x4*>(chars + (size_t)c * 16);  // (payload bytes behind the read are the host's zeros)
 					uint32_t packed = 0;
@@ -184,20 +209,21 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 				}
 				if (bad)
 					s_bad = 1;
-				__builtin_amdgcn_wave_barrier();
+				__syncthreads();
 				const uint32_t nk = n >= (uint32_t)v.k ? n - (uint32_t)v.k + 1 : 0;
 				int64_t* ids = reinterpret_cast<int64_t*>(slot + kBurstResultsAt);
-				if (!s_bad)
-					for (uint32_t p = lane; p < nk; p += 64) {
+				const uint32_t was_bad = s_bad;
+				if (!was_bad)
+					for (uint32_t p = tid; p < nk; p += kBurstThreads) {
 						const Kmer<KW> y = packed_kmer<KW>(s_seq, p, v.k);
 						const Kmer<KW> yr = kmer_rc<KW>(y, v.k);
 						ids[p] = serve_kmer<KW, LOGP>(v, yr < y ? yr : y);  // min_k, blight.cpp:86-91
 					}
-				if ((int)lane == src)
-					my_err = (int32_t)s_bad;
+				if (wv == 0 && (int)lane == src)
+					my_err = (int32_t)was_bad;
 			} else {  // n canonical k-mers
 				const bool want_bool = (w & 0x40000000u) != 0;
-				for (uint32_t i = lane; i < n; i += 64) {
+				for (uint32_t i = tid; i < n; i += kBurstThreads) {
 					const Kmer<KW> x = load_kmer<KW>(reinterpret_cast<const uint64_t*>(slot + kBurstPayloadAt), i);
 					const int64_t id = serve_kmer<KW, LOGP>(v, x);
 					if (want_bool)
@@ -206,25 +232,28 @@ __global__ __launch_bounds__(64) void k_serve_burst(DeviceIndexView v0, uint8_t*
 						reinterpret_cast<int64_t*>(slot + kBurstResultsAt)[i] = id;
 				}
 			}
+			__threadfence_system();  // this thread's results are on their way before ...
+			__syncthreads();         // ... the poller learns that the request is done (and before s_seq is packed again)
 		}
-		// ---- results before `done`: the results area of a read / k-mer list is fenced ONCE, then the answer line {ID, done, err} goes out
-		// as one 16-byte store per slot; a wave that had only scalar calls has nothing to fence
-		if (__ballot(pending && !mine_done))
-			__threadfence_system();
+		// ---- the answer line {ID, done, err}: one 16-byte store per slot.  The results areas were fenced by the threads that wrote them
+		// (above); a wave that had only scalar calls has nothing to fence.
+		(void)any_whole;
 		if (pending) {
 			typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 			const u32x4 ans = {(uint32_t)my_id, (uint32_t)((uint64_t)my_id >> 32), posted, (uint32_t)my_err};
 			asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(my_slot + offsetof(BurstHead, id0)), "v"(ans) : "memory");
 			served = posted;
 		}
-		t_mine = __builtin_amdgcn_s_memrealtime();
-		if (lane == 0)
-			atomicMax(&sh->last_work, (unsigned long long)t_mine);
+		if (wv == 0) {
+			t_mine = __builtin_amdgcn_s_memrealtime();
+			if (lane == 0)
+				atomicMax(&sh->last_work, (unsigned long long)t_mine);
+		}
 		if (leave)  // (told to leave while requests were pending: they are answered, the next ones are the next kernel's)
 			break;
 	}
-	// ---- leave: the last wave out publishes the generation
-	if (lane == 0) {
+	// ---- leave: the last workgroup out publishes the generation
+	if (tid == 0) {
 		__threadfence_system();
 		if (atomicAdd(&sh->left, 1u) + 1u == gridDim.x) {
 			sh->left = 0;
@@ -288,7 +317,7 @@ template <int KW> void launch_burst_kw(const Index& ix, BurstState& b, uint32_t 
 	const uint32_t idle_ticks = b.idle_us * 100u, max_ticks = b.max_ms * 100000u, max_polls = b.max_ms * 4000u + 1000u;
 #define BLMX_SV(LP)                                                                                                                                    \
 	case LP:                                                                                                                                           \
-		hipLaunchKernelGGL((k_serve_burst<KW, LP>), dim3(kBurstWaves), dim3(64), 0, b.s, v, b.ring.as<uint8_t>(), b.ctrl(), b.left.as<BurstShared>(), gen, \
+		hipLaunchKernelGGL((k_serve_burst<KW, LP>), dim3(kBurstWaves), dim3(kBurstThreads), 0, b.s, v, b.ring.as<uint8_t>(), b.ctrl(), b.left.as<BurstShared>(), gen, \
 		                   idle_ticks, max_ticks, max_polls);                                                                                          \
 		break;
 	switch (v.b) {
