@@ -435,6 +435,14 @@ def test_serving_burst_answers_small_calls_and_leaves(B, O):
             assert np.array_equal(ix.query_kmer_bool(part), want[a:a + 37] >= 0)
         # reads: one call each
         reads = _reads(rng, seqs, k, 120)
+        # ... and long ones: several k-mers per thread of the serving workgroup's two waves (a slot holds up to 1536 characters),
+        # lengths around the multiples of 128 k-mers, a whole indexed sequence and its reverse complement
+        long_src = "".join(seqs[:30])
+        for L in (k + 127, k + 128, k + 129, k + 255, k + 256, 700, 1535, 1536):
+            a = int(rng.integers(0, len(long_src) - L))
+            reads.append(long_src[a:a + L])
+        reads.append(_revcomp(long_src[:1200]))
+        reads.append(_rand_seq(rng, 1500))
         for r in reads:
             assert np.array_equal(ix.query_sequence_hash(r), _want(orc, [r], k))
         with pytest.raises(Exception):
