@@ -1419,6 +1419,273 @@ void exclusive_scan_u64(Scratch& sc, InIt in, uint64_t* out, uint64_t n, hipStre
 	BLMX_HIP(rocprim::exclusive_scan(tmp, bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
 }
 
+// ---- the build's shuffle: a stable LSD radix sort of 32-bit keys that also returns the order (r04; was rocprim::radix_sort_pairs) ----
+// Super-k-mers go to their buckets in INPUT order (blight.cpp:234-277 appends them to the bucket files as they come), so the sort by
+// minimizer has to be stable.  The key width is known -- 2m - 1 bits, 17 at m = 9 -- so it is ceil(bits / 9) passes of at most 9 bits:
+// per pass a histogram per tile of 8192 keys (k_rs_hist), an exclusive scan of the (digit, tile) matrix (k_scan_*: three small kernels)
+// and a stable scatter (k_rs_scatter).  Stability inside a tile without atomics: every wave owns a contiguous segment of the tile and
+// walks it 64 keys at a time; the lanes of a round that hold the same digit find each other with one ballot per digit bit, the lowest
+// of them adds the group's size to the wave's counter of that digit and hands the old value to the others (rank = old + peers below
+// me); waves are then ordered by a prefix over the four counters.  The tile is staged in LDS in digit order and copied out in runs.
+constexpr int kRsThreads = 256, kRsPer = 32, kRsTile = kRsThreads * kRsPer;
+constexpr int kRsMaxBits = 9;
+
+template <int BITS> __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t nblk, uint32_t* __restrict__ hist)
+{
+	constexpr int NB = 1 << BITS;
+	__shared__ uint32_t s_h[NB];
+	for (int d = threadIdx.x; d < NB; d += kRsThreads)
+		s_h[d] = 0;
+	__syncthreads();
+	const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+#pragma unroll 4
+	for (int e = 0; e < kRsPer; e++) {
+		const uint64_t i = base + (uint64_t)e * kRsThreads + threadIdx.x;
+		if (i < n)
+			atomicAdd(&s_h[(keys[i] >> shift) & (NB - 1)], 1u);
+	}
+	__syncthreads();
+	for (int d = threadIdx.x; d < NB; d += kRsThreads)
+		hist[(size_t)d * nblk + blockIdx.x] = s_h[d];  // digit-major: the scan of the matrix gives every (digit, tile) its first output slot
+}
+
+// exclusive scan of n 32-bit counts (n < 2^32 entries, total < 2^32): block sums, one block over the sums, apply
+constexpr int kScanThreads = 1024, kScanPer = 8, kScanTile = kScanThreads * kScanPer;
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t* s_w /* kScanThreads / 64 */, uint32_t& total)
+{
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t v = mine;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t u = __shfl_up(v, o);
+		if ((int)lane >= o)
+			v += u;
+	}
+	if (lane == 63)
+		s_w[wave] = v;
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+	for (uint32_t w = 0; w < blockDim.x / 64; w++) {
+		const uint32_t x = s_w[w];
+		if (w < wave)
+			before += x;
+		all += x;
+	}
+	__syncthreads();
+	total = all;
+	return before + v - mine;
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_sums(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ sums)
+{
+	__shared__ uint32_t s_w[kScanThreads / 64];
+	const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPer;
+	uint32_t mine = 0;
+#pragma unroll
+	for (int j = 0; j < kScanPer; j++)
+		mine += base + j < n ? in[base + j] : 0u;
+	uint32_t total;
+	(void)block_exclusive_scan(mine, s_w, total);
+	if (threadIdx.x == 0)
+		sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_top(uint32_t* __restrict__ sums, uint32_t nsums)  // one block; in place, exclusive
+{
+	__shared__ uint32_t s_w[kScanThreads / 64];
+	uint32_t carry = 0;
+	for (uint32_t at = 0; at < nsums; at += kScanThreads) {
+		const uint32_t i = at + threadIdx.x;
+		const uint32_t mine = i < nsums ? sums[i] : 0u;
+		uint32_t total;
+		const uint32_t ex = block_exclusive_scan(mine, s_w, total);
+		if (i < nsums)
+			sums[i] = carry + ex;
+		carry += total;
+	}
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint32_t* __restrict__ sums, uint32_t* __restrict__ out)
+{
+	__shared__ uint32_t s_w[kScanThreads / 64];
+	const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPer;
+	uint32_t x[kScanPer], mine = 0;
+#pragma unroll
+	for (int j = 0; j < kScanPer; j++) {
+		x[j] = base + j < n ? in[base + j] : 0u;
+		mine += x[j];
+	}
+	uint32_t total;
+	uint32_t at = sums[blockIdx.x] + block_exclusive_scan(mine, s_w, total);
+#pragma unroll
+	for (int j = 0; j < kScanPer; j++) {
+		if (base + j < n)
+			out[base + j] = at;
+		at += x[j];
+	}
+}
+void exclusive_scan_u32(uint32_t* inout, uint64_t n, uint32_t* d_sums, hipStream_t s)  // d_sums: (n + kScanTile - 1) / kScanTile words
+{
+	if (!n)
+		return;
+	const uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
+	hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kScanThreads), 0, s, inout, n, d_sums);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanThreads), 0, s, d_sums, nb);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanThreads), 0, s, inout, n, d_sums, inout);
+	BLMX_HIP(hipGetLastError());
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /* null: the index itself */,
+                                                         uint64_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblk, uint32_t* __restrict__ keys_out,
+                                                         uint32_t* __restrict__ vals_out)
+{
+	constexpr int NB = 1 << BITS, WAVES = kRsThreads / 64, DPT = (NB + kRsThreads - 1) / kRsThreads;  // digits per thread
+	__shared__ uint32_t s_key[kRsTile], s_val[kRsTile];
+	__shared__ uint32_t s_wcnt[WAVES][NB];  // keys of a digit in a wave's segment, then the tile-local slot of the segment's first one
+	__shared__ uint32_t s_gb[NB];          // first output slot of (digit, this tile) minus the digit's tile-local start (mod 2^32)
+	__shared__ uint32_t s_w[WAVES];
+	const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+	for (int d = t; d < NB; d += kRsThreads)
+#pragma unroll
+		for (int w = 0; w < WAVES; w++)
+			s_wcnt[w][d] = 0;
+	__syncthreads();
+	const uint64_t seg = (uint64_t)blockIdx.x * kRsTile + (uint64_t)wv * (64 * kRsPer);  // this wave's segment: kRsPer rounds of 64 keys
+	uint32_t key[kRsPer];
+	uint16_t rank[kRsPer];
+	const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int e = 0; e < kRsPer; e++) {
+		const uint64_t i = seg + (uint64_t)e * 64 + lane;
+		const bool valid = i < n;
+		key[e] = valid ? keys_in[i] : 0u;
+		const uint32_t d = (key[e] >> shift) & (NB - 1);
+		uint64_t peers = __ballot(valid);
+#pragma unroll
+		for (int b = 0; b < BITS; b++) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t bal = __ballot(bit);
+			peers &= bit ? bal : ~bal;
+		}
+		uint32_t old = 0;
+		const int leader = valid ? __ffsll((unsigned long long)peers) - 1 : (int)lane;
+		if (valid && (int)lane == leader) {
+			old = s_wcnt[wv][d];
+			s_wcnt[wv][d] = old + (uint32_t)__popcll(peers);
+		}
+		old = (uint32_t)__shfl((int)old, leader);
+		rank[e] = (uint16_t)(old + (uint32_t)__popcll(peers & below));
+	}
+	__syncthreads();
+	// per digit: tile-local start (exclusive scan over the digits of the tile's counts), the waves' segments behind one another
+	{
+		uint32_t c[DPT][WAVES], tot[DPT], mine = 0;
+#pragma unroll
+		for (int j = 0; j < DPT; j++) {
+			const int d = (int)t * DPT + j;
+			tot[j] = 0;
+#pragma unroll
+			for (int w = 0; w < WAVES; w++) {
+				c[j][w] = d < NB ? s_wcnt[w][d] : 0u;
+				tot[j] += c[j][w];
+			}
+			mine += tot[j];
+		}
+		uint32_t v = mine;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t u = __shfl_up(v, o);
+			if ((int)lane >= o)
+				v += u;
+		}
+		if (lane == 63)
+			s_w[wv] = v;
+		__syncthreads();
+		uint32_t at = v - mine;
+		for (uint32_t w = 0; w < wv; w++)
+			at += s_w[w];
+#pragma unroll
+		for (int j = 0; j < DPT; j++) {
+			const int d = (int)t * DPT + j;
+			if (d < NB) {
+				s_gb[d] = offs[(size_t)d * nblk + blockIdx.x] - at;
+				uint32_t a = at;
+#pragma unroll
+				for (int w = 0; w < WAVES; w++) {
+					s_wcnt[w][d] = a;
+					a += c[j][w];
+				}
+			}
+			at += tot[j];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < kRsPer; e++) {
+		const uint64_t i = seg + (uint64_t)e * 64 + lane;
+		if (i < n) {
+			const uint32_t lp = s_wcnt[wv][(key[e] >> shift) & (NB - 1)] + rank[e];
+			s_key[lp] = key[e];
+			s_val[lp] = vals_in ? vals_in[i] : (uint32_t)i;
+		}
+	}
+	__syncthreads();
+	const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+	const uint32_t count = (uint32_t)min((uint64_t)kRsTile, n - base);
+	for (uint32_t j = t; j < count; j += kRsThreads) {
+		const uint32_t kx = s_key[j];
+		const uint32_t pos = s_gb[(kx >> shift) & (NB - 1)] + j;
+		keys_out[pos] = kx;
+		vals_out[pos] = s_val[j];
+	}
+}
+
+// keys[0, n) (n < 2^32, `bits` significant bits) -> keys_out sorted, order_out[i] = the input index of the i-th smallest, stable
+void stable_sort_by_key_u32(Scratch& sc, const uint32_t* keys, uint32_t* keys_out, uint32_t* order_out, uint64_t n, unsigned bits, hipStream_t s)
+{
+	if (!n)
+		return;
+	if (bits == 0)
+		bits = 1;
+	const int npass = (int)((bits + kRsMaxBits - 1) / kRsMaxBits);
+	const uint32_t nblk = (uint32_t)((n + kRsTile - 1) / kRsTile);
+	const size_t hist_words = ((size_t)nblk << kRsMaxBits);
+	const size_t sums_words = (hist_words + kScanTile - 1) / kScanTile + 1;
+	// scratch: [histogram | scan sums | (more than one pass:) a second pair of key / order arrays]
+	const size_t pair_words = npass > 1 ? 2 * ((size_t)n + 1) : 0;
+	uint32_t* d_hist = static_cast<uint32_t*>(sc.get((hist_words + sums_words + pair_words) * 4));
+	uint32_t* d_sums = d_hist + hist_words;
+	uint32_t* tk = d_sums + sums_words;
+	uint32_t* tv = tk + (n + 1);
+	// the passes alternate between the caller's arrays and the temporaries so that the LAST one writes the caller's
+	const uint32_t* kin = keys;
+	const uint32_t* vin = nullptr;
+	for (int p = 0; p < npass; p++) {
+		const int shift = p * kRsMaxBits;
+		const int pb = (int)std::min<unsigned>(kRsMaxBits, bits - (unsigned)shift);
+		const bool to_caller = ((npass - 1 - p) % 2) == 0;
+		uint32_t* kout = to_caller ? keys_out : tk;
+		uint32_t* vout = to_caller ? order_out : tv;
+#define BLMX_RS(B)                                                                                                                          \
+	case B:                                                                                                                                 \
+		hipLaunchKernelGGL((k_rs_hist<B>), dim3(nblk), dim3(kRsThreads), 0, s, kin, n, shift, nblk, d_hist);                               \
+		exclusive_scan_u32(d_hist, (uint64_t)nblk << B, d_sums, s);                                                                         \
+		hipLaunchKernelGGL((k_rs_scatter<B>), dim3(nblk), dim3(kRsThreads), 0, s, kin, vin, n, shift, d_hist, nblk, kout, vout);           \
+		break;
+		switch (pb) {
+			BLMX_RS(1)
+			BLMX_RS(2)
+			BLMX_RS(3)
+			BLMX_RS(4)
+			BLMX_RS(5)
+			BLMX_RS(6)
+			BLMX_RS(7)
+			BLMX_RS(8)
+			BLMX_RS(9)
+		}
+#undef BLMX_RS
+		BLMX_HIP(hipGetLastError());
+		kin = kout;
+		vin = vout;
+	}
+}
+
 template <typename T> T read_scalar(const T* d, hipStream_t s)
 {
 	T h;
@@ -1721,13 +1988,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 			BLMX_HIP(d_hlenk.alloc((hn + 1) * 8, false, s));
 			BLMX_HIP(d_hstart.alloc((hn + 1) * 8, false, s));
 			if (hn) {
-				size_t bytes = 0;
-				rocprim::counting_iterator<uint32_t> iota(0);
-				BLMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_hmini.as<uint32_t>(), d_hsmini.as<uint32_t>(), iota, d_horder.as<uint32_t>(), (size_t)hn, 0u,
-				                                   (unsigned)(2 * ix.prm.m - 1), s));
-				void* tmp = sc.get(bytes);
-				BLMX_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_hmini.as<uint32_t>(), d_hsmini.as<uint32_t>(), iota, d_horder.as<uint32_t>(), (size_t)hn, 0u,
-				                                   (unsigned)(2 * ix.prm.m - 1), s));
+				stable_sort_by_key_u32(sc, d_hmini.as<uint32_t>(), d_hsmini.as<uint32_t>(), d_horder.as<uint32_t>(), hn, (unsigned)(2 * ix.prm.m - 1), s);
 				hipLaunchKernelGGL(k_sorted_lengths, dim3(grid_for(hn + 1)), dim3(kBlock), 0, s, d_horder.as<uint32_t>(), d_hpos.as<uint64_t>(),
 				                   d_hlast.as<uint64_t>(), hn, (int)ix.prm.k, d_hlennt.as<uint64_t>(), d_hlenk.as<uint64_t>());
 				BLMX_HIP(hipGetLastError());
@@ -1779,15 +2040,8 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 	DevBuf d_smini, d_order, d_lennt, d_lenk, d_ntstart, d_keystart;
 	BLMX_HIP(d_smini.alloc((nsk + 1) * 4, false, s));
 	BLMX_HIP(d_order.alloc((nsk + 1) * 4, false, s));
-	if (nsk) {
-		size_t bytes = 0;
-		rocprim::counting_iterator<uint32_t> iota(0);
-		BLMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_skmini.as<uint32_t>(), d_smini.as<uint32_t>(), iota, d_order.as<uint32_t>(),
-		                                   (size_t)nsk, 0u, (unsigned)(2 * m - 1), s));
-		void* tmp = sc.get(bytes);
-		BLMX_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_skmini.as<uint32_t>(), d_smini.as<uint32_t>(), iota, d_order.as<uint32_t>(),
-		                                   (size_t)nsk, 0u, (unsigned)(2 * m - 1), s));
-	}
+	stable_sort_by_key_u32(sc, d_skmini.as<uint32_t>(), d_smini.as<uint32_t>(), d_order.as<uint32_t>(), nsk, (unsigned)(2 * m - 1), s);
+	sc.buf.release();  // (the sort's second pair of arrays: 8 bytes per super-k-mer; the scans below ask for a few KB)
 	d_skmini.release();
 	BLMX_HIP(d_lennt.alloc((nsk + 1) * 8, false, s));
 	BLMX_HIP(d_lenk.alloc((nsk + 1) * 8, false, s));
@@ -2665,13 +2919,7 @@ void shard_build_plan(Index& ix, const uint64_t* global_hist, uint32_t world_of_
 	BLMX_HIP(d_seg.alloc(17 * 8, true, s));
 	if (nsk) {
 		hipLaunchKernelGGL(k_sk_owner, dim3(grid_for(nsk)), dim3(kBlock), 0, s, c.skmini.as<uint32_t>(), nsk, ix.gshift, t, d_owner.as<uint32_t>());
-		size_t bytes = 0;
-		rocprim::counting_iterator<uint32_t> iota(0);
-		BLMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_owner.as<uint32_t>(), d_sowner.as<uint32_t>(), iota, d_order.as<uint32_t>(), (size_t)nsk, 0u,
-		                                   5u, s));
-		void* tmp = sc.get(bytes);
-		BLMX_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_owner.as<uint32_t>(), d_sowner.as<uint32_t>(), iota, d_order.as<uint32_t>(), (size_t)nsk, 0u, 5u,
-		                                   s));
+		stable_sort_by_key_u32(sc, d_owner.as<uint32_t>(), d_sowner.as<uint32_t>(), d_order.as<uint32_t>(), nsk, 5u, s);
 	}
 	d_owner.release();
 	hipLaunchKernelGGL(k_owner_segments, dim3(1), dim3(64), 0, s, d_sowner.as<uint32_t>(), nsk, world, d_seg.as<uint64_t>());
