@@ -578,7 +578,7 @@ def primitive(op, data, arg=0, arg2=0, kmer_bytes=8):
     """device KAT entry point (tests): see blmx_primitive in include/blight_mi355x.h"""
     lib = load_library()
     a = np.ascontiguousarray(data)
-    in_elem = 4 if op <= 2 else (kmer_bytes if op in (3, 4, 7) else (8 if op == 5 else 1))
+    in_elem = 4 if (op <= 2 or op == 8) else (kmer_bytes if op in (3, 4, 7) else (8 if op == 5 else 1))
     n = a.nbytes // in_elem
     if op in (0,):
         out = np.empty(n, np.int32)
@@ -590,6 +590,8 @@ def primitive(op, data, arg=0, arg2=0, kmer_bytes=8):
         out = np.empty((n, 16), np.uint64)
     elif op == 7:
         out = np.empty((n, 2), np.uint64)
+    elif op == 8:
+        out = np.empty((2, n), np.uint32)  # sorted keys, then the order
     else:
         out = np.empty(n, np.uint8)
     rc = lib.blmx_primitive(op, kmer_bytes, a.ctypes.data, n, arg, arg2, out.ctypes.data)

@@ -1031,20 +1031,24 @@ int64_t blmx_export(blmx_index* h, int which, void* out, uint64_t cap)
 
 int blmx_primitive(int op, int kmer_bytes, const void* in, uint64_t n, int arg, int arg2, void* out)
 {
-	if (!in || !out || (kmer_bytes != 8 && kmer_bytes != 16) || op < 0 || op > 7 || (op == 7 && (arg2 < 0 || arg2 > kmer_bytes)))
+	if (!in || !out || (kmer_bytes != 8 && kmer_bytes != 16) || op < 0 || op > 8 || (op == 7 && (arg2 < 0 || arg2 > kmer_bytes)) ||
+	    (op == 8 && (arg < 1 || arg > 32 || n >= 0xffffffffull)))
 		return BLMX_EINVAL;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
 		return BLMX_EHIP;
 	return guarded(nullptr, [&] {
-		const size_t in_elem = (op <= 2) ? 4 : (op == 3 || op == 4 || op == 7) ? (size_t)kmer_bytes : (op == 5 ? 8 : 1);
-		const size_t out_elem =
-		    (op == 0 || op == 1 || op == 2 || op == 4) ? 4 : (op == 3 ? (size_t)kmer_bytes : (op == 5 ? 8 * kLevels : (op == 7 ? 16 : 1)));
+		const size_t in_elem = (op <= 2 || op == 8) ? 4 : (op == 3 || op == 4 || op == 7) ? (size_t)kmer_bytes : (op == 5 ? 8 : 1);
+		const size_t out_elem = (op == 0 || op == 1 || op == 2 || op == 4) ? 4
+		                        : (op == 3 ? (size_t)kmer_bytes : (op == 5 ? 8 * kLevels : (op == 7 ? 16 : (op == 8 ? 8 : 1))));
 		DevBuf d_in, d_out;
 		BLMX_HIP(d_in.alloc(n * in_elem + 16, false, nullptr));
 		BLMX_HIP(d_out.alloc(n * out_elem + 16, false, nullptr));
 		BLMX_HIP(hipMemcpy(d_in.p, in, n * in_elem, hipMemcpyHostToDevice));
-		launch_primitive(op, kmer_bytes / 8, d_in.p, n, arg, arg2, d_out.p, nullptr);
+		if (op == 8)
+			launch_sort_primitive(d_in.as<uint32_t>(), n, (unsigned)arg, d_out.as<uint32_t>(), nullptr);
+		else
+			launch_primitive(op, kmer_bytes / 8, d_in.p, n, arg, arg2, d_out.p, nullptr);
 		BLMX_HIP(hipDeviceSynchronize());
 		BLMX_HIP(hipMemcpy(out, d_out.p, n * out_elem, hipMemcpyDeviceToHost));
 	});

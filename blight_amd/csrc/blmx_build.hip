@@ -2787,6 +2787,16 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 // input order and the stable minimizer sort of the tail reproduces the single-GPU bucket content, hence the same IDs.
 }  // namespace
 
+// blmx_primitive op 8 (tests): the build's stable sort on its own -- n keys with `bits` significant bits -> n sorted keys, then the n
+// input indices in that order
+void launch_sort_primitive(const uint32_t* d_keys, uint64_t n, unsigned bits, uint32_t* d_out, hipStream_t s)
+{
+	Scratch sc;
+	sc.s = s;
+	stable_sort_by_key_u32(sc, d_keys, d_out, d_out + n, n, bits, s);
+	BLMX_HIP(hipStreamSynchronize(s));
+}
+
 struct ShardExchange {
 	BuildPool pool;  // first: outlives the buffers below
 	std::chrono::steady_clock::time_point t_begin;

@@ -758,5 +758,6 @@ void save_index(Index& ix, const char* path);
 void load_index(Index& ix, const char* path);
 int peek_index_params(const char* path, blmx_params& out);
 void launch_primitive(int op, int KW, const void* d_in, uint64_t n, int arg, int arg2, void* d_out, hipStream_t s);
+void launch_sort_primitive(const uint32_t* d_keys, uint64_t n, unsigned bits, uint32_t* d_out, hipStream_t s);  // blmx_build.hip
 
 }  // namespace blmx

@@ -361,6 +361,7 @@ int64_t blmx_export(blmx_index* ix, int which, void* out, uint64_t cap);
  * 2 parity_canon (arg m), 3 kmer rc (arg k), 4 kmer minimizer (arg k, arg2 m) -> u32, 5 level hashes: 16 u64 per key,
  * 6 nuc code of bytes -> u8 (4 = invalid), 7 MurmurHash3_x64_128 (reference MurmurHash3.cpp:255; dead code there, a
  * device utility here) of the first arg2 bytes (0 = all) of every kmer_bytes-byte record, seed arg -> 2 u64.
+ * 8 the build's stable sort: n u32 keys with arg significant bits (1..32) -> n sorted keys followed by the n input indices in that order.
  * in/out are host buffers. */
 int blmx_primitive(int op, int kmer_bytes, const void* in, uint64_t n, int arg, int arg2, void* out);
 
