@@ -31,6 +31,7 @@
 #include <cmath>
 
 #include "blmx_internal.h"
+#include "scan_kernels.h"
 #include "index_device.h"
 
 namespace blmx {
@@ -330,8 +331,9 @@ __global__ void k_sk_meta(const uint32_t* __restrict__ order, const uint32_t* __
 		meta[i] = ((uint64_t)sk_mini[order[i]] << 32) | (uint64_t)(uint32_t)len_nt[i];
 }
 
-struct MetaLen {
-	__host__ __device__ uint64_t operator()(uint64_t meta) const { return meta & 0xffffffffull; }
+struct MetaLen {  // scan input: the length field of a received super-k-mer's meta word
+	const uint64_t* meta;
+	__device__ uint64_t operator()(uint64_t i) const { return meta[i] & 0xffffffffull; }
 };
 
 // received (meta, running nt scan) -> the super-k-mer list the rest of the build works on
@@ -1410,13 +1412,19 @@ struct Scratch {
 	}
 };
 
-template <typename InIt>
-void exclusive_scan_u64(Scratch& sc, InIt in, uint64_t* out, uint64_t n, hipStream_t s)
+// 64-bit exclusive prefix sums (scan_kernels.h); `in` is a functor or a pointer
+template <typename In> void exclusive_scan_u64(Scratch& sc, In in, uint64_t* out, uint64_t n, hipStream_t s)
 {
-	size_t bytes = 0;
-	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
-	void* tmp = sc.get(bytes);
-	BLMX_HIP(rocprim::exclusive_scan(tmp, bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), s));
+	uint64_t* d_sums = static_cast<uint64_t*>(sc.get(scan_sums_words(n) * 8));
+	exclusive_scan_of<uint64_t>(in, out, n, d_sums, s);
+}
+inline void exclusive_scan_u64(Scratch& sc, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t s)
+{
+	exclusive_scan_u64(sc, ScanPlain<uint64_t>{in}, out, n, s);
+}
+inline void exclusive_scan_u64(Scratch& sc, uint64_t* in, uint64_t* out, uint64_t n, hipStream_t s)
+{
+	exclusive_scan_u64(sc, ScanPlain<uint64_t>{in}, out, n, s);
 }
 
 // ---- the build's shuffle: a stable LSD radix sort of 32-bit keys that also returns the order (r04; was rocprim::radix_sort_pairs) ----
@@ -1447,88 +1455,6 @@ template <int BITS> __global__ __launch_bounds__(kRsThreads) void k_rs_hist(cons
 	__syncthreads();
 	for (int d = threadIdx.x; d < NB; d += kRsThreads)
 		hist[(size_t)d * nblk + blockIdx.x] = s_h[d];  // digit-major: the scan of the matrix gives every (digit, tile) its first output slot
-}
-
-// exclusive scan of n 32-bit counts (n < 2^32 entries, total < 2^32): block sums, one block over the sums, apply
-constexpr int kScanThreads = 1024, kScanPer = 8, kScanTile = kScanThreads * kScanPer;
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t* s_w /* kScanThreads / 64 */, uint32_t& total)
-{
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint32_t v = mine;
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t u = __shfl_up(v, o);
-		if ((int)lane >= o)
-			v += u;
-	}
-	if (lane == 63)
-		s_w[wave] = v;
-	__syncthreads();
-	uint32_t before = 0, all = 0;
-	for (uint32_t w = 0; w < blockDim.x / 64; w++) {
-		const uint32_t x = s_w[w];
-		if (w < wave)
-			before += x;
-		all += x;
-	}
-	__syncthreads();
-	total = all;
-	return before + v - mine;
-}
-__global__ __launch_bounds__(kScanThreads) void k_scan_sums(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ sums)
-{
-	__shared__ uint32_t s_w[kScanThreads / 64];
-	const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPer;
-	uint32_t mine = 0;
-#pragma unroll
-	for (int j = 0; j < kScanPer; j++)
-		mine += base + j < n ? in[base + j] : 0u;
-	uint32_t total;
-	(void)block_exclusive_scan(mine, s_w, total);
-	if (threadIdx.x == 0)
-		sums[blockIdx.x] = total;
-}
-__global__ __launch_bounds__(kScanThreads) void k_scan_top(uint32_t* __restrict__ sums, uint32_t nsums)  // one block; in place, exclusive
-{
-	__shared__ uint32_t s_w[kScanThreads / 64];
-	uint32_t carry = 0;
-	for (uint32_t at = 0; at < nsums; at += kScanThreads) {
-		const uint32_t i = at + threadIdx.x;
-		const uint32_t mine = i < nsums ? sums[i] : 0u;
-		uint32_t total;
-		const uint32_t ex = block_exclusive_scan(mine, s_w, total);
-		if (i < nsums)
-			sums[i] = carry + ex;
-		carry += total;
-	}
-}
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint32_t* __restrict__ sums, uint32_t* __restrict__ out)
-{
-	__shared__ uint32_t s_w[kScanThreads / 64];
-	const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanPer;
-	uint32_t x[kScanPer], mine = 0;
-#pragma unroll
-	for (int j = 0; j < kScanPer; j++) {
-		x[j] = base + j < n ? in[base + j] : 0u;
-		mine += x[j];
-	}
-	uint32_t total;
-	uint32_t at = sums[blockIdx.x] + block_exclusive_scan(mine, s_w, total);
-#pragma unroll
-	for (int j = 0; j < kScanPer; j++) {
-		if (base + j < n)
-			out[base + j] = at;
-		at += x[j];
-	}
-}
-void exclusive_scan_u32(uint32_t* inout, uint64_t n, uint32_t* d_sums, hipStream_t s)  // d_sums: (n + kScanTile - 1) / kScanTile words
-{
-	if (!n)
-		return;
-	const uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
-	hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kScanThreads), 0, s, inout, n, d_sums);
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanThreads), 0, s, d_sums, nb);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kScanThreads), 0, s, inout, n, d_sums, inout);
-	BLMX_HIP(hipGetLastError());
 }
 
 template <int BITS>
@@ -1665,7 +1591,7 @@ void stable_sort_by_key_u32(Scratch& sc, const uint32_t* keys, uint32_t* keys_ou
 #define BLMX_RS(B)                                                                                                                          \
 	case B:                                                                                                                                 \
 		hipLaunchKernelGGL((k_rs_hist<B>), dim3(nblk), dim3(kRsThreads), 0, s, kin, n, shift, nblk, d_hist);                               \
-		exclusive_scan_u32(d_hist, (uint64_t)nblk << B, d_sums, s);                                                                         \
+		exclusive_scan_u32(d_hist, d_hist, (uint64_t)nblk << B, d_sums, s);                                                                         \
 		hipLaunchKernelGGL((k_rs_scatter<B>), dim3(nblk), dim3(kRsThreads), 0, s, kin, vin, n, shift, d_hist, nblk, kout, vout);           \
 		break;
 		switch (pb) {
@@ -1837,8 +1763,7 @@ void chop_input(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		                   d_ustart.as<unsigned long long>(), total_len, k, m, d_Hb.as<unsigned long long>(),
 		                   d_Eb.as<unsigned long long>());
 		BLMX_HIP(hipGetLastError());
-		auto hin = rocprim::make_transform_iterator(d_Hb.as<unsigned long long>(), PopcU64());
-		auto ein = rocprim::make_transform_iterator(d_Eb.as<unsigned long long>(), PopcU64());
+		const ScanPopc64<uint64_t> hin{d_Hb.as<unsigned long long>()}, ein{d_Eb.as<unsigned long long>()};
 		exclusive_scan_u64(sc, hin, d_Hpre.as<uint64_t>(), nbw + 1, s);
 		exclusive_scan_u64(sc, ein, d_Epre.as<uint64_t>(), nbw + 1, s);
 		nsk = read_scalar(d_Hpre.as<uint64_t>() + nbw, s);
@@ -3018,7 +2943,7 @@ void shard_build_finish(Index& ix, const void* d_meta_in, const void* d_words_in
 	if (nsk) {
 		DevBuf d_ntscan;
 		BLMX_HIP(d_ntscan.alloc((nsk + 1) * 8, false, s));
-		auto lens = rocprim::make_transform_iterator(reinterpret_cast<const uint64_t*>(d_meta_in), MetaLen());
+		const MetaLen lens{reinterpret_cast<const uint64_t*>(d_meta_in)};
 		exclusive_scan_u64(sc, lens, d_ntscan.as<uint64_t>(), nsk, s);
 		hipLaunchKernelGGL(k_sk_from_meta, dim3(grid_for(nsk)), dim3(kBlock), 0, s, reinterpret_cast<const uint64_t*>(d_meta_in), d_ntscan.as<uint64_t>(), nsk,
 		                   k, t, c.skpos.as<uint64_t>(), c.sklast.as<uint64_t>(), c.skmini.as<uint32_t>());

@@ -9,13 +9,13 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
 #include "blmx_internal.h"
+#include "scan_kernels.h"
 #include "index_device.h"
 #include "query_device.h"
 
@@ -1158,10 +1158,8 @@ void partition_launch(Index& ix, const PartitionPlan& pl, const uint64_t* km, co
 		                   ix.b_bins.as<uint32_t>(), ix.b_hist.as<uint32_t>(), nblk);
 	BLMX_HIP(hipGetLastError());
 	ix.prof_mark(2, s);
-	size_t bytes = 0;
-	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
-	ensure_buf(ix.b_tmp, bytes, s);
-	BLMX_HIP(rocprim::exclusive_scan(ix.b_tmp.p, bytes, ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), 0u, nh, rocprim::plus<uint32_t>(), s));
+	ensure_buf(ix.b_tmp, scan_sums_words(nh) * 4, s);
+	exclusive_scan_u32(ix.b_hist.as<uint32_t>(), ix.b_offs.as<uint32_t>(), nh, ix.b_tmp.as<uint32_t>(), s);
 	ix.prof_mark(3, s);
 	hipLaunchKernelGGL((k_bin_scatter<KW, TILE>), dim3(nblk), dim3(kBinThreads), 0, s, km, nq, minibuf, pl.bm, ix.b_hist.as<uint32_t>(),
 	                   ix.b_offs.as<uint32_t>(), nblk, nbins, reinterpret_cast<uint64_t*>(d_sorted), d_sorted_minis, d_inv);

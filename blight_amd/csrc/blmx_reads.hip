@@ -24,9 +24,9 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "blmx_internal.h"
+#include "scan_kernels.h"
 #include "query_device.h"
 
 namespace blmx {
@@ -511,16 +511,6 @@ __global__ __launch_bounds__(256) void k_seq_pack(const uint8_t* __restrict__ ch
 	atomicOr(&packed[gw], (unsigned long long)word);
 }
 
-struct PopcU64 {
-	__host__ __device__ uint32_t operator()(unsigned long long v) const
-	{
-#if defined(__HIP_DEVICE_COMPILE__)
-		return (uint32_t)__popcll(v);
-#else
-		return (uint32_t)__builtin_popcountll(v);
-#endif
-	}
-};
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
 namespace {
@@ -537,11 +527,8 @@ void ensure_scratch(DevBuf& b, size_t bytes, hipStream_t s)
 // exclusive prefix of the popcounts of `words` bitmap words (n + 1 outputs: the last one is the total)
 void popcount_prefix(FrontScratch& fs, const unsigned long long* d_bits, uint64_t n, uint32_t* d_pre, hipStream_t s)
 {
-	auto in = rocprim::make_transform_iterator(d_bits, PopcU64());
-	size_t bytes = 0;
-	BLMX_HIP(rocprim::exclusive_scan(nullptr, bytes, in, d_pre, 0u, n + 1, rocprim::plus<uint32_t>(), s));
-	ensure_scratch(fs.tmp, bytes, s);
-	BLMX_HIP(rocprim::exclusive_scan(fs.tmp.p, bytes, in, d_pre, 0u, n + 1, rocprim::plus<uint32_t>(), s));
+	ensure_scratch(fs.tmp, scan_sums_words(n + 1) * 4, s);
+	exclusive_scan_of<uint32_t>(ScanPopc64<uint32_t>{d_bits}, d_pre, n + 1, fs.tmp.as<uint32_t>(), s);
 }
 }  // namespace
 
