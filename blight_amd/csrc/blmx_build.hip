@@ -331,6 +331,24 @@ __global__ void k_sk_meta(const uint32_t* __restrict__ order, const uint32_t* __
 		meta[i] = ((uint64_t)sk_mini[order[i]] << 32) | (uint64_t)(uint32_t)len_nt[i];
 }
 
+// kept super-k-mers (flag 1) -> slot[i] of the three output arrays; the last thread publishes the number kept
+__global__ void k_select3(const uint8_t* __restrict__ flag, const uint32_t* __restrict__ slot, uint64_t n, const uint64_t* __restrict__ pos,
+                          const uint64_t* __restrict__ last, const uint32_t* __restrict__ mini, uint64_t* __restrict__ pos2, uint64_t* __restrict__ last2,
+                          uint32_t* __restrict__ mini2, uint64_t* __restrict__ kept)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	if (flag[i]) {
+		const uint32_t o = slot[i];
+		pos2[o] = pos[i];
+		last2[o] = last[i];
+		mini2[o] = mini[i];
+	}
+	if (i == n - 1)
+		*kept = slot[n];
+}
+
 struct MetaLen {  // scan input: the length field of a received super-k-mer's meta word
 	const uint64_t* meta;
 	__device__ uint64_t operator()(uint64_t i) const { return meta[i] & 0xffffffffull; }
@@ -1870,7 +1888,7 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 		shard.id_base = pre[glo];
 		// the super-k-mers of the groups [g0, g1), in input order
 		DevBuf d_flags, d_cnt;
-		BLMX_HIP(d_flags.alloc(nsk + 1, false, s));
+		BLMX_HIP(d_flags.alloc(nsk + 1, true, s));  // (flag[nsk] stays 0: the scan's last output is the number kept)
 		BLMX_HIP(d_cnt.alloc(8, true, s));
 		auto select_groups = [&](uint32_t g0, uint32_t g1, DevBuf& d_pos2, DevBuf& d_last2, DevBuf& d_mini2) -> uint64_t {
 			BLMX_HIP(d_pos2.alloc((nsk + 1) * 8, false, s));
@@ -1880,20 +1898,13 @@ void build_impl(Index& ix, const uint8_t* d_ascii, const uint64_t* d_offs, uint6
 				return 0;
 			hipLaunchKernelGGL(k_shard_flags, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_skmini.as<uint32_t>(), nsk, gshift, g0, g1, d_flags.as<uint8_t>());
 			BLMX_HIP(hipGetLastError());
-			size_t bytes = 0;
-			BLMX_HIP(rocprim::select(nullptr, bytes, d_skpos.as<uint64_t>(), d_flags.as<uint8_t>(), d_pos2.as<uint64_t>(), d_cnt.as<uint64_t>(),
-			                         (size_t)nsk, s));
-			void* tmp = sc.get(bytes);
-			BLMX_HIP(rocprim::select(tmp, bytes, d_skpos.as<uint64_t>(), d_flags.as<uint8_t>(), d_pos2.as<uint64_t>(), d_cnt.as<uint64_t>(),
-			                         (size_t)nsk, s));
-			BLMX_HIP(rocprim::select(tmp, bytes, d_sklast.as<uint64_t>(), d_flags.as<uint8_t>(), d_last2.as<uint64_t>(), d_cnt.as<uint64_t>(),
-			                         (size_t)nsk, s));
-			size_t bytes32 = 0;
-			BLMX_HIP(rocprim::select(nullptr, bytes32, d_skmini.as<uint32_t>(), d_flags.as<uint8_t>(), d_mini2.as<uint32_t>(), d_cnt.as<uint64_t>(),
-			                         (size_t)nsk, s));
-			tmp = sc.get(std::max(bytes, bytes32));
-			BLMX_HIP(rocprim::select(tmp, bytes32, d_skmini.as<uint32_t>(), d_flags.as<uint8_t>(), d_mini2.as<uint32_t>(), d_cnt.as<uint64_t>(),
-			                         (size_t)nsk, s));
+			// stream compaction in input order: exclusive scan of the flags, then every kept super-k-mer moves to its slot
+			uint32_t* d_slot = static_cast<uint32_t*>(sc.get((nsk + 1 + scan_sums_words(nsk + 1)) * 4));
+			exclusive_scan_of<uint32_t>(ScanPlain<uint8_t>{d_flags.as<uint8_t>()}, d_slot, nsk + 1, d_slot + nsk + 1, s);  // (flag[nsk] is 0)
+			hipLaunchKernelGGL(k_select3, dim3(grid_for(nsk)), dim3(kBlock), 0, s, d_flags.as<uint8_t>(), d_slot, nsk, d_skpos.as<uint64_t>(),
+			                   d_sklast.as<uint64_t>(), d_skmini.as<uint32_t>(), d_pos2.as<uint64_t>(), d_last2.as<uint64_t>(), d_mini2.as<uint32_t>(),
+			                   d_cnt.as<uint64_t>());
+			BLMX_HIP(hipGetLastError());
 			return read_scalar(d_cnt.as<uint64_t>(), s);
 		};
 		// ---- halo: the head of what follows this shard in the single index = the first buckets of the groups behind ghi, laid out like
