@@ -23,7 +23,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -1453,35 +1452,42 @@ inline void exclusive_scan_u64(Scratch& sc, uint64_t* in, uint64_t* out, uint64_
 // walks it 64 keys at a time; the lanes of a round that hold the same digit find each other with one ballot per digit bit, the lowest
 // of them adds the group's size to the wave's counter of that digit and hands the old value to the others (rank = old + peers below
 // me); waves are then ordered by a prefix over the four counters.  The tile is staged in LDS in digit order and copied out in runs.
-constexpr int kRsThreads = 256, kRsPer = 32, kRsTile = kRsThreads * kRsPer;
+constexpr int kRsThreads = 256;
 constexpr int kRsMaxBits = 9;
+template <typename K> struct RsShape {  // keys per thread and tile: 8192 32-bit keys or 4096 64-bit ones (the tile is staged in LDS)
+	static constexpr int per = sizeof(K) == 4 ? 32 : 16;
+	static constexpr int tile = kRsThreads * per;
+};
 
-template <int BITS> __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const uint32_t* __restrict__ keys, uint64_t n, int shift, uint32_t nblk, uint32_t* __restrict__ hist)
+template <int BITS, typename K>
+__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const K* __restrict__ keys, uint64_t n, int shift, uint32_t nblk, uint32_t* __restrict__ hist)
 {
-	constexpr int NB = 1 << BITS;
+	constexpr int NB = 1 << BITS, PER = RsShape<K>::per, TILE = RsShape<K>::tile;
 	__shared__ uint32_t s_h[NB];
 	for (int d = threadIdx.x; d < NB; d += kRsThreads)
 		s_h[d] = 0;
 	__syncthreads();
-	const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+	const uint64_t base = (uint64_t)blockIdx.x * TILE;
 #pragma unroll 4
-	for (int e = 0; e < kRsPer; e++) {
+	for (int e = 0; e < PER; e++) {
 		const uint64_t i = base + (uint64_t)e * kRsThreads + threadIdx.x;
 		if (i < n)
-			atomicAdd(&s_h[(keys[i] >> shift) & (NB - 1)], 1u);
+			atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & (NB - 1)], 1u);
 	}
 	__syncthreads();
 	for (int d = threadIdx.x; d < NB; d += kRsThreads)
 		hist[(size_t)d * nblk + blockIdx.x] = s_h[d];  // digit-major: the scan of the matrix gives every (digit, tile) its first output slot
 }
 
-template <int BITS>
-__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /* null: the index itself */,
-                                                         uint64_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblk, uint32_t* __restrict__ keys_out,
-                                                         uint32_t* __restrict__ vals_out)
+template <int BITS, typename K>
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /* null: the index itself */,
+                                                         uint64_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblk, K* __restrict__ keys_out,
+                                                         uint32_t* __restrict__ vals_out /* null: keys only */)
 {
 	constexpr int NB = 1 << BITS, WAVES = kRsThreads / 64, DPT = (NB + kRsThreads - 1) / kRsThreads;  // digits per thread
-	__shared__ uint32_t s_key[kRsTile], s_val[kRsTile];
+	constexpr int PER = RsShape<K>::per, TILE = RsShape<K>::tile;
+	__shared__ K s_key[TILE];
+	__shared__ uint32_t s_val[TILE];
 	__shared__ uint32_t s_wcnt[WAVES][NB];  // keys of a digit in a wave's segment, then the tile-local slot of the segment's first one
 	__shared__ uint32_t s_gb[NB];          // first output slot of (digit, this tile) minus the digit's tile-local start (mod 2^32)
 	__shared__ uint32_t s_w[WAVES];
@@ -1491,16 +1497,16 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t* __res
 		for (int w = 0; w < WAVES; w++)
 			s_wcnt[w][d] = 0;
 	__syncthreads();
-	const uint64_t seg = (uint64_t)blockIdx.x * kRsTile + (uint64_t)wv * (64 * kRsPer);  // this wave's segment: kRsPer rounds of 64 keys
-	uint32_t key[kRsPer];
-	uint16_t rank[kRsPer];
+	const uint64_t seg = (uint64_t)blockIdx.x * TILE + (uint64_t)wv * (64 * PER);  // this wave's segment: PER rounds of 64 keys
+	K key[PER];
+	uint16_t rank[PER];
 	const uint64_t below = (1ull << lane) - 1ull;
 #pragma unroll
-	for (int e = 0; e < kRsPer; e++) {
+	for (int e = 0; e < PER; e++) {
 		const uint64_t i = seg + (uint64_t)e * 64 + lane;
 		const bool valid = i < n;
-		key[e] = valid ? keys_in[i] : 0u;
-		const uint32_t d = (key[e] >> shift) & (NB - 1);
+		key[e] = valid ? keys_in[i] : (K)0;
+		const uint32_t d = (uint32_t)(key[e] >> shift) & (NB - 1);
 		uint64_t peers = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < BITS; b++) {
@@ -1561,56 +1567,61 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t* __res
 	}
 	__syncthreads();
 #pragma unroll
-	for (int e = 0; e < kRsPer; e++) {
+	for (int e = 0; e < PER; e++) {
 		const uint64_t i = seg + (uint64_t)e * 64 + lane;
 		if (i < n) {
-			const uint32_t lp = s_wcnt[wv][(key[e] >> shift) & (NB - 1)] + rank[e];
+			const uint32_t lp = s_wcnt[wv][(uint32_t)(key[e] >> shift) & (NB - 1)] + rank[e];
 			s_key[lp] = key[e];
 			s_val[lp] = vals_in ? vals_in[i] : (uint32_t)i;
 		}
 	}
 	__syncthreads();
-	const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
-	const uint32_t count = (uint32_t)min((uint64_t)kRsTile, n - base);
+	const uint64_t base = (uint64_t)blockIdx.x * TILE;
+	const uint32_t count = (uint32_t)min((uint64_t)TILE, n - base);
 	for (uint32_t j = t; j < count; j += kRsThreads) {
-		const uint32_t kx = s_key[j];
-		const uint32_t pos = s_gb[(kx >> shift) & (NB - 1)] + j;
+		const K kx = s_key[j];
+		const uint32_t pos = s_gb[(uint32_t)(kx >> shift) & (NB - 1)] + j;
 		keys_out[pos] = kx;
-		vals_out[pos] = s_val[j];
+		if (vals_out)
+			vals_out[pos] = s_val[j];
 	}
 }
 
-// keys[0, n) (n < 2^32, `bits` significant bits) -> keys_out sorted, order_out[i] = the input index of the i-th smallest, stable
-void stable_sort_by_key_u32(Scratch& sc, const uint32_t* keys, uint32_t* keys_out, uint32_t* order_out, uint64_t n, unsigned bits, hipStream_t s)
+// keys[0, n) (n < 2^32, `bits` significant bits) -> keys_out sorted by those bits, STABLE; vals_out[i] = vals_in[j] (vals_in null: j
+// itself) for the input index j of the i-th key; vals_out null: keys only
+template <typename K>
+void stable_sort_pairs(Scratch& sc, const K* keys, K* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, unsigned bits, hipStream_t s)
 {
 	if (!n)
 		return;
 	if (bits == 0)
 		bits = 1;
+	constexpr int TILE = RsShape<K>::tile;
 	const int npass = (int)((bits + kRsMaxBits - 1) / kRsMaxBits);
-	const uint32_t nblk = (uint32_t)((n + kRsTile - 1) / kRsTile);
+	const uint32_t nblk = (uint32_t)((n + TILE - 1) / TILE);
 	const size_t hist_words = ((size_t)nblk << kRsMaxBits);
-	const size_t sums_words = (hist_words + kScanTile - 1) / kScanTile + 1;
-	// scratch: [histogram | scan sums | (more than one pass:) a second pair of key / order arrays]
-	const size_t pair_words = npass > 1 ? 2 * ((size_t)n + 1) : 0;
-	uint32_t* d_hist = static_cast<uint32_t*>(sc.get((hist_words + sums_words + pair_words) * 4));
+	const size_t sums_words = scan_sums_words(hist_words);
+	// scratch: [histogram | scan sums | (more than one pass:) a second array of keys and one of values]
+	const size_t kw = sizeof(K) / 4;
+	const size_t pair_words = npass > 1 ? (kw + 1) * ((size_t)n + 2) : 0;
+	uint32_t* d_hist = static_cast<uint32_t*>(sc.get((hist_words + sums_words + pair_words + 2) * 4));
 	uint32_t* d_sums = d_hist + hist_words;
-	uint32_t* tk = d_sums + sums_words;
-	uint32_t* tv = tk + (n + 1);
+	K* tk = reinterpret_cast<K*>(d_sums + ((sums_words + 1) & ~(size_t)1));
+	uint32_t* tv = reinterpret_cast<uint32_t*>(tk + (n + 1));
 	// the passes alternate between the caller's arrays and the temporaries so that the LAST one writes the caller's
-	const uint32_t* kin = keys;
-	const uint32_t* vin = nullptr;
+	const K* kin = keys;
+	const uint32_t* vin = vals_in;
 	for (int p = 0; p < npass; p++) {
 		const int shift = p * kRsMaxBits;
 		const int pb = (int)std::min<unsigned>(kRsMaxBits, bits - (unsigned)shift);
 		const bool to_caller = ((npass - 1 - p) % 2) == 0;
-		uint32_t* kout = to_caller ? keys_out : tk;
-		uint32_t* vout = to_caller ? order_out : tv;
+		K* kout = to_caller ? keys_out : tk;
+		uint32_t* vout = vals_out ? (to_caller ? vals_out : tv) : nullptr;
 #define BLMX_RS(B)                                                                                                                          \
 	case B:                                                                                                                                 \
-		hipLaunchKernelGGL((k_rs_hist<B>), dim3(nblk), dim3(kRsThreads), 0, s, kin, n, shift, nblk, d_hist);                               \
-		exclusive_scan_u32(d_hist, d_hist, (uint64_t)nblk << B, d_sums, s);                                                                         \
-		hipLaunchKernelGGL((k_rs_scatter<B>), dim3(nblk), dim3(kRsThreads), 0, s, kin, vin, n, shift, d_hist, nblk, kout, vout);           \
+		hipLaunchKernelGGL((k_rs_hist<B, K>), dim3(nblk), dim3(kRsThreads), 0, s, kin, n, shift, nblk, d_hist);                            \
+		exclusive_scan_u32(d_hist, d_hist, (uint64_t)nblk << B, d_sums, s);                                                                 \
+		hipLaunchKernelGGL((k_rs_scatter<B, K>), dim3(nblk), dim3(kRsThreads), 0, s, kin, vin, n, shift, d_hist, nblk, kout, vout);        \
 		break;
 		switch (pb) {
 			BLMX_RS(1)
@@ -1628,6 +1639,11 @@ void stable_sort_by_key_u32(Scratch& sc, const uint32_t* keys, uint32_t* keys_ou
 		kin = kout;
 		vin = vout;
 	}
+}
+// 32-bit keys -> sorted keys and the order (the build's shuffle)
+void stable_sort_by_key_u32(Scratch& sc, const uint32_t* keys, uint32_t* keys_out, uint32_t* order_out, uint64_t n, unsigned bits, hipStream_t s)
+{
+	stable_sort_pairs<uint32_t>(sc, keys, keys_out, nullptr, order_out, n, bits, s);
 }
 
 template <typename T> T read_scalar(const T* d, hipStream_t s)
@@ -2495,13 +2511,10 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 		if (Fp) {
 			DevBuf d_fk, d_frank, d_fgrp;
 			BLMX_HIP(d_fbsorted.alloc(Fp * 8, false, s));
-			size_t bytes = 0;
 			unsigned idx_bits = 1;
 			while (idx_bits < 64 && (N >> idx_bits))
 				idx_bits++;
-			BLMX_HIP(rocprim::radix_sort_keys(nullptr, bytes, d_fbmerged.as<uint64_t>(), d_fbsorted.as<uint64_t>(), (size_t)Fp, 0u, idx_bits, s));
-			void* tmp = sc.get(bytes);
-			BLMX_HIP(rocprim::radix_sort_keys(tmp, bytes, d_fbmerged.as<uint64_t>(), d_fbsorted.as<uint64_t>(), (size_t)Fp, 0u, idx_bits, s));
+			stable_sort_pairs<uint64_t>(sc, d_fbmerged.as<uint64_t>(), d_fbsorted.as<uint64_t>(), nullptr, nullptr, Fp, idx_bits, s);
 			BLMX_HIP(d_fk.alloc(Fp * 8 * KW, false, s));
 			BLMX_HIP(d_frank.alloc(Fp * 8, false, s));
 			BLMX_HIP(d_fgrp.alloc(Fp * 4, false, s));
@@ -2519,10 +2532,7 @@ void build_tail(Index& ix, Chopped& chopped, const ShardCtx& shard, PhaseMarks& 
 				BLMX_HIP(d_p0.alloc(Fp * 4, false, s));
 				BLMX_HIP(d_p1.alloc(Fp * 4, false, s));
 				auto sort_by = [&](const uint64_t* kin, const uint32_t* pin, uint32_t* pout, unsigned bits) {
-					size_t nb = 0;
-					BLMX_HIP(rocprim::radix_sort_pairs(nullptr, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)Fp, 0u, bits, s));
-					void* t2 = sc.get(nb);
-					BLMX_HIP(rocprim::radix_sort_pairs(t2, nb, kin, d_k1.as<uint64_t>(), pin, pout, (size_t)Fp, 0u, bits, s));
+					stable_sort_pairs<uint64_t>(sc, kin, d_k1.as<uint64_t>(), pin, pout, Fp, bits, s);
 				};
 				hipLaunchKernelGGL(k_fb_sortkey, dim3(grid_for(Fp)), dim3(kBlock), 0, s, d_fk.as<uint64_t>(), d_fgrp.as<uint32_t>(), (const uint32_t*)nullptr, Fp, KW, 0,
 				                   d_k0.as<uint64_t>(), d_p0.as<uint32_t>());
