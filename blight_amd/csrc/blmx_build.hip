@@ -183,17 +183,6 @@ __global__ __launch_bounds__(kBlock) void k_superkmer_flags(const uint64_t* __re
 	}
 }
 
-struct PopcU64 {
-	__host__ __device__ uint64_t operator()(unsigned long long v) const
-	{
-#if defined(__HIP_DEVICE_COMPILE__)
-		return (uint64_t)__popcll(v);
-#else
-		return (uint64_t)__builtin_popcountll(v);
-#endif
-	}
-};
-
 // ---- K3 ----------------------------------------------------------------------------------------------------------------
 // One lane per bitmap word: scatter the positions of its set bits (heads -> sk_pos, ends -> sk_last = q-1).
 __global__ void k_collect(const unsigned long long* __restrict__ Hb, const unsigned long long* __restrict__ Eb,

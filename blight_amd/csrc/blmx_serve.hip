@@ -163,7 +163,6 @@ __global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (the payload was written before `posted`)
 		// ---- scalar calls of 64-bit k-mers: every watcher answers its own from the polled line
-		bool mine_done = false;
 		int64_t my_id = 0;
 		int32_t my_err = 0;
 		if constexpr (KW == 1) {
@@ -172,11 +171,9 @@ __global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v
 				x.lo = k0;
 				const int64_t id = serve_kmer<1, LOGP>(v, x);
 				my_id = (what & 0x40000000u) ? (int64_t)(id >= 0 ? 1 : 0) : id;
-				mine_done = true;
 			}
 		}
 		// ---- everything else, one request after the other, both waves on each: thread t takes k-mers t, t + 128, ...
-		const bool any_whole = rest != 0;
 		while (rest) {
 			const int src = __ffsll((unsigned long long)rest) - 1;
 			rest &= rest - 1;
@@ -237,7 +234,6 @@ __global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v
 		}
 		// ---- the answer line {ID, done, err}: one 16-byte store per slot.  The results areas were fenced by the threads that wrote them
 		// (above); a wave that had only scalar calls has nothing to fence.
-		(void)any_whole;
 		if (pending) {
 			typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 			const u32x4 ans = {(uint32_t)my_id, (uint32_t)((uint64_t)my_id >> 32), posted, (uint32_t)my_err};
