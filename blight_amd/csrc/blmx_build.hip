@@ -1468,34 +1468,27 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const K* __restrict__ ke
 		hist[(size_t)d * nblk + blockIdx.x] = s_h[d];  // digit-major: the scan of the matrix gives every (digit, tile) its first output slot
 }
 
-template <int BITS, typename K>
-__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /* null: the index itself */,
-                                                         uint64_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblk, K* __restrict__ keys_out,
-                                                         uint32_t* __restrict__ vals_out /* null: keys only */)
+// One tile, one digit: the threads hold the tile's keys and values (wave w the segment [w 64 PER, (w + 1) 64 PER), round e its keys
+// e 64 + lane) and leave them in LDS in digit order, stable.  s_start (may be null) receives the tile-local start of every digit.
+template <int BITS, typename K, int PER>
+__device__ __forceinline__ void rs_tile_sort(const K (&key)[PER], const uint32_t (&val)[PER], uint32_t nloc, int shift, uint32_t dmask, K* __restrict__ s_key,
+                                             uint32_t* __restrict__ s_val, uint32_t (*__restrict__ s_wcnt)[1 << BITS], uint32_t* __restrict__ s_w,
+                                             uint32_t* __restrict__ s_start)
 {
 	constexpr int NB = 1 << BITS, WAVES = kRsThreads / 64, DPT = (NB + kRsThreads - 1) / kRsThreads;  // digits per thread
-	constexpr int PER = RsShape<K>::per, TILE = RsShape<K>::tile;
-	__shared__ K s_key[TILE];
-	__shared__ uint32_t s_val[TILE];
-	__shared__ uint32_t s_wcnt[WAVES][NB];  // keys of a digit in a wave's segment, then the tile-local slot of the segment's first one
-	__shared__ uint32_t s_gb[NB];          // first output slot of (digit, this tile) minus the digit's tile-local start (mod 2^32)
-	__shared__ uint32_t s_w[WAVES];
 	const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
 	for (int d = t; d < NB; d += kRsThreads)
 #pragma unroll
 		for (int w = 0; w < WAVES; w++)
 			s_wcnt[w][d] = 0;
 	__syncthreads();
-	const uint64_t seg = (uint64_t)blockIdx.x * TILE + (uint64_t)wv * (64 * PER);  // this wave's segment: PER rounds of 64 keys
-	K key[PER];
 	uint16_t rank[PER];
 	const uint64_t below = (1ull << lane) - 1ull;
+	const uint32_t seg = wv * (64 * PER);
 #pragma unroll
 	for (int e = 0; e < PER; e++) {
-		const uint64_t i = seg + (uint64_t)e * 64 + lane;
-		const bool valid = i < n;
-		key[e] = valid ? keys_in[i] : (K)0;
-		const uint32_t d = (uint32_t)(key[e] >> shift) & (NB - 1);
+		const bool valid = seg + (uint32_t)e * 64 + lane < nloc;
+		const uint32_t d = (uint32_t)(key[e] >> shift) & dmask;
 		uint64_t peers = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < BITS; b++) {
@@ -1543,7 +1536,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const K* __restrict__
 		for (int j = 0; j < DPT; j++) {
 			const int d = (int)t * DPT + j;
 			if (d < NB) {
-				s_gb[d] = offs[(size_t)d * nblk + blockIdx.x] - at;
+				if (s_start)
+					s_start[d] = at;
 				uint32_t a = at;
 #pragma unroll
 				for (int w = 0; w < WAVES; w++) {
@@ -1557,22 +1551,93 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const K* __restrict__
 	__syncthreads();
 #pragma unroll
 	for (int e = 0; e < PER; e++) {
-		const uint64_t i = seg + (uint64_t)e * 64 + lane;
-		if (i < n) {
-			const uint32_t lp = s_wcnt[wv][(uint32_t)(key[e] >> shift) & (NB - 1)] + rank[e];
+		if (seg + (uint32_t)e * 64 + lane < nloc) {
+			const uint32_t lp = s_wcnt[wv][(uint32_t)(key[e] >> shift) & dmask] + rank[e];
 			s_key[lp] = key[e];
-			s_val[lp] = vals_in ? vals_in[i] : (uint32_t)i;
+			s_val[lp] = val[e];
 		}
 	}
 	__syncthreads();
+}
+
+template <int BITS, typename K>
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /* null: the index itself */,
+                                                         uint64_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblk, K* __restrict__ keys_out,
+                                                         uint32_t* __restrict__ vals_out /* null: keys only */)
+{
+	constexpr int NB = 1 << BITS, WAVES = kRsThreads / 64;
+	constexpr int PER = RsShape<K>::per, TILE = RsShape<K>::tile;
+	__shared__ K s_key[TILE];
+	__shared__ uint32_t s_val[TILE];
+	__shared__ uint32_t s_wcnt[WAVES][NB];  // keys of a digit in a wave's segment, then the tile-local slot of the segment's first one
+	__shared__ uint32_t s_gb[NB];          // tile-local start of the digit, then: first output slot of (digit, this tile) minus that start (mod 2^32)
+	__shared__ uint32_t s_w[WAVES];
+	const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
 	const uint64_t base = (uint64_t)blockIdx.x * TILE;
 	const uint32_t count = (uint32_t)min((uint64_t)TILE, n - base);
+	K key[PER];
+	uint32_t val[PER];
+#pragma unroll
+	for (int e = 0; e < PER; e++) {
+		const uint32_t l = wv * (64 * PER) + (uint32_t)e * 64 + lane;
+		key[e] = l < count ? keys_in[base + l] : (K)0;
+		val[e] = l < count ? (vals_in ? vals_in[base + l] : (uint32_t)(base + l)) : 0u;
+	}
+	rs_tile_sort<BITS, K, PER>(key, val, count, shift, (uint32_t)NB - 1u, s_key, s_val, s_wcnt, s_w, s_gb);
+	for (int d = t; d < NB; d += kRsThreads)
+		s_gb[d] = offs[(size_t)d * nblk + blockIdx.x] - s_gb[d];
+	__syncthreads();
 	for (uint32_t j = t; j < count; j += kRsThreads) {
 		const K kx = s_key[j];
 		const uint32_t pos = s_gb[(uint32_t)(kx >> shift) & (NB - 1)] + j;
 		keys_out[pos] = kx;
 		if (vals_out)
 			vals_out[pos] = s_val[j];
+	}
+}
+
+// up to one tile of keys: every pass inside ONE workgroup, the tile going back and forth between registers and LDS (a fallback table of a
+// few hundred entries took 8 passes x 5 launches through the kernels above)
+template <typename K>
+__global__ __launch_bounds__(kRsThreads) void k_rs_small(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n, unsigned bits,
+                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+	constexpr int BITS = kRsMaxBits, NB = 1 << BITS, WAVES = kRsThreads / 64;
+	constexpr int PER = RsShape<K>::per, TILE = RsShape<K>::tile;
+	__shared__ K s_key[TILE];
+	__shared__ uint32_t s_val[TILE];
+	__shared__ uint32_t s_wcnt[WAVES][NB];
+	__shared__ uint32_t s_w[WAVES];
+	const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+	K key[PER];
+	uint32_t val[PER];
+#pragma unroll
+	for (int e = 0; e < PER; e++) {
+		const uint32_t l = wv * (64 * PER) + (uint32_t)e * 64 + lane;
+		key[e] = l < n ? keys_in[l] : (K)0;
+		val[e] = l < n ? (vals_in ? vals_in[l] : l) : 0u;
+	}
+	for (unsigned shift = 0; shift < bits; shift += BITS) {
+		const unsigned pb = min((unsigned)BITS, bits - shift);
+		rs_tile_sort<BITS, K, PER>(key, val, n, (int)shift, (1u << pb) - 1u, s_key, s_val, s_wcnt, s_w, nullptr);
+#pragma unroll
+		for (int e = 0; e < PER; e++) {
+			const uint32_t l = wv * (64 * PER) + (uint32_t)e * 64 + lane;
+			if (l < n) {
+				key[e] = s_key[l];
+				val[e] = s_val[l];
+			}
+		}
+		__syncthreads();
+	}
+#pragma unroll
+	for (int e = 0; e < PER; e++) {
+		const uint32_t l = wv * (64 * PER) + (uint32_t)e * 64 + lane;
+		if (l < n) {
+			keys_out[l] = key[e];
+			if (vals_out)
+				vals_out[l] = val[e];
+		}
 	}
 }
 
@@ -1586,6 +1651,11 @@ void stable_sort_pairs(Scratch& sc, const K* keys, K* keys_out, const uint32_t* 
 	if (bits == 0)
 		bits = 1;
 	constexpr int TILE = RsShape<K>::tile;
+	if (n <= (uint64_t)TILE) {
+		hipLaunchKernelGGL((k_rs_small<K>), dim3(1), dim3(kRsThreads), 0, s, keys, vals_in, (uint32_t)n, bits, keys_out, vals_out);
+		BLMX_HIP(hipGetLastError());
+		return;
+	}
 	const int npass = (int)((bits + kRsMaxBits - 1) / kRsMaxBits);
 	const uint32_t nblk = (uint32_t)((n + TILE - 1) / TILE);
 	const size_t hist_words = ((size_t)nblk << kRsMaxBits);
