@@ -76,6 +76,24 @@ __device__ __forceinline__ int64_t serve_kmer(const DeviceIndexView& v, Kmer<KW>
 	return id;
 }
 
+// The minimizer of ONE 64-bit k-mer by 16 lanes (a scalar call has nothing else for them to do): lane `sub` of the group hashes the
+// windows sub and sub + 16 (k - m <= 31), then a 16-lane minimum -- ~60 instructions deep instead of the ~340 of kmer_minimizer on
+// one lane, half a microsecond of a call's eight.  Same windows, same strand rule, same signed order (device_prims.h: kmer_minimizer).
+__device__ __forceinline__ uint32_t kmer_minimizer_by16(Kmer<1> x, Kmer<1> xr, int k, int m, uint32_t sub)
+{
+	const uint32_t mask = (m >= 16) ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+	const int w = k - m;
+	int32_t best = 0x7fffffff;
+	for (int i = (int)sub; i <= w; i += 16) {
+		const uint32_t f = kmer_shr32(x, 2 * i), r = kmer_shr32(xr, 2 * (w - i));
+		const uint32_t sel = (__popc(f & mask) & 1) ? f : r;  // the strand with odd parity (ParityCanonical, kmer.h:475-487)
+		best = min(best, revhash32(__builtin_amdgcn_ubfe(sel, 1u, (uint32_t)(2 * m - 1))));
+	}
+	for (int o = 8; o >= 1; o >>= 1)
+		best = min(best, __shfl_xor(best, o, 16));
+	return unrevhash32((uint32_t)best);
+}
+
 // what the waves of one serving kernel share (device memory): they leave TOGETHER -- wave 0 decides, from the time ANY wave last served
 // a request -- so that "a kernel is there" means every slot is being watched (a wave that left alone would strand its four slots)
 struct BurstShared {
@@ -166,11 +184,24 @@ __global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v
 		int64_t my_id = 0;
 		int32_t my_err = 0;
 		if constexpr (KW == 1) {
-			if (pending && (what & 0xbfffffffu) == 1u) {
-				Kmer<1> x;
-				x.lo = k0;
-				const int64_t id = serve_kmer<1, LOGP>(v, x);
-				my_id = (what & 0x40000000u) ? (int64_t)(id >= 0 ? 1 : 0) : id;
+			const bool scalar = pending && (what & 0xbfffffffu) == 1u;
+			if (wv == 0 && __ballot(scalar)) {  // (wave-uniform: the 16 lanes [16 l, 16 l + 16) work on watcher l's k-mer)
+				const int src = (int)(lane >> 4);
+				Kmer<1> gx;
+				gx.lo = (uint64_t)(uint32_t)__shfl((int)(uint32_t)k0, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k0 >> 32), src) << 32);
+				const Kmer<1> gxr = kmer_rc<1>(gx, v.k);
+				const uint32_t gmini = kmer_minimizer_by16(gx, gxr, v.k, v.m, lane & 15u);
+				const uint32_t mini = (uint32_t)__shfl((int)gmini, (int)((lane & 3u) << 4));  // watcher l takes its group's
+				if (scalar) {
+					Kmer<1> x;
+					x.lo = k0;
+					const Kmer<1> xr = kmer_rc<1>(x, v.k);
+					int64_t id = -1;
+					int32_t posj;
+					if (!(xr < x))  // (a non-canonical k-mer matches nothing: blight.cpp:733-735)
+						query_one<1, LOGP, false>(v, x, xr, mini, id, posj);
+					my_id = (what & 0x40000000u) ? (int64_t)(id >= 0 ? 1 : 0) : id;
+				}
 			}
 		}
 		// ---- everything else, one request after the other, both waves on each: thread t takes k-mers t, t + 128, ...
