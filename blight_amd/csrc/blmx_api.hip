@@ -891,7 +891,7 @@ int blmx_stats(const blmx_index* h, blmx_stats_t* out)
 	if (!h || !out)
 		return BLMX_EINVAL;
 	*out = h->ix.st;
-	out->number_query = h->ix.number_query.load(std::memory_order_relaxed);
+	out->number_query = h->ix.number_query.load(std::memory_order_relaxed) + burst_number_query(h->ix);
 	out->nbuckets = h->ix.nbuckets;
 	out->ngroups = h->ix.ngroups;
 	out->k = h->ix.prm.k;

@@ -325,6 +325,8 @@ namespace {
 
 HostFront& host_front(Index& ix)
 {
+	if (HostFront* have = __atomic_load_n(&ix.hf, __ATOMIC_ACQUIRE))  // (small calls come from many threads: no lock once it exists)
+		return *have;
 	std::lock_guard<std::mutex> l(ix.hf_mu);
 	if (!ix.hf) {
 		std::unique_ptr<HostFront> hf(new HostFront());
@@ -335,7 +337,7 @@ HostFront& host_front(Index& ix)
 		unsigned nt = e ? (unsigned)atoi(e) : (hw && hw < 16 ? hw : 16u);
 		nt = nt < 1 ? 1u : (nt > 64 ? 64u : nt);
 		hf->pool.reset(new WorkerPool(nt));
-		ix.hf = hf.release();
+		__atomic_store_n(&ix.hf, hf.release(), __ATOMIC_RELEASE);
 	}
 	return *ix.hf;
 }
@@ -708,11 +710,11 @@ void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets
 		return;
 	if (!ids_out)
 		throw StatusError{BLMX_EINVAL, "ids_out is null"};
+	if (nseq == 1 && burst_query_sequence(ix, concat + a0, total - a0, nk_all, ids_out))  // one read: the serving burst (blmx_serve.hip)
+		return;
 	BLMX_HIP(hipSetDevice(ix.prm.device));
 	HostFront& hf = host_front(ix);
 	// ---- one launch on a pinned slot
-	if (nseq == 1 && burst_query_sequence(ix, concat + a0, total - a0, nk_all, ids_out))  // one read: the serving burst (blmx_serve.hip)
-		return;
 	if (total - a0 <= kSmallChars && nseq <= kSmallSeqs && nk_all <= 48000 && read_query_fusable(ix)) {
 		SmallReq rq;  // answered by ONE launch together with whatever other callers are waiting (combine_small)
 		rq.kind = SmallReq::kSequences;
@@ -930,12 +932,12 @@ void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint6
 		throw StatusError{BLMX_ESTATE, "index not built"};
 	if (nq == 0)
 		return;
+	if (!minis && (mode == kQueryIds || mode == kQueryBool) && burst_query_kmers(ix, kmers, nq, out, mode == kQueryBool))  // blmx_serve.hip
+		return;
 	BLMX_HIP(hipSetDevice(ix.prm.device));
 	HostFront& hf = host_front(ix);
 	const size_t kb = (size_t)ix.KW * 8;
 	const size_t ob = mode == kQueryIds ? 8 : (mode == kQueryPos ? 4 : 1);
-	if (!minis && (mode == kQueryIds || mode == kQueryBool) && burst_query_kmers(ix, kmers, nq, out, mode == kQueryBool))  // blmx_serve.hip
-		return;
 	if (nq <= kSmallKmers && !minis && (mode == kQueryIds || mode == kQueryBool) && ix.prm.bits_saved <= 8) {
 		SmallReq rq;  // scalar calls of the facade land here: answered by ONE launch together with whatever other callers are waiting
 		rq.kind = SmallReq::kKmers;

@@ -705,6 +705,7 @@ bool burst_query_sequence(Index& ix, const char* chars, uint64_t nbytes, uint64_
 void burst_stop(Index& ix);
 void burst_destroy(Index& ix);
 void burst_stats(Index& ix, uint64_t out[4]);
+uint64_t burst_number_query(const Index& ix);  // k-mers the burst answered (kept per slot, added to number_query when it is read)
 // host-buffer entry points (blmx_stream.hip): pinned staging, windows in flight, small-call slots
 void query_sequences_host(Index& ix, const char* concat, const uint64_t* offsets, uint64_t nseq, int64_t* ids_out);
 void query_kmers_host(Index& ix, const void* kmers, const uint32_t* minis, uint64_t nq, void* out, QueryMode mode);

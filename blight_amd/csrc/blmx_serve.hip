@@ -6,8 +6,14 @@
 // the reference.  Here the first caller launches a small serving kernel that STAYS while requests keep arriving:
 //
 //   * a ring of request slots in pinned host memory (64 slots of 16 KiB); a caller claims a slot, writes its k-mers or its read, then
-//     the slot's sequence number -- one 16-byte line that also carries the first k-mer, so a scalar call costs the kernel one read
-//     over PCIe --, and spins on the slot's `done` word;
+//     POSTS the request on the request board: one 16-byte line per slot {first k-mer | sequence number, kind} -- a scalar call needs
+//     nothing else -- and spins on the slot's `done` word.  The board is a piece of the pinned ring; the host's stop word is one of its
+//     lines and comes with the same load instruction (ONE read over PCIe per poll; r04 before: two, one behind the other).
+//     BLIGHT_SERVE_BOARD=device puts the board into DEVICE memory that the host writes through the PCIe BAR (two posted 8-byte writes,
+//     the k-mer first): the kernel's poll is then a local load.  tools/pingpong_probe says that saves 0.3-1 us of a bare round trip
+//     (profiles/r04_pingpong_probe.jsonl); on the real path it does not pay -- three runs each on one box, 8 callers: 1.34-1.49e6
+//     scalar q/s with the board in device memory, 1.50-1.63e6 in pinned memory (the host's fenced stores into the write-combining
+//     mapping cost the callers more than the wave's PCIe read) -- so it is an option, not the default;
 //   * 16 workgroups of two waves: wave 0 polls four slots (system-scope loads) and answers scalar calls by itself; for a read or a
 //     k-mer list both waves work -- the query body of the batch kernels (query_device.h: same filter, same MPHF probes, same scan),
 //     one thread per k-mer; a read is 2-bit packed into LDS first and every thread takes the k-mers at its positions --, store the
@@ -26,7 +32,9 @@
 
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <fcntl.h>
 #include <immintrin.h>
+#include <unistd.h>
 
 #include "blmx_internal.h"
 #include "query_device.h"
@@ -42,11 +50,13 @@ constexpr uint32_t kBurstMaxChars = 1536, kBurstMaxKmers = 128;
 constexpr uint32_t kBurstMaxIds = (uint32_t)((kBurstSlotBytes - kBurstResultsAt) / 8);  // 1784
 static_assert(kBurstMaxChars <= kBurstPayloadBytes && kBurstMaxKmers * 16 <= kBurstPayloadBytes && kBurstMaxChars <= kBurstMaxIds, "slot layout");
 
-// the first 64 bytes of a slot.  Host writes [8, 24) and the payload, then `posted`; the device writes the results, err, then `done`.
+// the first 64 bytes of a slot.  The host writes the payload and then posts the request on the board (below); the device writes the
+// results, err, then `done`.  `what` of a board line: bit 31: a read (characters), else k-mers; bit 30: membership bytes wanted; low
+// bits: characters / k-mers.
 struct BurstHead {
-	uint32_t posted;    // sequence number of the request in the slot (host; 0 = never used)
-	uint32_t what;      // bit 31: a read (characters), else k-mers; bit 30: membership bytes wanted; low bits: characters / k-mers
-	uint64_t kmer0[2];  // the first k-mer (scalar calls need nothing else)
+	uint32_t posted_unused;  // (before the board the request was posted here)
+	uint32_t what_unused;
+	uint64_t kmer0_unused[2];
 	uint32_t pad0[2];
 	// the answer line: ONE aligned 16-byte store of the device = one write over PCIe, no fence in front of it for a scalar call
 	int64_t id0;        // the ID (or 0 / 1 for a membership call) of a scalar call of a 64-bit k-mer; other calls: results area
@@ -58,10 +68,19 @@ static_assert(offsetof(BurstHead, id0) == 32, "the answer is one aligned 16-byte
 static_assert(sizeof(BurstHead) == 64, "BurstHead");
 
 struct BurstCtrl {  // one line of pinned memory next to the ring
-	uint32_t stop;          // host: leave now
+	uint32_t unused;
 	uint32_t exited_gen;    // device: generation of the last kernel whose waves have all left
 	uint32_t pad[14];
 };
+
+// The request board: kBurstSlots + 1 lines of 16 bytes.  Line i < kBurstSlots = {u64 first k-mer (low word) | u32 posted, u32 what} of slot i;
+// the last line = {0 | u32 stop, 0}: the host tells the waves to leave.  The host writes a line as TWO 8-byte stores with a store fence
+// between them, the half that carries the sequence number last: 8-byte stores are single transactions on every mapping (a 16-byte store
+// through a write-combining mapping need not be), and posted writes stay in order -- a poll can see a new k-mer behind an old
+// sequence number (not posted yet), never the reverse.
+constexpr size_t kBoardLine = 16, kBoardBytes = 4096;
+constexpr uint32_t kBoardStopLine = kBurstSlots;
+static_assert((kBurstSlots + 1) * kBoardLine <= kBoardBytes, "board");
 
 template <int KW, int LOGP>
 __device__ __forceinline__ int64_t serve_kmer(const DeviceIndexView& v, Kmer<KW> x)
@@ -106,8 +125,8 @@ constexpr uint32_t kBurstThreads = 128;  // the polling wave + one helper wave t
 
 template <int KW, int LOGP>
 __global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v0, uint8_t* __restrict__ ring, BurstCtrl* __restrict__ ctrl,
-                                                              BurstShared* __restrict__ sh, uint32_t gen, uint32_t idle_ticks, uint32_t max_ticks,
-                                                              uint32_t max_polls)
+                                                              const uint8_t* __restrict__ board, BurstShared* __restrict__ sh, uint32_t gen,
+                                                              uint32_t idle_ticks, uint32_t max_ticks, uint32_t max_polls)
 {
 	__shared__ uint64_t s_seq[kBurstMaxChars / 32 + 8];  // a read, 2-bit packed, first nucleotide most significant (like the index's text)
 	__shared__ uint32_t s_bad;
@@ -120,7 +139,10 @@ __global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, wave = blockIdx.x;
 	// lane l < kBurstPerWave of wave 0 watches slot wave + l * kBurstWaves
 	const bool watcher = wv == 0 && lane < kBurstPerWave;
-	uint8_t* my_slot = ring + (size_t)(wave + (watcher ? lane : 0) * kBurstWaves) * kBurstSlotBytes;
+	const bool poller = watcher || (wv == 0 && lane == 63);  // lane 63 reads the stop line with the same instruction
+	const uint32_t my_index = wave + (watcher ? lane : 0) * kBurstWaves;
+	uint8_t* my_slot = ring + (size_t)my_index * kBurstSlotBytes;
+	const uint8_t* my_line = board + (size_t)(lane == 63 ? kBoardStopLine : my_index) * kBoardLine;
 	uint32_t served = 0;
 	if (watcher)  // what was answered before this kernel started stays answered
 		served = __hip_atomic_load(&reinterpret_cast<BurstHead*>(my_slot)->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -133,16 +155,17 @@ __global__ __launch_bounds__(kBurstThreads) void k_serve_burst(DeviceIndexView v
 		uint64_t k0 = 0;
 		bool pending = false;
 		if (wv == 0) {
-			// ---- poll: ONE 16-byte read per watched slot (one PCIe read: a consistent picture of the line) brings the sequence number,
-			// the kind and the first k-mer (low word)
+			// ---- poll: ONE 16-byte read per watched board line brings the first k-mer (low word), the sequence number and the kind; lane 63
+			// reads the host's stop word in the same instruction (one memory round trip per poll, local when the board is in device memory)
+			uint4 q = make_uint4(0u, 0u, 0u, 0u);
+			if (poller)
+				asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(my_line) : "memory");
 			if (watcher) {
-				uint4 q;
-				asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(my_slot) : "memory");
-				posted = q.x;
-				what = q.y;
-				k0 = (uint64_t)q.z | ((uint64_t)q.w << 32);
+				k0 = (uint64_t)q.x | ((uint64_t)q.y << 32);
+				posted = q.z;
+				what = q.w;
 			}
-			const uint32_t stop = lane == 63 ? __hip_atomic_load(&ctrl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+			const uint32_t stop = lane == 63 ? q.z : 0u;
 			pending = watcher && posted != served;
 			const uint64_t pend = __ballot(pending);
 			// Wave 0 of workgroup 0 looks at the clock for all of them (idle since ANY workgroup's last request, or the kernel's own time
@@ -297,15 +320,44 @@ struct BurstState {
 	hipStream_t s = nullptr;
 	std::mutex launch_mu;
 	std::atomic<uint32_t> launched_gen{0};
-	std::atomic<uint32_t> busy[kBurstSlots];
+	// what the callers of one slot share, on a line of its own: eight OpenMP callers at a million calls a second must not pass one cache
+	// line around (r04: the slots' busy words sat side by side, and every call also took the index's mutex twice and bumped two shared
+	// counters -- the callers spent more time on each other than on the GPU)
+	struct alignas(64) SlotState {
+		std::atomic<uint32_t> busy{0};
+		uint32_t seq = 0;
+		std::atomic<uint64_t> calls{0};
+		std::atomic<uint64_t> kmers{0};  // k-mers answered through this slot: part of the index's number_query (burst_number_query)
+	};
+	SlotState st[kBurstSlots];
 	std::atomic<uint32_t> next_hint{0};
-	uint32_t seq[kBurstSlots] = {};
-	std::atomic<uint64_t> launches{0}, calls{0}, relaunch_after_timeout{0}, relaunch_after_exit{0};
-	uint32_t idle_us = 60, max_ms = 20;
-	BurstState()
+	std::atomic<uint64_t> launches{0}, relaunch_after_timeout{0}, relaunch_after_exit{0};
+	uint64_t calls_total() const
 	{
-		for (auto& b : busy)
-			b.store(0);
+		uint64_t n = 0;
+		for (const auto& x : st)
+			n += x.calls.load(std::memory_order_relaxed);
+		return n;
+	}
+	uint32_t idle_us = 60, max_ms = 20;
+	uint8_t* board = nullptr;     // the request board: device memory behind the BAR, or (fallback) a piece of the pinned ring
+	void* board_dev = nullptr;    // the device allocation, when the board is there
+	BurstState() = default;
+	~BurstState()
+	{
+		if (board_dev)
+			(void)hipFree(board_dev);
+	}
+	// one board line: the half with the sequence number (or the stop word) last, a store fence in front of either half -- the payload in
+	// the pinned slot is globally visible before the k-mer, the k-mer before the sequence number (see kBoardLine)
+	void board_write(uint32_t line, uint64_t w0, uint64_t w1)
+	{
+		volatile uint64_t* p = reinterpret_cast<volatile uint64_t*>(board + (size_t)line * kBoardLine);
+		_mm_sfence();
+		p[0] = w0;
+		_mm_sfence();
+		p[1] = w1;
+		_mm_sfence();
 	}
 	uint8_t* slot(uint32_t i) { return ring.as<uint8_t>() + (size_t)i * kBurstSlotBytes; }
 	BurstCtrl* ctrl() { return reinterpret_cast<BurstCtrl*>(ring.as<uint8_t>() + (size_t)kBurstSlots * kBurstSlotBytes); }
@@ -320,6 +372,8 @@ namespace {
 
 BurstState* burst_state(Index& ix)
 {
+	if (BurstState* have = __atomic_load_n(&ix.burst, __ATOMIC_ACQUIRE))
+		return have;
 	std::lock_guard<std::mutex> l(ix.hf_mu);
 	if (!ix.burst) {
 		std::unique_ptr<BurstState> b(new BurstState());
@@ -328,11 +382,35 @@ BurstState* burst_state(Index& ix)
 		BLMX_HIP(hipStreamCreateWithFlags(&b->s, hipStreamNonBlocking));
 		BLMX_HIP(b->left.alloc(64, true, b->s));
 		BLMX_HIP(hipStreamSynchronize(b->s));
+		// The request board: a piece of the pinned ring, or (BLIGHT_SERVE_BOARD=device) device memory, if THIS process can store into it
+		// (large BAR).  Asked without a signal: the kernel is made to store into the page -- read(2) from /dev/zero -- and an address the
+		// process cannot write is EFAULT there; the board then stays in the pinned ring.
+		b->board = b->ring.as<uint8_t>() + (size_t)kBurstSlots * kBurstSlotBytes + 2048;
+		const char* where = getenv("BLIGHT_SERVE_BOARD");
+		if (where && !strcmp(where, "device")) {
+			void* d = nullptr;
+			if (hipExtMallocWithFlags(&d, kBoardBytes, hipDeviceMallocUncached) == hipSuccess && d) {
+				bool ok = hipMemsetAsync(d, 0, kBoardBytes, b->s) == hipSuccess && hipStreamSynchronize(b->s) == hipSuccess;
+				if (ok) {
+					const int fd = open("/dev/zero", O_RDONLY | O_CLOEXEC);
+					ok = fd >= 0 && read(fd, d, kBoardBytes) == (ssize_t)kBoardBytes;
+					if (fd >= 0)
+						close(fd);
+				}
+				if (ok) {
+					b->board_dev = d;
+					b->board = reinterpret_cast<uint8_t*>(d);
+				} else {
+					(void)hipFree(d);
+				}
+			}
+			(void)hipGetLastError();
+		}
 		if (const char* e = getenv("BLIGHT_SERVE_IDLE_US"))
 			b->idle_us = (uint32_t)std::max(1, atoi(e));
 		if (const char* e = getenv("BLIGHT_SERVE_MAX_MS"))
 			b->max_ms = (uint32_t)std::max(1, atoi(e));
-		ix.burst = b.release();
+		__atomic_store_n(&ix.burst, b.release(), __ATOMIC_RELEASE);
 	}
 	return ix.burst;
 }
@@ -344,7 +422,7 @@ template <int KW> void launch_burst_kw(const Index& ix, BurstState& b, uint32_t 
 	const uint32_t idle_ticks = b.idle_us * 100u, max_ticks = b.max_ms * 100000u, max_polls = b.max_ms * 4000u + 1000u;
 #define BLMX_SV(LP)                                                                                                                                    \
 	case LP:                                                                                                                                           \
-		hipLaunchKernelGGL((k_serve_burst<KW, LP>), dim3(kBurstWaves), dim3(kBurstThreads), 0, b.s, v, b.ring.as<uint8_t>(), b.ctrl(), b.left.as<BurstShared>(), gen, \
+		hipLaunchKernelGGL((k_serve_burst<KW, LP>), dim3(kBurstWaves), dim3(kBurstThreads), 0, b.s, v, b.ring.as<uint8_t>(), b.ctrl(), b.board, b.left.as<BurstShared>(), gen, \
 		                   idle_ticks, max_ticks, max_polls);                                                                                          \
 		break;
 	switch (v.b) {
@@ -373,7 +451,7 @@ void ensure_burst(Index& ix, BurstState& b)
 	if (b.alive())
 		return;
 	BLMX_HIP(hipSetDevice(ix.prm.device));
-	__atomic_store_n(&b.ctrl()->stop, 0u, __ATOMIC_RELEASE);
+	b.board_write(kBoardStopLine, 0, 0);
 	uint32_t gen = b.launched_gen.load(std::memory_order_relaxed) + 1;
 	if (gen == 0)
 		gen = 1;
@@ -385,14 +463,22 @@ void ensure_burst(Index& ix, BurstState& b)
 	b.launches.fetch_add(1, std::memory_order_relaxed);
 }
 
+// A thread goes back to the slot it had last time (nobody else touches that line then); the first call of a thread, or one that finds
+// its slot taken, draws the next one -- consecutive slots belong to different serving waves.
 int claim_slot(BurstState& b)
 {
+	thread_local uint32_t mine = 0xffffffffu;
+	uint32_t z = 0;
+	if (mine < kBurstSlots && b.st[mine].busy.compare_exchange_strong(z, 1u, std::memory_order_acquire))
+		return (int)mine;
 	const uint32_t h = b.next_hint.fetch_add(1, std::memory_order_relaxed);
 	for (uint32_t i = 0; i < kBurstSlots; i++) {
 		const uint32_t sidx = (h + i) % kBurstSlots;
-		uint32_t z = 0;
-		if (b.busy[sidx].compare_exchange_strong(z, 1u, std::memory_order_acquire))
+		z = 0;
+		if (b.st[sidx].busy.compare_exchange_strong(z, 1u, std::memory_order_acquire)) {
+			mine = sidx;
 			return (int)sidx;
+		}
 	}
 	return -1;
 }
@@ -401,13 +487,11 @@ int claim_slot(BurstState& b)
 void post_and_wait(Index& ix, BurstState& b, int si, uint32_t what, const uint64_t kmer0[2])
 {
 	BurstHead* h = reinterpret_cast<BurstHead*>(b.slot((uint32_t)si));
-	uint32_t seq = ++b.seq[si];
+	uint32_t seq = ++b.st[si].seq;
 	if (seq == 0)
-		seq = ++b.seq[si];
-	h->what = what;
-	h->kmer0[0] = kmer0[0];
-	h->kmer0[1] = kmer0[1];
-	__atomic_store_n(&h->posted, seq, __ATOMIC_RELEASE);
+		seq = ++b.st[si].seq;
+	(void)kmer0[1];  // (the high word of a 128-bit k-mer travels in the payload)
+	b.board_write((uint32_t)si, kmer0[0], (uint64_t)seq | ((uint64_t)what << 32));
 	ensure_burst(ix, b);
 	const auto t0 = std::chrono::steady_clock::now();
 	auto deadline = t0 + std::chrono::microseconds(200);
@@ -440,7 +524,7 @@ void post_and_wait(Index& ix, BurstState& b, int si, uint32_t what, const uint64
 struct SlotLease {
 	BurstState& b;
 	int si;
-	~SlotLease() { b.busy[si].store(0, std::memory_order_release); }
+	~SlotLease() { b.st[si].busy.store(0, std::memory_order_release); }
 };
 
 }  // namespace
@@ -473,8 +557,8 @@ bool burst_query_kmers(Index& ix, const void* kmers, uint64_t n, void* out, bool
 	} else {
 		memcpy(out, slot + kBurstResultsAt, want_bool ? n : n * 8);
 	}
-	ix.number_query.fetch_add(n, std::memory_order_relaxed);
-	b.calls.fetch_add(1, std::memory_order_relaxed);
+	b.st[si].kmers.fetch_add(n, std::memory_order_relaxed);
+	b.st[si].calls.fetch_add(1, std::memory_order_relaxed);
 	return true;
 }
 
@@ -496,8 +580,8 @@ bool burst_query_sequence(Index& ix, const char* chars, uint64_t nbytes, uint64_
 	if (reinterpret_cast<BurstHead*>(slot)->err)
 		throw StatusError{BLMX_EDNA, "Invalid char in DNA"};
 	memcpy(out, slot + kBurstResultsAt, nk * 8);
-	ix.number_query.fetch_add(nk, std::memory_order_relaxed);
-	b.calls.fetch_add(1, std::memory_order_relaxed);
+	b.st[si].kmers.fetch_add(nk, std::memory_order_relaxed);
+	b.st[si].calls.fetch_add(1, std::memory_order_relaxed);
 	return true;
 }
 
@@ -510,7 +594,7 @@ void burst_stop(Index& ix)
 	std::lock_guard<std::mutex> l(b->launch_mu);
 	if (!b->alive())
 		return;
-	__atomic_store_n(&b->ctrl()->stop, 1u, __ATOMIC_RELEASE);
+	b->board_write(kBoardStopLine, 0, 1);
 	const auto t0 = std::chrono::steady_clock::now();
 	while (b->alive() && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
 		_mm_pause();
@@ -522,9 +606,9 @@ void burst_destroy(Index& ix)
 	if (!ix.burst)
 		return;
 	burst_stop(ix);
-	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) != 0 && ix.burst->calls.load())
+	if (getenv("BLIGHT_TRACE") && atoi(getenv("BLIGHT_TRACE")) != 0 && ix.burst->calls_total())
 		fprintf(stderr, "[blmx serve] %llu calls answered by %llu serving kernels (%llu launched by a caller that saw the kernel gone, %llu after a caller's 200-us deadline)\n",
-		        (unsigned long long)ix.burst->calls.load(), (unsigned long long)ix.burst->launches.load(),
+		        (unsigned long long)ix.burst->calls_total(), (unsigned long long)ix.burst->launches.load(),
 		        (unsigned long long)ix.burst->relaunch_after_exit.load(), (unsigned long long)ix.burst->relaunch_after_timeout.load());
 	if (ix.burst->s) {
 		(void)hipStreamSynchronize(ix.burst->s);
@@ -534,6 +618,17 @@ void burst_destroy(Index& ix)
 	ix.burst = nullptr;
 }
 
+// k-mers answered by the burst: they are counted per slot, not on the index's shared counter (blmx_stats adds them)
+uint64_t burst_number_query(const Index& ix)
+{
+	const BurstState* b = __atomic_load_n(&ix.burst, __ATOMIC_ACQUIRE);
+	uint64_t n = 0;
+	if (b)
+		for (const auto& x : b->st)
+			n += x.kmers.load(std::memory_order_relaxed);
+	return n;
+}
+
 // what the tests look at: {kernels launched, calls answered, relaunches by a waiting caller (kernel gone / deadline), 1 if a kernel is there now}
 void burst_stats(Index& ix, uint64_t out[4])
 {
@@ -541,7 +636,7 @@ void burst_stats(Index& ix, uint64_t out[4])
 	if (!ix.burst)
 		return;
 	out[0] = ix.burst->launches.load();
-	out[1] = ix.burst->calls.load();
+	out[1] = ix.burst->calls_total();
 	out[2] = ix.burst->relaunch_after_timeout.load() + ix.burst->relaunch_after_exit.load();
 	out[3] = ix.burst->alive() ? 1 : 0;
 }

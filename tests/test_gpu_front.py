@@ -409,14 +409,18 @@ def test_partition_paths_and_skewed_batches(B, O, k, kb, b):
     assert np.array_equal(ix.query_kmer_hash(half.reshape(-1)), wants["uniform"][: len(half)])
 
 
-def test_serving_burst_answers_small_calls_and_leaves(B, O):
+@pytest.mark.parametrize("board", ["pinned", "device"])
+def test_serving_burst_answers_small_calls_and_leaves(B, O, board, monkeypatch):
     """Small calls -- one k-mer, a few k-mers, one read: the reference's calling pattern (blight.cpp:537-550, 575-591) -- are answered by
     a BOUNDED serving kernel that polls a request ring in pinned memory (blmx_serve.hip).  Every answer equals the oracle's (64- and
     128-bit k-mers, membership, reads with and without invalid characters, from eight threads at once); the kernel is gone within
     its idle bound once the calls stop, the next call simply starts the next one; with serve_burst = 0 the same calls take one launch
-    per round and give the same answers."""
+    per round and give the same answers.  `board`: where the kernel looks for posted requests -- a piece of the pinned ring (default), or
+    device memory that the host writes through the PCIe BAR (BLIGHT_SERVE_BOARD=device; falls back to pinned memory by itself where
+    the process cannot store into device memory)."""
     import time
-    for (k, kb, m, n, b) in ((31, 8, 9, 6, 6), (63, 16, 9, 5, 8), (21, 8, 7, 3, 2)):
+    monkeypatch.setenv("BLIGHT_SERVE_BOARD", board)  # (read when an index starts its first serving kernel)
+    for (k, kb, m, n, b) in ((31, 8, 9, 6, 6), (63, 16, 9, 5, 8), (21, 8, 7, 3, 2))[: 3 if board == "pinned" else 2]:
         ix, orc, seqs, rng = _index(B, O, k, m, n, b, kb, 23 + k, nseq=600)
         ix.set_tuning("absent_filter", 1)
         pos = np.concatenate([orc.canonical_kmers(s).reshape(-1, kb // 8) for s in seqs[:40]])
