@@ -836,34 +836,49 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_level_sliced(BuildGroups b
 	if (threadIdx.x == 0)
 		s_in = s_set = s_cnt = 0;
 	__syncthreads();
-	// mark (processLevel_, bbhash.h:677-709) + count the keys that fall into this slice; four keys in flight per thread (the walk
-	// is a stream of dependent-free loads: one per iteration left the CU at a few GB/s)
-	constexpr uint32_t kIlp = 4;
+	// mark (processLevel_, bbhash.h:677-709) + count the keys that fall into this slice.  The walk is a stream of dependent-free loads
+	// and every slice of the group walks ALL of the group's bit indices: 16-byte loads, two per thread in flight (r04 before: 4-byte
+	// loads, four in flight -- 16 KB in flight per CU is 4 GB/s per workgroup, and the giant groups of the skewed inputs spent 25 ms in
+	// level 0 alone).  [0, head) and [tail0, count): the few indices in front of / behind the 16-byte-aligned quads.
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	constexpr uint32_t kIlp = 2;
 	const uint32_t* __restrict__ mybits = lbits + kb;  // bit index of the i-th key of the group's current list (k_sliced_level_bits)
 	(void)keys;
-	const uint32_t rounds = (count + kGroupBlock * kIlp - 1) / (kGroupBlock * kIlp);
+	const uint32_t head = min(count, (4u - (uint32_t)((reinterpret_cast<uintptr_t>(mybits) >> 2) & 3u)) & 3u);
+	const uint32_t nquads = (count - head) >> 2, tail0 = head + (nquads << 2);
+	const u32x4* __restrict__ quads = reinterpret_cast<const u32x4*>(mybits + head);
+	const uint32_t rounds = (nquads + kGroupBlock * kIlp - 1) / (kGroupBlock * kIlp);
 	uint32_t mine = 0;
+	auto mark = [&](uint32_t b) {
+		const uint32_t lw = (b >> 5) - w0;
+		if (lw < wn) {
+			const uint32_t m = 1u << (b & 31);
+			if (atomicOr(&s_bits[lw], m) & m)
+				atomicOr(&s_coll[lw], m);
+			mine++;
+		}
+	};
+	if (threadIdx.x < head)
+		mark(mybits[threadIdx.x]);
+	if (tail0 + threadIdx.x < count)
+		mark(mybits[tail0 + threadIdx.x]);
 	for (uint32_t r = 0; r < rounds; r++) {
-		uint32_t bitv[kIlp];
+		u32x4 qv[kIlp];
 		bool in[kIlp];
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
-			const uint32_t i = (r * kIlp + u) * kGroupBlock + threadIdx.x;
-			in[u] = i < count;
-			bitv[u] = in[u] ? mybits[i] : 0;
+			const uint32_t q = (r * kIlp + u) * kGroupBlock + threadIdx.x;
+			in[u] = q < nquads;
+			qv[u] = in[u] ? quads[q] : u32x4{0u, 0u, 0u, 0u};
 		}
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
 			if (!in[u])
 				continue;
-			const uint32_t b = bitv[u];
-			const uint32_t lw = (b >> 5) - w0;
-			if (lw < wn) {
-				const uint32_t m = 1u << (b & 31);
-				if (atomicOr(&s_bits[lw], m) & m)
-					atomicOr(&s_coll[lw], m);
-				mine++;
-			}
+			mark(qv[u].x);
+			mark(qv[u].y);
+			mark(qv[u].z);
+			mark(qv[u].w);
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1)
@@ -890,36 +905,46 @@ __global__ __launch_bounds__(kGroupBlock) void k_mphf_level_sliced(BuildGroups b
 	if (threadIdx.x == 0)
 		s_base = atomicAdd(&lvcnt[(uint64_t)(level + 1) * bg.ngroups + g], nsurv);
 	__syncthreads();
+	// the survivors (keys whose bit collided) go to the group's next list: one LDS atomic per wave and element, called by whole waves
+	auto emit = [&](bool surv, uint32_t idx) {
+		const unsigned long long bal = __ballot(surv);
+		if (bal) {
+			const uint32_t lane = threadIdx.x & 63;
+			uint32_t base = 0;
+			const int leader = __ffsll(bal) - 1;
+			if ((int)lane == leader)
+				base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
+			base = __shfl(base, leader);
+			if (surv)  // (the key's index: only survivors read the list)
+				nxt[s_base + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = level == 0 ? idx : cur[idx];
+		}
+	};
+	auto collided = [&](uint32_t b) {
+		const uint32_t lw = (b >> 5) - w0;
+		return lw < wn && ((s_coll[lw] >> (b & 31)) & 1u);
+	};
+	{
+		const bool h = threadIdx.x < head, t = tail0 + threadIdx.x < count;
+		emit(h && collided(mybits[h ? threadIdx.x : 0]), threadIdx.x);
+		emit(t && collided(mybits[t ? tail0 + threadIdx.x : 0]), tail0 + threadIdx.x);
+	}
 	for (uint32_t r = 0; r < rounds; r++) {
-		uint32_t bitv[kIlp];
-		uint32_t ii[kIlp];
+		u32x4 qv[kIlp];
+		uint32_t qi[kIlp];
 		bool in[kIlp];
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
-			const uint32_t i = (r * kIlp + u) * kGroupBlock + threadIdx.x;
-			in[u] = i < count;
-			ii[u] = i;
-			bitv[u] = in[u] ? mybits[i] : 0;
+			const uint32_t q = (r * kIlp + u) * kGroupBlock + threadIdx.x;
+			in[u] = q < nquads;
+			qi[u] = head + (q << 2);
+			qv[u] = in[u] ? quads[q] : u32x4{0u, 0u, 0u, 0u};
 		}
 #pragma unroll
 		for (uint32_t u = 0; u < kIlp; u++) {
-			bool surv = false;
-			if (in[u]) {
-				const uint32_t b = bitv[u];
-				const uint32_t lw = (b >> 5) - w0;
-				surv = lw < wn && ((s_coll[lw] >> (b & 31)) & 1u);
-			}
-			const unsigned long long bal = __ballot(surv);
-			if (bal) {
-				const uint32_t lane = threadIdx.x & 63;
-				uint32_t base = 0;
-				const int leader = __ffsll(bal) - 1;
-				if ((int)lane == leader)
-					base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
-				base = __shfl(base, leader);
-				if (surv)  // (the key's index: only survivors read the list)
-					nxt[s_base + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = level == 0 ? ii[u] : cur[ii[u]];
-			}
+			emit(in[u] && collided(qv[u].x), qi[u]);
+			emit(in[u] && collided(qv[u].y), qi[u] + 1);
+			emit(in[u] && collided(qv[u].z), qi[u] + 2);
+			emit(in[u] && collided(qv[u].w), qi[u] + 3);
 		}
 	}
 }
