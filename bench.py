@@ -764,6 +764,24 @@ def main():
     multi = world > 1 or args.rehearse_sharded  # a process group exists and the sharded code path runs
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL has no timeout: a collective that a peer never joins would leave this run hanging until somebody kills it, and the
+        # native exchange has never met a second GPU.  A run of N ranks takes one to two minutes; after
+        # BLIGHT_BENCH_WATCHDOG_S (default 900) seconds every rank gives up by itself, and rank 0 leaves a line that says so.
+        import threading
+        limit_s = float(os.environ.get("BLIGHT_BENCH_WATCHDOG_S", "900"))
+
+        def give_up():
+            log("rank %d: no result after %.0f s: a collective is stuck (RCCL has no timeout); giving up" % (rank, limit_s))
+            if rank == 0:
+                print(json.dumps({"metric": "kmer_id_queries_per_sec", "value": None, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+                                  "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                                  "data": "synthetic", "error": "watchdog: the run did not finish within %.0f s (a stuck collective); no number was measured" % limit_s}),
+                      flush=True)
+            os._exit(4)
+        if limit_s > 0:
+            wd = threading.Timer(limit_s, give_up)
+            wd.daemon = True
+            wd.start()
         if world == 1:
             import socket
             sk = socket.socket()
