@@ -222,3 +222,18 @@ def test_shard_query_cpp_loopback_ranks(tmp_path, world):
     assert sum(r["reads"] for r in res) == len(reads)
     assert (sum(r["kmers"] for r in res), sum(r["found"] for r in res), sum(r["absent"] for r in res)) == (kmers, found, absent)
     assert sum(r["checksum"] for r in res) % (1 << 64) == checksum
+
+
+def test_bench_watchdog_ends_a_run_that_does_not_finish():
+    """RCCL has no timeout: an N > 1 run of bench.py whose collective never completes must not hang until somebody kills it.  The
+    watchdog (BLIGHT_BENCH_WATCHDOG_S) ends every rank by itself and rank 0 leaves one JSON line with a null value and the reason.
+    Driven here through the world-1 rehearsal of the N > 1 code path with a limit far below the time the workload takes."""
+    import json
+    import sys
+    env = dict(os.environ, BLIGHT_BENCH_WATCHDOG_S="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-sharded", "--workload", "C3", "--cpu-seconds", "0", "--reads", "0",
+                        "--no-fasta-leg", "--no-host-legs", "--steps", "200000", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 4, (r.returncode, r.stderr[-400:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and "watchdog" in line["error"]
+    assert "giving up" in r.stderr
