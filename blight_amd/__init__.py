@@ -526,7 +526,7 @@ class Comm:
         return self._lib.blmx_comm_transport(self._c).decode()
 
     def set_tuning(self, key, value):
-        """"flow_words" / "pieces" (see blmx_comm_set_tuning); the same on every rank"""
+        """"flow_words" / "pieces" / "ship_minimizers" (see blmx_comm_set_tuning); the same on every rank"""
         rc = self._lib.blmx_comm_set_tuning(self._c, key.encode(), int(value))
         if rc:
             _raise(rc, self._lib.blmx_last_error(None).decode() or "blmx_comm_set_tuning failed")

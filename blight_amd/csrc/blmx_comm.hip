@@ -449,6 +449,12 @@ struct Comm {
 	// ranks whose flows are shorter simply take part in fewer rounds).  See kFlowWords.
 	uint64_t flow_words;
 	int pieces = 0;            // pieces of a query batch (software pipeline); 0 = BLIGHT_DIST_CHUNKS or 2.  The same on every rank.
+	// Do the minimizers of a slot range travel with its k-mers (4 of the 12 bytes a slot costs on the wire), or does the owner hash the
+	// k-mers it receives again (query_slot without a minimizer array: ~340 vector instructions per k-mer inside a kernel that waits for
+	// memory)?  -1 = by the size of the world: with 2 to 7 ranks a GPU pushes 1/2 ... 1/7 of every batch through ONE link and the
+	// exchange is predicted link-bound, so the bytes matter more than the owner's instructions; from 8 ranks on the
+	// links are predicted to keep up and the minimizers travel.  0 / 1 force it.  The same on every rank (checked in the count exchange).
+	int ship_minis = -1;
 	hipStream_t cs = nullptr;  // the exchange runs on this stream, next to the caller's compute stream
 	hipEvent_t ev_part[kMaxPieces] = {}, ev_k[kMaxPieces] = {}, ev_q[kMaxPieces] = {}, ev_i[kMaxPieces] = {};
 	DevBuf sorted[kMaxPieces], inv[kMaxPieces], recv_k[kMaxPieces], recv_m[kMaxPieces], recv_h[kMaxPieces], ids_remote[kMaxPieces], ids_sorted[kMaxPieces];
@@ -535,6 +541,8 @@ void comm_set_tuning(Comm& c, const char* key, int64_t value)
 		c.flow_words = (uint64_t)value;
 	} else if (k == "pieces") {
 		c.pieces = value < 0 ? 0 : (value > kMaxPieces ? kMaxPieces : (int)value);
+	} else if (k == "ship_minimizers") {
+		c.ship_minis = value < 0 ? -1 : (value ? 1 : 0);
 	} else {
 		throw StatusError{BLMX_EINVAL, "unknown communicator tuning key"};
 	}
@@ -709,7 +717,12 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 	// the flows (ID width, number of pieces: per-rank settings that must agree) and one "cannot take part" flag in one all-gather
 	const bool narrow = ix.tune_narrow_ids && ix.st.number_kmer < 0xffffffffull;
 	const size_t idw = narrow ? 1 : 2;  // 32-bit words per slot of a returned slot range
-	const size_t per_piece = (size_t)world + 1 + 4, per_rank = (size_t)pieces * per_piece + 3;
+	const char* e_ship = getenv("BLIGHT_DIST_SHIP_MINIMIZERS");
+	const int ship_set = c.ship_minis >= 0 ? c.ship_minis : (e_ship ? (atoi(e_ship) != 0) : -1);
+	const bool ship = ship_set >= 0 ? ship_set != 0 : world >= 8;
+	// (the table has room for kMaxPieces pieces whatever `pieces` is here: ranks that disagree on it must still gather tables of ONE size --
+	// an all-gather whose ranks name different lengths is a hang on RCCL, not an error)
+	const size_t per_piece = (size_t)world + 1 + 4, per_rank = (size_t)kMaxPieces * per_piece + 4;
 	std::vector<uint64_t> mine(per_rank, 0), all(per_rank * world, 0);
 	for (int p = 0; p < pieces; p++) {
 		uint64_t* mp = &mine[(size_t)p * per_piece];
@@ -723,6 +736,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 		mp[world + 3] = c.recv_h[p].bytes;
 		mp[world + 4] = c.ids_remote[p].bytes;
 	}
+	mine[per_rank - 4] = ship ? 1 : 0;
 	mine[per_rank - 3] = narrow ? 1 : 0;
 	mine[per_rank - 2] = (uint64_t)pieces;
 	mine[per_rank - 1] = local.code != BLMX_OK;
@@ -735,8 +749,10 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 			throw StatusError{BLMX_ERCCL, "sharded query: another rank could not take part"};
 		}
 	for (uint32_t r = 0; r < world; r++)  // (every rank sees the same table: all of them give up together, before any flow is posted)
-		if (all[(size_t)r * per_rank + per_rank - 3] != (narrow ? 1u : 0u) || all[(size_t)r * per_rank + per_rank - 2] != (uint64_t)pieces)
-			throw StatusError{BLMX_EINVAL, "sharded query: the ranks disagree on the ID width (narrow_ids) or on the number of pieces (BLIGHT_DIST_CHUNKS / comm tuning)"};
+		if (all[(size_t)r * per_rank + per_rank - 3] != (narrow ? 1u : 0u) || all[(size_t)r * per_rank + per_rank - 2] != (uint64_t)pieces ||
+		    all[(size_t)r * per_rank + per_rank - 4] != (ship ? 1u : 0u))
+			throw StatusError{BLMX_EINVAL, "sharded query: the ranks disagree on the ID width (narrow_ids), on the number of pieces (BLIGHT_DIST_CHUNKS / comm tuning) "
+			                               "or on whether minimizers travel (BLIGHT_DIST_SHIP_MINIMIZERS / comm tuning)"};
 	auto fmt_of = [&](uint32_t r, int p) { return all[(size_t)r * per_rank + (size_t)p * per_piece] != 0; };
 	auto cnt_of = [&](uint32_t r, int p, uint32_t d) { return all[(size_t)r * per_rank + (size_t)p * per_piece + 1 + d]; };
 	auto cap_of = [&](uint32_t r, int p, int which) { return all[(size_t)r * per_rank + (size_t)p * per_piece + world + 1 + which]; };
@@ -765,12 +781,12 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 			const bool self = r == who;
 			// out: what `who` sends to owner r
 			f.ks[r] = (out_slots && self) ? 0 : out_n;                               // k-mers (slots or dense), KW words each
-			f.ms[r] = (out_slots && !self) ? out_n / 2 : 0;                          // minimizers, two per word
+			f.ms[r] = (ship && out_slots && !self) ? out_n / 2 : 0;                  // minimizers, two per word (ship: they travel at all)
 			f.hs[r] = (out_slots && !self) ? (uint64_t)slot_owner_bins(ix, r) + 1 : 0;
 			f.ir[r] = out_slots ? (self ? 0 : out_n * idw / 2) : out_n;              // IDs that come back from owner r (words)
 			// in: what sender r holds for `who`
 			f.kr[r] = (in_slots && self) ? 0 : in_n;
-			f.mr[r] = (in_slots && !self) ? in_n / 2 : 0;
+			f.mr[r] = (ship && in_slots && !self) ? in_n / 2 : 0;
 			f.hr[r] = (in_slots && !self) ? (uint64_t)who_nb + 1 : 0;
 			f.is[r] = in_slots ? (self ? 0 : in_n * idw / 2) : in_n;
 			f.recv_k_words += f.kr[r] * kw;
@@ -867,7 +883,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 					fs.hdr = c.sp[p].hdr.as<uint64_t>() + c.sp[p].first_bin[me];
 				} else {
 					fs.slots = c.recv_k[p].as<uint64_t>() + ko;
-					fs.minis = reinterpret_cast<const uint32_t*>(c.recv_m[p].as<uint64_t>() + mo);
+					fs.minis = ship ? reinterpret_cast<const uint32_t*>(c.recv_m[p].as<uint64_t>() + mo) : nullptr;  // (null: the owner hashes the k-mers again)
 					fs.ids = c.ids_remote[p].as<uint64_t>() + io;
 					fs.hdr = c.recv_h[p].as<uint64_t>() + ho;
 				}

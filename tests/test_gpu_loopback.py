@@ -100,10 +100,14 @@ def test_native_exchange_on_the_loopback_transport(world, k, m, n, b, tmp_path):
     # ---- the query exchange: 1..4 pieces, whole flows and flows cut into many ragged rounds; pieces that travel densely (the exact
     # partition: the first batch of an index, small pieces) and as bin regions of the one-pass partition (slot_piece_min lowered so that
     # these small batches qualify; rank 0 keeps the default, i.e. sends densely while the others send regions: formats mix)
-    for pieces, flow_words, slot_min in ((2, 1 << 25, 0), (1, 997, 2000), (3, 4099, 2000), (4, 1 << 25, 2000), (2, 1 << 25, 2000)):
+    # ship: do the minimizers of a slot range travel with its k-mers, or does the owner hash what it receives again (-1: by the size of
+    # the world, the default)
+    for pieces, flow_words, slot_min, ship in ((2, 1 << 25, 0, -1), (1, 997, 2000, 1), (3, 4099, 2000, 0), (4, 1 << 25, 2000, 1), (2, 1 << 25, 2000, 0),
+                                               (2, 1 << 25, 2000, -1)):
         for r, c in enumerate(comms):
             c.set_tuning("pieces", pieces)
             c.set_tuning("flow_words", flow_words)
+            c.set_tuning("ship_minimizers", ship)
             ixs[r].set_tuning("slot_piece_min", slot_min if (r > 0 or pieces == 2) else 0)
 
         def query(r):
@@ -271,5 +275,60 @@ def test_a_rank_that_never_arrives_kills_the_group_not_the_process(monkeypatch):
             comms[r].query_kmers_sharded_device(shards[r], q.data_ptr(), 5000, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert time.time() - t0 < 1.0  # at once: no second deadline
     torch.cuda.synchronize()
+    for c in comms:
+        c.close()
+
+
+def test_ranks_that_disagree_on_a_flow_setting_fail_together():
+    """The ID width, the number of pieces and whether minimizers travel size the flows of the exchange; they are per-rank settings.  Ranks
+    that disagree would post sends and receives of different lengths (RCCL: a hang).  The count exchange carries the settings: every rank
+    sees the same table and fails with the same error before a flow is posted -- and the same communicators answer again once they agree."""
+    import torch
+    import blight_amd as B
+    rng = np.random.default_rng(5)
+    k, m, n, b = 31, 9, 6, 6
+    seqs = [_rand_seq(rng, 200) for _ in range(800)]
+    single = B.kmer_Set_Light(k, m, n, 3, 1, b)
+    single.construct_index_from_sequences(seqs)
+    shards = []
+    for r in range(2):
+        a = B.kmer_Set_Light(k, m, n, 3, 1, b)
+        a.set_shard(r, 2)
+        a.construct_index_from_sequences(seqs)
+        a.set_tuning("slot_piece_min", 2000)
+        shards.append(a)
+    uid = B.comm_loopback_id()
+    comms = [None, None]
+
+    def mk(r):
+        comms[r] = B.Comm(uid, r, 2, device=0)
+    run_ranks(2, mk)
+    dev = torch.device("cuda", 0)
+    from oracle import oracle as O
+    orc = O.Oracle(k, m, n, b, seqs)
+    q_np = np.concatenate([orc.canonical_kmers(s).reshape(-1) for s in seqs[:60]] + [rng.integers(0, 1 << 61, 3000, dtype=np.uint64)])
+    q = torch.from_numpy(np.ascontiguousarray(q_np).view(np.int64)).to(dev)
+    want = single.query_kmer_hash(np.ascontiguousarray(q_np))
+    outs = [torch.empty(q.numel(), dtype=torch.int64, device=dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def query(r):
+        comms[r].query_kmers_sharded_device(shards[r], q.data_ptr(), q.numel(), outs[r].data_ptr(), streams[r].cuda_stream)
+        streams[r].synchronize()
+        return outs[r].cpu().numpy()
+
+    for key, values in (("ship_minimizers", (1, 0)), ("pieces", (1, 2))):
+        for r in range(2):
+            comms[r].set_tuning(key, values[r])
+        got, err = run_ranks(2, query)
+        assert all(e is not None and "disagree" in str(e) for e in err), err
+        for r in range(2):
+            comms[r].set_tuning(key, values[0])
+        for _ in range(2):  # (the second batch goes through the learnt regions)
+            got, err = run_ranks(2, query)
+            assert not any(err), err
+            for r in range(2):
+                assert np.array_equal(got[r], want)
     for c in comms:
         c.close()
