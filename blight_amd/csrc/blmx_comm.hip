@@ -451,9 +451,10 @@ struct Comm {
 	int pieces = 0;            // pieces of a query batch (software pipeline); 0 = BLIGHT_DIST_CHUNKS or 2.  The same on every rank.
 	// Do the minimizers of a slot range travel with its k-mers (4 of the 12 bytes a slot costs on the wire), or does the owner hash the
 	// k-mers it receives again (query_slot without a minimizer array: ~340 vector instructions per k-mer inside a kernel that waits for
-	// memory)?  -1 = by the size of the world: with 2 to 7 ranks a GPU pushes 1/2 ... 1/7 of every batch through ONE link and the
-	// exchange is predicted link-bound, so the bytes matter more than the owner's instructions; from 8 ranks on the
-	// links are predicted to keep up and the minimizers travel.  0 / 1 force it.  The same on every rank (checked in the count exchange).
+	// memory)?  -1 / 0: they stay home -- even on the loopback transport, whose wire is a device copy, the exchange is faster without
+	// them at every world size (C4, world 2 / 4 / 8: 6.13 / 6.85 / 8.9 ms per step against 6.35 / 7.15 / 9.8,
+	// profiles/r04_loopback_rehearsal_c4.txt), and a real link is slower than a device copy.  1: they travel.  The same on every rank
+	// (checked in the count exchange).
 	int ship_minis = -1;
 	hipStream_t cs = nullptr;  // the exchange runs on this stream, next to the caller's compute stream
 	hipEvent_t ev_part[kMaxPieces] = {}, ev_k[kMaxPieces] = {}, ev_q[kMaxPieces] = {}, ev_i[kMaxPieces] = {};
@@ -719,7 +720,7 @@ void query_kmers_sharded(Index& ix, Comm& c, const void* d_kmers, const uint32_t
 	const size_t idw = narrow ? 1 : 2;  // 32-bit words per slot of a returned slot range
 	const char* e_ship = getenv("BLIGHT_DIST_SHIP_MINIMIZERS");
 	const int ship_set = c.ship_minis >= 0 ? c.ship_minis : (e_ship ? (atoi(e_ship) != 0) : -1);
-	const bool ship = ship_set >= 0 ? ship_set != 0 : world >= 8;
+	const bool ship = ship_set > 0;
 	// (the table has room for kMaxPieces pieces whatever `pieces` is here: ranks that disagree on it must still gather tables of ONE size --
 	// an all-gather whose ranks name different lengths is a hang on RCCL, not an error)
 	const size_t per_piece = (size_t)world + 1 + 4, per_rank = (size_t)kMaxPieces * per_piece + 4;

@@ -235,8 +235,8 @@ const char* blmx_comm_transport(const blmx_comm* c);
 /* Communicator knobs; set the same value on every rank.  "flow_words": pairwise flows of the all-to-all-v are cut into rounds of at
  * most this many 8-byte words (default 2^25 = 256 MiB).  "pieces": pieces of a query batch that run as a software pipeline
  * (1..4; 0 = the environment's BLIGHT_DIST_CHUNKS, or 2).  "ship_minimizers": 1 = the minimizers of a slot range travel with its
- * k-mers (12 bytes per slot on the wire), 0 = the owner hashes the k-mers it receives again (8 bytes), -1 = by the size of the world
- * (they travel from 8 ranks on; BLIGHT_DIST_SHIP_MINIMIZERS overrides). */
+ * k-mers (12 bytes per slot on the wire), 0 = the owner hashes the k-mers it receives again (8 bytes; the default, also -1;
+ * BLIGHT_DIST_SHIP_MINIMIZERS sets it where the communicator does not). */
 int blmx_comm_set_tuning(blmx_comm* c, const char* key, int64_t value);
 int blmx_comm_create(const void* id, uint32_t rank, uint32_t world, int device, blmx_comm** out);
 void blmx_comm_destroy(blmx_comm* c);
