@@ -1155,6 +1155,13 @@ def main():
                                 "ends half the queries after one line, and `traffic_frac` is what the counters say the kernel really moved"}
         if multi:
             out["exchange"] = "native-rccl" if comm is not None else ("torch.distributed" if querier is not None else "replicas")
+            if comm is not None:
+                # what a slot costs on the wire (the prediction a SCALE record is read against): regions are 6 % + 256 slots
+                # per bin larger than their content; (N - 1) / N of every batch travels, over N - 1 links
+                ship = os.environ.get("BLIGHT_DIST_SHIP_MINIMIZERS", "0") not in ("", "0")
+                out["exchange_wire"] = {"out_bytes_per_slot": 8 * kw + (4 if ship else 0), "back_bytes_per_slot": 4 if st["number_kmer"] < (1 << 32) - 1 else 8,
+                                        "minimizers_travel": ship, "region_slack": "6 % + 256 slots per bin",
+                                        "fraction_of_a_batch_that_travels": (world - 1) / world if world > 1 else 0.0}
         if args.mode == "sharded" and multi and not sharded:
             out["sharded_fallback"] = effective_mode
         orc = None
